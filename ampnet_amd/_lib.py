@@ -1,0 +1,69 @@
+"""ctypes binding of libampconv.so (C ABI declared in include/ampconv.h).
+
+The product path has no fallback: if the shared library is missing or does not
+export a symbol, importing/using the HIP path raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libampconv.so')
+
+AMPCONV_F32 = 0
+AMPCONV_BF16 = 1
+COLSUM_BLOCKS = 1024      # scratch blocks of ampconv_masked_colsum (csrc/node_ops.hip)
+
+
+class View(ctypes.Structure):
+    """ampconv_view_t: element (n, l, h, c) at ptr + n*node + l*row + h*head + c."""
+    _fields_ = [('ptr', ctypes.c_void_p), ('node_stride', ctypes.c_int64),
+                ('row_stride', ctypes.c_int64), ('head_stride', ctypes.c_int64)]
+
+
+_vp, _i64, _i32, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/ampconv.h one to one
+SIGNATURES = {
+    'ampconv_version': (_i32, []),
+    'ampconv_error_string': (ctypes.c_char_p, [_i32]),
+    'ampconv_csr_workspace_bytes': (_sz, [_i64, _i64]),
+    'ampconv_csr_build': (_i32, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'ampconv_fwd_edge': (_i32, [View, View, View, _vp, _vp, _vp, _i64, _i32, _i32, _i32, View, _i32, _vp]),
+    'ampconv_bwd_edge_dst': (_i32, [View, View, View, View, _vp, _vp, _i64, _i32, _i32, _i32, View, _i32, _vp]),
+    'ampconv_bwd_edge_src': (_i32, [View, View, View, View, _vp, _vp, _vp, _i64, _i32, _i32, _i32,
+                                    View, View, _i32, _vp]),
+    'ampconv_attn_weights': (_i32, [View, View, _vp, _i64, _i32, _i32, _i32, _vp, _i32, _vp]),
+    'ampconv_segment_mean': (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _vp]),
+    'ampconv_mask_rows': (_i32, [_vp, _vp, _i64, _i64, _vp]),
+    'ampconv_masked_colsum': (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, _vp]),
+}
+
+_lib = None
+
+
+class AmpconvError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libampconv.so once; raise (never fall back) if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AmpconvError(
+            f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            '(hipcc --offload-arch=gfx950). ampnet_amd has no non-HIP fallback.')
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)           # AttributeError if the export is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().ampconv_error_string(rc)
+        raise AmpconvError(f'{what} failed: {msg.decode() if msg else rc} (code {rc})')

@@ -1,0 +1,182 @@
+"""AMPConv -- drop-in for reference src/ampnet/conv/amp_conv.py:9-51 on MI355X.
+
+Same constructor, method names, attribute names and state-dict keys as the
+reference class:
+
+    AMPConv(embed_dim, num_heads)                       amp_conv.py:10
+    .forward(x, edge_index) -> [N, L*D]                 amp_conv.py:24-26
+    .message(x_i, x_j)      -> [E, L*D]                 amp_conv.py:28-51
+    .aggregate(inputs, index, dim_size=N) (aggr='mean') amp_conv.py:11
+    .multi_head_attention   (nn.MultiheadAttention: parameter container, identical
+                             init and keys `multi_head_attention.in_proj_weight` ...)
+    .attn_output [E, L, D], .attn_output_weights [E, L, L]   amp_conv.py:12-13,39
+
+All arithmetic runs in libampconv.so (hand-written HIP for gfx950) plus dense
+GEMMs on the per-node rows; there is no CPU or eager fallback -- inputs that are
+not on the GPU, or a missing shared library, raise.
+"""
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from ..graph import EdgeCSR, graph_cache
+from . import functional as F_
+
+try:                                            # PyG is optional (absent in the build image)
+    from torch_geometric.nn import MessagePassing as _PyGMessagePassing
+except Exception:                               # pragma: no cover - depends on the environment
+    _PyGMessagePassing = None
+
+
+class InvalidConfiguration(ValueError, RuntimeError):
+    """x.shape[1] is not a multiple of embed_dim (the reference prints
+    "Error, invalid configuration" and then torch.reshape raises RuntimeError,
+    amp_conv.py:32-35)."""
+
+
+class _MessagePassingBase(nn.Module):
+    """Minimal stand-in with PyG's method names when torch_geometric is absent."""
+
+    def __init__(self, aggr='mean'):
+        super().__init__()
+        self.aggr = aggr
+
+    def update(self, inputs):
+        return inputs
+
+
+MessagePassing = _PyGMessagePassing if _PyGMessagePassing is not None else _MessagePassingBase
+
+
+class AMPConv(MessagePassing):
+    def __init__(self, embed_dim, num_heads):
+        super().__init__(aggr='mean')
+        self._attn_ctx = None
+        self._attn_output = None
+        self._attn_output_weights = None
+        self.retain_attention = True            # keep what the lazy per-edge outputs need
+        self.num_heads = num_heads
+        self.embed_dim = embed_dim
+        # parameter container only: same init RNG consumption and state-dict keys as the reference
+        self.multi_head_attention = nn.MultiheadAttention(
+            embed_dim=embed_dim, num_heads=num_heads, batch_first=True, bias=True)
+
+    # ------------------------------------------------------------------ checks
+    def _check_x(self, x, name='x'):
+        if x.dim() != 2:
+            raise ValueError(f'{name} must be [num_nodes, L*embed_dim], got {tuple(x.shape)}')
+        if x.shape[1] % self.embed_dim != 0:
+            print("Error, invalid configuration")           # amp_conv.py:32-33
+            raise InvalidConfiguration(
+                f'{name}.shape[1]={x.shape[1]} is not a multiple of embed_dim={self.embed_dim}')
+        if not x.is_cuda:
+            raise ValueError('ampnet_amd.AMPConv runs on the GPU only (no CPU fallback): '
+                             f'{name} is on {x.device}')
+        if x.dtype != torch.float32:
+            raise ValueError(f'{name} must be float32, got {x.dtype}')
+        p = self.multi_head_attention.in_proj_weight
+        if p.device != x.device:
+            raise ValueError(f'parameters are on {p.device} but {name} is on {x.device}')
+
+    def _params(self):
+        m = self.multi_head_attention
+        return m.in_proj_weight, m.in_proj_bias, m.out_proj.weight, m.out_proj.bias
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x, edge_index):
+        out = self.propagate(edge_index, x=x)
+        return out
+
+    def propagate(self, edge_index, size=None, **kwargs):
+        """Fused gather -> attention -> mean -> out-projection (one pass, HIP)."""
+        x = kwargs['x']
+        self._check_x(x)
+        _lib.load()
+        if edge_index.device != x.device:
+            raise ValueError(f'edge_index is on {edge_index.device} but x is on {x.device}')
+        csr = graph_cache.get(edge_index, x.size(0))
+        y, qkv, _ = F_.AMPConvFunction.apply(x, x, *self._params(), csr, self.num_heads, True)
+        L = x.size(1) // self.embed_dim
+        self._set_attn_ctx(qkv, None, edge_index, L, shared=True)
+        return y
+
+    def message(self, x_i, x_j):
+        """Pass messages from nodes x_j to nodes x_i: per-edge cross-attention of the
+        pre-gathered pairs, [E, L*D] (amp_conv.py:28-51)."""
+        self._check_x(x_i, 'x_i')
+        self._check_x(x_j, 'x_j')
+        if x_i.shape != x_j.shape:
+            raise ValueError(f'x_i {tuple(x_i.shape)} and x_j {tuple(x_j.shape)} differ')
+        E = x_i.size(0)
+        csr = EdgeCSR.identity(E, x_i.device)
+        y, q, kv = F_.AMPConvFunction.apply(x_i, x_j, *self._params(), csr, self.num_heads, False)
+        ar = torch.arange(E, dtype=torch.int64, device=x_i.device)
+        L = x_i.size(1) // self.embed_dim
+        self._set_attn_ctx(q, kv, torch.stack([ar, ar]), L, shared=False)
+        self._attn_output = y.view(E, L, self.embed_dim)
+        return y
+
+    def aggregate(self, inputs, index, ptr=None, dim_size=None):
+        """aggr='mean' scatter of [E, F] messages to dim_size rows (zero rows where
+        nothing arrives; testing_message_passing_pyg.py:37-40)."""
+        if not inputs.is_cuda:
+            raise ValueError('ampnet_amd.AMPConv runs on the GPU only (no CPU fallback)')
+        n = int(dim_size) if dim_size is not None else int(index.max().item()) + 1
+        ar = torch.arange(index.numel(), dtype=torch.int64, device=index.device)
+        csr = EdgeCSR(torch.stack([ar % n, index.to(torch.int64)]), n)
+        return F_.segment_mean(inputs.to(torch.float32), csr)
+
+    # ------------------------------------------------------------------ lazy per-edge outputs
+    def _set_attn_ctx(self, q_buf, kv_buf, edge_index, L, shared):
+        self._attn_output = None
+        self._attn_output_weights = None
+        if not self.retain_attention:
+            self._attn_ctx = None
+            return
+        self._attn_ctx = (q_buf.detach(), None if kv_buf is None else kv_buf.detach(),
+                          edge_index, L, shared)
+
+    def _attn_views(self):
+        q_buf, kv_buf, edge_index, L, shared = self._attn_ctx
+        D, dh = self.embed_dim, self.embed_dim // self.num_heads
+        if shared:
+            Qv, Kv, Vv = (F_._view(q_buf, i * D, L, dh) for i in range(3))
+        else:
+            Qv, Kv, Vv = F_._view(q_buf, 0, L, dh), F_._view(kv_buf, 0, L, dh), F_._view(kv_buf, D, L, dh)
+        return Qv, Kv, Vv, edge_index, L
+
+    @property
+    def attn_output_weights(self):
+        """[E, L, L]: w[e, row, col] = how much destination token `row` attends to source
+        token `col`, mean over heads, original edge order (amp_conv.py:43-47)."""
+        if self._attn_output_weights is None and self._attn_ctx is not None:
+            Qv, Kv, _, edge_index, L = self._attn_views()
+            self._attn_output_weights = F_.attention_weights(
+                Qv, Kv, edge_index.contiguous(), L, self.embed_dim, self.num_heads)
+        return self._attn_output_weights
+
+    @attn_output_weights.setter
+    def attn_output_weights(self, value):
+        self._attn_output_weights = value
+
+    @property
+    def attn_output(self):
+        """[E, L, D] per-edge attention output after the out-projection (amp_conv.py:39)."""
+        if self._attn_output is None and self._attn_ctx is not None:
+            Qv, Kv, Vv, edge_index, L = self._attn_views()
+            D, H = self.embed_dim, self.num_heads
+            E = edge_index.size(1)
+            ident = EdgeCSR.identity(E, edge_index.device)
+            ident.col = edge_index[0].to(torch.int32).contiguous()
+            qidx = edge_index[1].to(torch.int32).contiguous()
+            o = torch.empty(E * L, D, dtype=torch.float32, device=edge_index.device)
+            with torch.cuda.device(edge_index.device):
+                F_.edge_forward(Qv, Kv, Vv, ident, E, L, D, H, o, qidx=qidx)
+            m = self.multi_head_attention
+            with torch.no_grad():
+                self._attn_output = torch.addmm(m.out_proj.bias, o, m.out_proj.weight.t()).view(E, L, D)
+        return self._attn_output
+
+    @attn_output.setter
+    def attn_output(self, value):
+        self._attn_output = value

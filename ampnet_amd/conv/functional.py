@@ -1,0 +1,158 @@
+"""Fused AMPConv forward/backward on MI355X: projections as dense GEMMs on the
+per-NODE rows, edge phase in hand-written HIP through the C ABI.
+
+What it replaces in the reference (paths relative to /root/reference):
+  src/ampnet/conv/amp_conv.py:24-26,28-51   propagate -> message -> mean
+  torch functional.py:5785-5862             packed in-projection (per edge there, per node here)
+  torch functional.py:6578-6601             scale, QK^T, softmax, PV, out-projection
+Backward formulas: SURVEY.md A.2 (the reference relies on autograd).
+
+Data layout in HBM (fp32):
+  QKV   [N*L, 3D]   one packed projection; Q/K/V are column thirds (strided views)
+  Obar  [N*L, D]    mean over in-edges of the per-edge attention output, pre out-proj
+  dQKV  [N*L, 3D]   written by the two backward edge passes, consumed by one GEMM each
+                    for dX and d(in_proj_weight)
+"""
+import ctypes
+
+import torch
+
+from .. import _lib
+from ..graph import EdgeCSR, _stream
+
+
+def _view(buf2d, col_off, L, dh):
+    """ampconv_view_t over columns [col_off, col_off + D) of a contiguous [rows*L, W] buffer."""
+    assert buf2d.is_contiguous() and buf2d.dtype == torch.float32
+    W = buf2d.size(1)
+    return _lib.View(buf2d.data_ptr() + 4 * col_off, L * W, W, dh)
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+def edge_forward(Q, K, V, csr, n_rows, L, D, H, out2d, qidx=None):
+    lib = _lib.load()
+    rc = lib.ampconv_fwd_edge(Q, K, V, csr.rowptr.data_ptr(), csr.col.data_ptr(), _ptr(qidx),
+                              n_rows, L, D, H, _view(out2d, 0, L, D // H), _lib.AMPCONV_F32, _stream())
+    _lib.check(rc, 'ampconv_fwd_edge')
+
+
+class AMPConvFunction(torch.autograd.Function):
+    """y = mask(deg>0) * (mean_in-edges(attention) Wo^T + bo), differentiable in
+    xq, xkv and the four nn.MultiheadAttention parameters.
+
+    `xq` supplies the query (destination) rows and `xkv` the key/value (source)
+    rows; AMPConv.forward passes the same tensor for both, AMPConv.message passes
+    the pre-gathered x_i / x_j with an identity graph."""
+
+    @staticmethod
+    def forward(ctx, xq, xkv, w_in, b_in, w_out, b_out, csr, num_heads, shared):
+        lib = _lib.load()
+        D = w_out.size(0)
+        H = int(num_heads)
+        dh = D // H
+        L = xq.size(1) // D
+        Nq, Nk = xq.size(0), xkv.size(0)
+        xq2 = xq.contiguous().view(Nq * L, D)
+        with torch.cuda.device(xq.device):
+            if shared:
+                qkv = torch.addmm(b_in, xq2, w_in.t())                     # [N*L, 3D]
+                Qv, Kv, Vv = (_view(qkv, i * D, L, dh) for i in range(3))
+                xkv2 = xq2
+                kv = None
+            else:
+                xkv2 = xkv.contiguous().view(Nk * L, D)
+                qkv = torch.addmm(b_in[:D], xq2, w_in[:D].t())             # [Nq*L, D]
+                kv = torch.addmm(b_in[D:], xkv2, w_in[D:].t())             # [Nk*L, 2D]
+                Qv = _view(qkv, 0, L, dh)
+                Kv, Vv = _view(kv, 0, L, dh), _view(kv, D, L, dh)
+            obar = torch.empty(Nq * L, D, dtype=xq.dtype, device=xq.device)
+            edge_forward(Qv, Kv, Vv, csr, Nq, L, D, H, obar)
+            y = torch.addmm(b_out, obar, w_out.t())
+            rc = lib.ampconv_mask_rows(y.data_ptr(), csr.rowptr.data_ptr(), Nq, L * D, _stream())
+            _lib.check(rc, 'ampconv_mask_rows')
+        ctx.save_for_backward(xq2, xkv2, w_in, w_out, qkv, kv, obar)
+        ctx.csr, ctx.dims, ctx.shared = csr, (Nq, Nk, L, D, H), shared
+        ctx.mark_non_differentiable(qkv)
+        if kv is not None:
+            ctx.mark_non_differentiable(kv)
+        return y.view(Nq, L * D), qkv, kv
+
+    @staticmethod
+    def backward(ctx, dy, _dqkv=None, _dkv=None):
+        lib = _lib.load()
+        xq2, xkv2, w_in, w_out, qkv, kv, obar = ctx.saved_tensors
+        csr, shared = ctx.csr, ctx.shared
+        Nq, Nk, L, D, H = ctx.dims
+        dh = D // H
+        dev = dy.device
+        need_xq, need_xkv = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        with torch.cuda.device(dev):
+            dy2 = dy.contiguous().view(Nq * L, D)
+            # out-projection: rows with no in-edge contribute nothing (their obar is 0, and
+            # the bias gradient masks them explicitly)
+            scratch = torch.empty((1 + _lib.COLSUM_BLOCKS) * D, dtype=torch.float32, device=dev)
+            rc = lib.ampconv_masked_colsum(dy2.data_ptr(), csr.rowptr.data_ptr(), Nq, L, D,
+                                           scratch.data_ptr(), _stream())
+            _lib.check(rc, 'ampconv_masked_colsum')
+            db_out = scratch[:D].clone()
+            dw_out = dy2.t().mm(obar)
+            dobar = dy2.mm(w_out)                                          # [Nq*L, D]
+            dOv = _view(dobar, 0, L, dh)
+            if shared:
+                dqkv = torch.empty(Nq * L, 3 * D, dtype=torch.float32, device=dev)
+                Qv, Kv, Vv = (_view(qkv, i * D, L, dh) for i in range(3))
+                dQv, dKv, dVv = (_view(dqkv, i * D, L, dh) for i in range(3))
+                dkv = None
+            else:
+                dqkv = torch.empty(Nq * L, D, dtype=torch.float32, device=dev)
+                dkv = torch.empty(Nk * L, 2 * D, dtype=torch.float32, device=dev)
+                Qv, Kv, Vv = _view(qkv, 0, L, dh), _view(kv, 0, L, dh), _view(kv, D, L, dh)
+                dQv, dKv, dVv = _view(dqkv, 0, L, dh), _view(dkv, 0, L, dh), _view(dkv, D, L, dh)
+            rc = lib.ampconv_bwd_edge_dst(Qv, Kv, Vv, dOv, csr.rowptr.data_ptr(), csr.col.data_ptr(),
+                                          Nq, L, D, H, dQv, _lib.AMPCONV_F32, _stream())
+            _lib.check(rc, 'ampconv_bwd_edge_dst')
+            rc = lib.ampconv_bwd_edge_src(Qv, Kv, Vv, dOv, csr.cscptr.data_ptr(), csr.crow.data_ptr(),
+                                          csr.rowptr.data_ptr(), Nk, L, D, H, dKv, dVv,
+                                          _lib.AMPCONV_F32, _stream())
+            _lib.check(rc, 'ampconv_bwd_edge_src')
+            del dobar
+            if shared:
+                dw_in = dqkv.t().mm(xq2)
+                db_in = dqkv.sum(dim=0)
+                dxq = dqkv.mm(w_in).view(Nq, L * D) if need_xq else None
+                dxkv = None
+            else:
+                dw_in = torch.cat([dqkv.t().mm(xq2), dkv.t().mm(xkv2)], dim=0)
+                db_in = torch.cat([dqkv.sum(dim=0), dkv.sum(dim=0)])
+                dxq = dqkv.mm(w_in[:D]).view(Nq, L * D) if need_xq else None
+                dxkv = dkv.mm(w_in[D:]).view(Nk, L * D) if need_xkv else None
+        return dxq, dxkv, dw_in, db_in, dw_out, db_out, None, None, None
+
+
+def attention_weights(Qv, Kv, edge_index, L, D, H):
+    """[E, L, L] head-averaged softmax weights in ORIGINAL edge order
+    (amp_conv.py:39,43-47; torch functional.py:6604-6606)."""
+    lib = _lib.load()
+    E = edge_index.size(1)
+    W = torch.empty(E, L, L, dtype=torch.float32, device=edge_index.device)
+    with torch.cuda.device(edge_index.device):
+        rc = lib.ampconv_attn_weights(Qv, Kv, edge_index.data_ptr(), E, L, D, H, W.data_ptr(),
+                                      _lib.AMPCONV_F32, _stream())
+    _lib.check(rc, 'ampconv_attn_weights')
+    return W
+
+
+def segment_mean(msg, csr):
+    """PyG aggr='mean' of an [E, F] message matrix over the dst-sorted CSR."""
+    lib = _lib.load()
+    msg = msg.contiguous()
+    N, F = csr.num_nodes, msg.size(1)
+    out = torch.empty(N, F, dtype=torch.float32, device=msg.device)
+    with torch.cuda.device(msg.device):
+        rc = lib.ampconv_segment_mean(msg.data_ptr(), csr.rowptr.data_ptr(), csr.eperm.data_ptr(),
+                                      N, F, out.data_ptr(), _stream())
+    _lib.check(rc, 'ampconv_segment_mean')
+    return out

@@ -1,0 +1,70 @@
+// C-ABI entry points of the edge phase: argument checks + dispatch between the
+// MFMA fast path (edge_mfma.hip) and the shape-generic kernels
+// (edge_generic.hip).  AMPCONV_FORCE_GENERIC=1 in the environment pins the
+// generic kernels (used by the tests to cross-check the two paths).
+#include <cstdlib>
+#include "common.h"
+
+namespace {
+bool force_generic() {
+  const char *e = std::getenv("AMPCONV_FORCE_GENERIC");
+  return e && e[0] == '1';
+}
+int check_common(int L, int D, int H, int dtype) {
+  if (dtype != AMPCONV_F32) return AMPCONV_E_DTYPE;
+  if (L <= 0 || D <= 0 || H <= 0 || D % H != 0) return AMPCONV_E_BADARG;
+  return AMPCONV_OK;
+}
+}  // namespace
+
+extern "C" int ampconv_version(void) { return AMPCONV_VERSION; }
+
+extern "C" const char *ampconv_error_string(int code) {
+  switch (code) {
+    case AMPCONV_OK: return "ok";
+    case AMPCONV_E_BADARG: return "ampconv: bad argument";
+    case AMPCONV_E_DTYPE: return "ampconv: dtype not supported";
+    case AMPCONV_E_WORKSPACE: return "ampconv: workspace too small";
+    default: return code > 0 ? hipGetErrorString((hipError_t)code) : "ampconv: unknown error";
+  }
+}
+
+extern "C" int ampconv_fwd_edge(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
+                                const int32_t *rowptr, const int32_t *col, const int32_t *qidx,
+                                int64_t n_rows, int L, int D, int H, ampconv_view_t O, int dtype,
+                                void *stream) {
+  if (int rc = check_common(L, D, H, dtype)) return rc;
+  if (n_rows < 0) return AMPCONV_E_BADARG;
+  if (n_rows == 0) return AMPCONV_OK;
+  if (!view_ok(Q) || !view_ok(K) || !view_ok(V) || !view_ok(O) || !rowptr) return AMPCONV_E_BADARG;
+  return ampconv_fwd_edge_generic(Q, K, V, rowptr, col, qidx, n_rows, L, D, H, O,
+                                  (hipStream_t)stream);
+}
+
+extern "C" int ampconv_bwd_edge_dst(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
+                                    ampconv_view_t dObar, const int32_t *rowptr,
+                                    const int32_t *col, int64_t n_rows, int L, int D, int H,
+                                    ampconv_view_t dQ, int dtype, void *stream) {
+  if (int rc = check_common(L, D, H, dtype)) return rc;
+  if (n_rows < 0) return AMPCONV_E_BADARG;
+  if (n_rows == 0) return AMPCONV_OK;
+  if (!view_ok(Q) || !view_ok(K) || !view_ok(V) || !view_ok(dObar) || !view_ok(dQ) || !rowptr)
+    return AMPCONV_E_BADARG;
+  return ampconv_bwd_edge_dst_generic(Q, K, V, dObar, rowptr, col, n_rows, L, D, H, dQ,
+                                      (hipStream_t)stream);
+}
+
+extern "C" int ampconv_bwd_edge_src(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
+                                    ampconv_view_t dObar, const int32_t *cscptr,
+                                    const int32_t *crow, const int32_t *rowptr, int64_t n_src,
+                                    int L, int D, int H, ampconv_view_t dK, ampconv_view_t dV,
+                                    int dtype, void *stream) {
+  if (int rc = check_common(L, D, H, dtype)) return rc;
+  if (n_src < 0) return AMPCONV_E_BADARG;
+  if (n_src == 0) return AMPCONV_OK;
+  if (!view_ok(Q) || !view_ok(K) || !view_ok(V) || !view_ok(dObar) || !view_ok(dK) ||
+      !view_ok(dV) || !cscptr || !rowptr)
+    return AMPCONV_E_BADARG;
+  return ampconv_bwd_edge_src_generic(Q, K, V, dObar, cscptr, crow, rowptr, n_src, L, D, H, dK,
+                                      dV, (hipStream_t)stream);
+}

@@ -1,0 +1,97 @@
+// Node-side helpers around the edge phase: PyG-style segment mean
+// (`aggregate`), the in-degree mask of the out-projection, and the masked
+// column sum that is out_proj.bias.grad.
+#include "common.h"
+
+namespace {
+
+// out[n, :] = mean over the CSR segment of n of msg[eperm[p], :]   (0 if empty)
+// reference: MessagePassing(aggr='mean'), amp_conv.py:11;
+//            testing_message_passing_pyg.py:37-40 pins direction, mean and the zero rows.
+__global__ void segment_mean_kernel(const float *__restrict__ msg,
+                                    const int32_t *__restrict__ rowptr,
+                                    const int32_t *__restrict__ eperm, int64_t F,
+                                    float *__restrict__ out) {
+  const int64_t n = blockIdx.x;
+  const int beg = rowptr[n], end = rowptr[n + 1];
+  const float inv = end > beg ? 1.f / (float)(end - beg) : 0.f;
+  for (int64_t f = threadIdx.x; f < F; f += blockDim.x) {
+    float acc = 0.f;
+    for (int p = beg; p < end; ++p) acc += msg[(int64_t)eperm[p] * F + f];
+    out[n * F + f] = acc * inv;
+  }
+}
+
+__global__ void mask_rows_kernel(float *__restrict__ Y, const int32_t *__restrict__ rowptr,
+                                 int64_t N, int64_t F) {
+  const int64_t n = blockIdx.x;
+  if (rowptr[n + 1] != rowptr[n]) return;
+  for (int64_t f = threadIdx.x; f < F; f += blockDim.x) Y[n * F + f] = 0.f;
+}
+
+// partial[b, c] = sum over rows n in block b's slice with deg>0, tokens l of dY[n, l, c]
+__global__ void masked_colsum_partial(const float *__restrict__ dY,
+                                      const int32_t *__restrict__ rowptr, int64_t N, int L, int D,
+                                      int64_t rows_per_block, float *__restrict__ partial) {
+  const int64_t n0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t n1 = n0 + rows_per_block < N ? n0 + rows_per_block : N;
+  for (int c = threadIdx.x; c < D; c += blockDim.x) {
+    float acc = 0.f;
+    for (int64_t n = n0; n < n1; ++n) {
+      if (rowptr[n + 1] == rowptr[n]) continue;
+      const float *row = dY + n * (int64_t)L * D + c;
+      for (int l = 0; l < L; ++l) acc += row[(int64_t)l * D];
+    }
+    partial[(int64_t)blockIdx.x * D + c] = acc;
+  }
+}
+
+__global__ void colsum_final(const float *__restrict__ partial, int nblocks, int D,
+                             float *__restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= D) return;
+  float acc = 0.f;
+  for (int b = 0; b < nblocks; ++b) acc += partial[(int64_t)b * D + c];
+  out[c] = acc;
+}
+
+}  // namespace
+
+extern "C" int ampconv_segment_mean(const float *msg, const int32_t *rowptr, const int32_t *eperm,
+                                    int64_t N, int64_t F, float *out, void *stream) {
+  if (N < 0 || F < 0 || N > INT32_MAX) return AMPCONV_E_BADARG;
+  if (N == 0 || F == 0) return AMPCONV_OK;
+  if (!rowptr || !out) return AMPCONV_E_BADARG;
+  segment_mean_kernel<<<(unsigned)N, 256, 0, (hipStream_t)stream>>>(msg, rowptr, eperm, F, out);
+  return ampconv_launch_status();
+}
+
+extern "C" int ampconv_mask_rows(float *Y, const int32_t *rowptr, int64_t N, int64_t F,
+                                 void *stream) {
+  if (N < 0 || F < 0 || N > INT32_MAX) return AMPCONV_E_BADARG;
+  if (N == 0 || F == 0) return AMPCONV_OK;
+  if (!Y || !rowptr) return AMPCONV_E_BADARG;
+  mask_rows_kernel<<<(unsigned)N, 256, 0, (hipStream_t)stream>>>(Y, rowptr, N, F);
+  return ampconv_launch_status();
+}
+
+// `out` must have room for D floats followed by a scratch area of
+// AMPCONV_COLSUM_BLOCKS * D floats (see ampnet_amd/_lib.py); the two-step sum is
+// deterministic (fixed block slices, fixed order).
+extern "C" int ampconv_masked_colsum(const float *dY, const int32_t *rowptr, int64_t N, int L,
+                                     int D, float *out, void *stream) {
+  if (N < 0 || L <= 0 || D <= 0) return AMPCONV_E_BADARG;
+  if (!out) return AMPCONV_E_BADARG;
+  const int nblocks = 1024;
+  float *partial = out + D;
+  if (N == 0) {
+    hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * D, (hipStream_t)stream);
+    return e == hipSuccess ? AMPCONV_OK : (int)e;
+  }
+  if (!dY || !rowptr) return AMPCONV_E_BADARG;
+  const int64_t rpb = (N + nblocks - 1) / nblocks;
+  const int used = (int)((N + rpb - 1) / rpb);
+  masked_colsum_partial<<<used, 256, 0, (hipStream_t)stream>>>(dY, rowptr, N, L, D, rpb, partial);
+  colsum_final<<<(D + 255) / 256, 256, 0, (hipStream_t)stream>>>(partial, used, D, out);
+  return ampconv_launch_status();
+}

@@ -1,0 +1,134 @@
+/*
+ * ampconv.h -- C ABI of libampconv.so: the MI355X (gfx950) implementation of the
+ * AMPConv hot path of HarryL-Git/ampnet.
+ *
+ * The reference has no FFI layer of its own: its boundary for this path is the
+ * Python class `AMPConv` (reference src/ampnet/conv/amp_conv.py:9-51) on top of
+ * torch.nn.MultiheadAttention and torch_geometric.nn.MessagePassing.  Each entry
+ * point below names the reference lines whose arithmetic it replaces.  The host
+ * side that binds these with ctypes is ampnet_amd/conv/amp_conv.py; the stub a
+ * reference maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller; the library
+ *     allocates nothing and keeps no state between calls (re-entrant);
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it and
+ *     no call synchronises the device;
+ *   - every function returns 0 on success, a negative AMPCONV_E_* code for
+ *     argument errors detected on the host, or a positive hipError_t;
+ *     nothing throws or aborts;
+ *   - N = nodes, E = edges, L = tokens per node, D = embed_dim, H = heads,
+ *     dh = D / H.  Messages flow src = edge_index[0] -> dst = edge_index[1]
+ *     (amp_conv.py:40-41).
+ */
+#ifndef AMPCONV_H_
+#define AMPCONV_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AMPCONV_VERSION 100
+
+enum {
+  AMPCONV_OK = 0,
+  AMPCONV_E_BADARG = -1,   /* null pointer, negative size, D % H != 0, ... */
+  AMPCONV_E_DTYPE = -2,    /* dtype not supported by this build */
+  AMPCONV_E_WORKSPACE = -3 /* workspace too small */
+};
+
+enum { AMPCONV_F32 = 0, AMPCONV_BF16 = 1 };
+
+/*
+ * Strided view of a per-node token matrix: element (node n, token l, head h,
+ * channel c) lives at  ptr + n*node_stride + l*row_stride + h*head_stride + c
+ * (strides in ELEMENTS).  A row-major [N, L, D] tensor is
+ * {ptr, L*D, D, dh}; the K third of a packed [N*L, 3D] projection is
+ * {ptr + D, L*3*D, 3*D, dh}.
+ */
+typedef struct {
+  void *ptr;
+  int64_t node_stride;
+  int64_t row_stride;
+  int64_t head_stride;
+} ampconv_view_t;
+
+int ampconv_version(void);
+const char *ampconv_error_string(int code);
+
+/* ---- graph preparation ------------------------------------------------------
+ * Replaces what PyG's propagate() does implicitly with index_select/scatter on
+ * the unsorted edge list (amp_conv.py:25).  Builds, with stable sorts so that
+ * every later floating-point sum has a fixed order:
+ *   dst-sorted CSR: rowptr[N+1], col[E] (source of each sorted edge),
+ *                   eperm[E] (original edge id at each sorted position)
+ *   src-sorted CSC: cscptr[N+1], crow[E] (destination), cperm[E]
+ * `oob` (device int32) is set non-zero if any index is outside [0, N); such
+ * indices are clamped so that no kernel faults.  */
+size_t ampconv_csr_workspace_bytes(int64_t N, int64_t E);
+int ampconv_csr_build(const int64_t *edge_index, int64_t E, int64_t N,
+                      int32_t *rowptr, int32_t *col, int32_t *eperm,
+                      int32_t *cscptr, int32_t *crow, int32_t *cperm,
+                      int32_t *oob, void *workspace, size_t workspace_bytes,
+                      void *stream);
+
+/* ---- edge phase, forward ----------------------------------------------------
+ * For every row r < n_rows (destination d = qidx ? qidx[r] : r) and head h:
+ *   O[r,:,h] = (1/deg_r) * sum_{p in [rowptr[r], rowptr[r+1])}
+ *                 softmax_rows(Q[d,:,h] K[col[p],:,h]^T / sqrt(dh)) V[col[p],:,h]
+ * and O[r] = 0 when deg_r = 0.  Replaces, per edge: torch functional.py:6578
+ * (scale), :6589 (QK^T), :6590 (softmax), :6594 (PV), and PyG's mean
+ * aggregation (amp_conv.py:11).  Q/K/V are the per-NODE projections.  */
+int ampconv_fwd_edge(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
+                     const int32_t *rowptr, const int32_t *col,
+                     const int32_t *qidx, int64_t n_rows, int L, int D, int H,
+                     ampconv_view_t O, int dtype, void *stream);
+
+/* ---- edge phase, backward (autograd of the above; amp_conv.py has no custom
+ * backward, cora_benchmark_graphsaint.py:110 calls loss.backward()) ------------
+ * dObar is the gradient w.r.t. the MEAN (the kernels apply 1/deg).
+ * _dst: one pass over the dst-sorted CSR, writes dQ[r] for every row.
+ * _src: one pass over the src-sorted CSC, writes dK[s], dV[s] for every source;
+ *       `rowptr` is the dst-CSR pointer array (for 1/deg of each destination).
+ * No atomics: every output row is owned by one wavefront.  */
+int ampconv_bwd_edge_dst(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
+                         ampconv_view_t dObar, const int32_t *rowptr,
+                         const int32_t *col, int64_t n_rows, int L, int D, int H,
+                         ampconv_view_t dQ, int dtype, void *stream);
+int ampconv_bwd_edge_src(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
+                         ampconv_view_t dObar, const int32_t *cscptr,
+                         const int32_t *crow, const int32_t *rowptr,
+                         int64_t n_src, int L, int D, int H, ampconv_view_t dK,
+                         ampconv_view_t dV, int dtype, void *stream);
+
+/* ---- per-edge side outputs, ORIGINAL edge order ------------------------------
+ * attn_weights: W[e] = mean_h softmax_rows(Q[dst e,:,h] K[src e,:,h]^T/sqrt(dh)),
+ * [E, L, L] fp32 -- `self.attn_output_weights` (amp_conv.py:39,43-47; torch
+ * functional.py:6604-6606).  */
+int ampconv_attn_weights(ampconv_view_t Q, ampconv_view_t K,
+                         const int64_t *edge_index, int64_t E, int L, int D,
+                         int H, float *W, int dtype, void *stream);
+
+/* ---- node-side helpers --------------------------------------------------------
+ * segment_mean: PyG aggr='mean' on an [E, F] message matrix (amp_conv.py:11,
+ * testing_message_passing_pyg.py:37-40): out[n] = mean of msg[eperm[p]] over the
+ * CSR segment of n, 0 for empty segments.
+ * mask_rows: zero, in place, the rows of Y[N, F] whose CSR segment is empty
+ * (out-projection bias must not leak into nodes nobody sends to).
+ * masked_colsum: out[f] = sum over rows with a non-empty segment of dY[n, f],
+ * folded over the L tokens: out has D entries (out_proj.bias gradient).  */
+int ampconv_segment_mean(const float *msg, const int32_t *rowptr,
+                         const int32_t *eperm, int64_t N, int64_t F, float *out,
+                         void *stream);
+int ampconv_mask_rows(float *Y, const int32_t *rowptr, int64_t N, int64_t F,
+                      void *stream);
+int ampconv_masked_colsum(const float *dY, const int32_t *rowptr, int64_t N,
+                          int L, int D, float *out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AMPCONV_H_ */

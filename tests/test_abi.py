@@ -1,0 +1,99 @@
+"""CPU checks of the boundary: libampconv.so loads, exports every symbol that
+include/ampconv.h declares (no compute calls here), and the host-side class
+mirrors the reference's API and error behaviour."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT
+
+HEADER = os.path.join(ROOT, 'include', 'ampconv.h')
+
+
+def _declared():
+    src = open(HEADER).read()
+    src = re.sub(r'/\*.*?\*/', '', src, flags=re.S)
+    return sorted(set(re.findall(r'\b(ampconv_[a-z_0-9]+)\s*\(', src)))
+
+
+@pytest.fixture(scope='module')
+def built():
+    import __graft_entry__ as ge
+    ge.build()
+    return os.path.join(ROOT, 'ampnet_amd', 'libampconv.so')
+
+
+def test_header_declares_the_path():
+    names = _declared()
+    for n in ('ampconv_csr_build', 'ampconv_fwd_edge', 'ampconv_bwd_edge_dst', 'ampconv_bwd_edge_src',
+              'ampconv_attn_weights', 'ampconv_segment_mean', 'ampconv_mask_rows',
+              'ampconv_masked_colsum', 'ampconv_version'):
+        assert n in names
+
+
+def test_library_exports_every_declared_symbol(built):
+    lib = ctypes.CDLL(built)
+    for n in _declared():
+        assert hasattr(lib, n), f'{n} declared in include/ampconv.h but not exported'
+    lib.ampconv_version.restype = ctypes.c_int
+    assert lib.ampconv_version() >= 100
+
+
+def test_python_binding_matches_header(built):
+    from ampnet_amd import _lib
+    assert sorted(_lib.SIGNATURES) == _declared()
+    _lib.load()
+
+
+def test_error_strings(built):
+    from ampnet_amd import _lib
+    lib = _lib.load()
+    assert lib.ampconv_error_string(0) == b'ok'
+    assert b'bad argument' in lib.ampconv_error_string(-1)
+    with pytest.raises(_lib.AmpconvError):
+        _lib.check(-2, 'x')
+
+
+def test_class_api_matches_reference():
+    # src/ampnet/conv/amp_conv.py:10-22: ctor args, attribute and state-dict names
+    from ampnet_amd import AMPConv
+    torch.manual_seed(1)
+    m = AMPConv(embed_dim=16, num_heads=4)
+    assert m.embed_dim == 16 and m.num_heads == 4
+    assert m.attn_output is None and m.attn_output_weights is None
+    assert list(m.state_dict().keys()) == [
+        'multi_head_attention.in_proj_weight', 'multi_head_attention.in_proj_bias',
+        'multi_head_attention.out_proj.weight', 'multi_head_attention.out_proj.bias']
+    for name in ('forward', 'message', 'aggregate', 'propagate'):
+        assert callable(getattr(m, name))
+    # identical init RNG consumption as the reference's container module
+    torch.manual_seed(1)
+    ref = torch.nn.MultiheadAttention(16, 4, batch_first=True, bias=True)
+    assert torch.equal(ref.in_proj_weight, m.multi_head_attention.in_proj_weight)
+    assert torch.equal(ref.out_proj.weight, m.multi_head_attention.out_proj.weight)
+    m.attn_output_weights = None                  # attribute stays assignable like the reference's
+
+
+def test_error_behaviour_no_cpu_fallback():
+    from ampnet_amd import AMPConv, InvalidConfiguration
+    m = AMPConv(8, 2)
+    ei = torch.tensor([[0], [1]])
+    with pytest.raises(ValueError, match='GPU only'):
+        m(torch.randn(4, 16), ei)
+    with pytest.raises(RuntimeError):              # reference: reshape raises RuntimeError
+        m(torch.randn(4, 15), ei)
+    with pytest.raises(InvalidConfiguration):
+        m.message(torch.randn(3, 9), torch.randn(3, 9))
+    with pytest.raises(AssertionError):            # embed_dim % num_heads, asserted by torch MHA ctor
+        AMPConv(10, 3)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from ampnet_amd import _lib
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'nope.so'))
+    with pytest.raises(_lib.AmpconvError, match='no non-HIP fallback'):
+        _lib.load()

@@ -1,0 +1,223 @@
+"""GPU parity: the HIP path (through the C ABI) against the reference's own
+outputs (tests/golden) and against the CPU oracle on seeded inputs.
+
+Tolerance (fp32): atol 1e-5, rtol 1e-4 on y, dx, weights; parameter
+gradients are sums over N*L rows so their atol is scaled by max|grad|.  Rows with
+in-degree 0 must be EXACTLY zero."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_files, load_golden, assert_close_scaled
+
+pytestmark = pytest.mark.gpu
+
+SINGLE = golden_files(two_layer=False)
+TWO = golden_files(two_layer=True)
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available()
+    from ampnet_amd import _lib
+    _lib.load()                                     # the HIP extension must be the thing that runs
+    return torch.device('cuda:0')
+
+
+def _layer(g, dev, prefix=''):
+    from ampnet_amd import AMPConv
+    layer = AMPConv(int(g['D']), int(g['H'])).to(dev)
+    sd = {'multi_head_attention.in_proj_weight': torch.from_numpy(g[prefix + 'in_proj_weight']),
+          'multi_head_attention.in_proj_bias': torch.from_numpy(g[prefix + 'in_proj_bias']),
+          'multi_head_attention.out_proj.weight': torch.from_numpy(g[prefix + 'out_proj_weight']),
+          'multi_head_attention.out_proj.bias': torch.from_numpy(g[prefix + 'out_proj_bias'])}
+    layer.load_state_dict(sd)                       # reference checkpoints load by key
+    return layer
+
+
+def _grads(layer):
+    m = layer.multi_head_attention
+    return (m.in_proj_weight.grad.cpu().numpy(), m.in_proj_bias.grad.cpu().numpy(),
+            m.out_proj.weight.grad.cpu().numpy(), m.out_proj.bias.grad.cpu().numpy())
+
+
+def _check_single(g, dev):
+    layer = _layer(g, dev)
+    x = torch.from_numpy(g['x']).to(dev).requires_grad_(True)
+    ei = torch.from_numpy(g['edge_index']).to(dev)
+    y = layer(x, ei)
+    (y * torch.from_numpy(g['dy']).to(dev)).sum().backward()
+    yh = y.detach().cpu().numpy()
+    assert_close_scaled(yh, g['y'], 'y')
+    deg = np.bincount(g['edge_index'][1], minlength=int(g['N']))
+    assert (yh[deg == 0] == 0).all(), 'rows with no in-edge must be exactly 0'
+    assert_close_scaled(x.grad.cpu().numpy(), g['dx'], 'dx')
+    gw, gb, gow, gob = _grads(layer)
+    assert_close_scaled(gw, g['g_in_proj_weight'], 'g_in_proj_weight')
+    assert_close_scaled(gb, g['g_in_proj_bias'], 'g_in_proj_bias')
+    assert_close_scaled(gow, g['g_out_proj_weight'], 'g_out_proj_weight')
+    assert_close_scaled(gob, g['g_out_proj_bias'], 'g_out_proj_bias')
+    w = layer.attn_output_weights
+    assert tuple(w.shape) == (g['edge_index'].shape[1], int(g['L']), int(g['L']))
+    wh = w.cpu().numpy()
+    assert_close_scaled(wh[g['w_edges']], g['attn_output_weights'], 'attn_output_weights')
+    np.testing.assert_allclose(wh.sum(-1), 1.0, atol=1e-5)
+    ao = layer.attn_output.cpu().numpy()
+    assert_close_scaled(ao[g['w_edges'][:4]], g['attn_output'], 'attn_output')
+    return layer, x, ei
+
+
+@pytest.mark.parametrize('path', SINGLE, ids=[os.path.basename(p)[:-4] for p in SINGLE])
+def test_golden_single_layer(path, dev):
+    _check_single(load_golden(path), dev)
+
+
+@pytest.mark.parametrize('path', SINGLE[:4], ids=[os.path.basename(p)[:-4] for p in SINGLE[:4]])
+def test_golden_generic_kernels(path, dev, monkeypatch):
+    # the shape-generic kernels must agree with the reference on every shape too
+    monkeypatch.setenv('AMPCONV_FORCE_GENERIC', '1')
+    _check_single(load_golden(path), dev)
+
+
+@pytest.mark.parametrize('path', TWO, ids=[os.path.basename(p)[:-4] for p in TWO])
+def test_golden_two_layer(path, dev):
+    # conv -> ReLU -> conv -> ReLU, src/ampnet/module/amp_gcn.py:248-262
+    g = load_golden(path)
+    l1, l2 = _layer(g, dev, 'l1_'), _layer(g, dev, 'l2_')
+    x = torch.from_numpy(g['x']).to(dev).requires_grad_(True)
+    ei = torch.from_numpy(g['edge_index']).to(dev)
+    y = torch.relu(l2(torch.relu(l1(x, ei)), ei))
+    (y * torch.from_numpy(g['dy']).to(dev)).sum().backward()
+    assert_close_scaled(y.detach().cpu().numpy(), g['y'], 'y')
+    assert_close_scaled(x.grad.cpu().numpy(), g['dx'], 'dx')
+    for p, layer in (('l1_', l1), ('l2_', l2)):
+        gw, gb, gow, gob = _grads(layer)
+        assert_close_scaled(gw, g[p + 'g_in_proj_weight'], p + 'g_in_proj_weight')
+        assert_close_scaled(gb, g[p + 'g_in_proj_bias'], p + 'g_in_proj_bias')
+        assert_close_scaled(gow, g[p + 'g_out_proj_weight'], p + 'g_out_proj_weight')
+        assert_close_scaled(gob, g[p + 'g_out_proj_bias'], p + 'g_out_proj_bias')
+
+
+def test_message_matches_per_edge_reference(dev):
+    # message(x_i, x_j) on pre-gathered rows == the reference's per-edge attn_output (amp_conv.py:39,49)
+    g = load_golden([p for p in SINGLE if 'cora_L20' in p][0])
+    layer = _layer(g, dev)
+    x = torch.from_numpy(g['x']).to(dev)
+    ei = torch.from_numpy(g['edge_index']).to(dev)
+    sel = torch.from_numpy(g['w_edges'][:4]).to(dev)
+    m = layer.message(x[ei[1, sel]], x[ei[0, sel]])
+    L, D = int(g['L']), int(g['D'])
+    assert_close_scaled(m.detach().cpu().numpy().reshape(4, L, D), g['attn_output'], 'message')
+    assert_close_scaled(layer.attn_output_weights.cpu().numpy(), g['attn_output_weights'][:4], 'w')
+
+
+def test_aggregate_known_answer(dev):
+    # synthetic_benchmark/testing_message_passing_pyg.py:23-40
+    from ampnet_amd import AMPConv
+    layer = AMPConv(3, 1).to(dev)
+    x = torch.tensor([[1, 1, 1], [2, 2, 2], [3, 3, 3], [10, 10, 10], [11, 11, 11]],
+                     dtype=torch.float32, device=dev)
+    for ei, want in (([[0, 1, 3, 4], [2, 2, 2, 2]], 6.0), ([[0, 1, 2, 3, 4], [2, 2, 2, 2, 2]], 5.4)):
+        ei = torch.tensor(ei, device=dev)
+        out = layer.aggregate(x[ei[0]], ei[1], dim_size=5).cpu().numpy()
+        np.testing.assert_allclose(out[2], [want] * 3, rtol=1e-6)
+        assert (out[[0, 1, 3, 4]] == 0).all()
+
+
+def test_csr_build_is_a_stable_sort(dev):
+    from ampnet_amd import EdgeCSR
+    rng = np.random.default_rng(3)
+    N, E = 1000, 20000
+    ei = rng.integers(0, N, size=(2, E)).astype(np.int64)
+    ei[1, :4000] = 7                                  # a hub
+    csr = EdgeCSR(torch.from_numpy(ei).to(dev), N)
+    perm = np.argsort(ei[1], kind='stable')
+    np.testing.assert_array_equal(csr.eperm.cpu().numpy(), perm)
+    np.testing.assert_array_equal(csr.col.cpu().numpy(), ei[0][perm])
+    np.testing.assert_array_equal(csr.rowptr.cpu().numpy(),
+                                  np.concatenate([[0], np.cumsum(np.bincount(ei[1], minlength=N))]))
+    cperm = np.argsort(ei[0], kind='stable')
+    np.testing.assert_array_equal(csr.cperm.cpu().numpy(), cperm)
+    np.testing.assert_array_equal(csr.crow.cpu().numpy(), ei[1][cperm])
+    np.testing.assert_array_equal(csr.cscptr.cpu().numpy(),
+                                  np.concatenate([[0], np.cumsum(np.bincount(ei[0], minlength=N))]))
+
+
+def test_edge_cases(dev):
+    from ampnet_amd import AMPConv
+    layer = AMPConv(8, 2).to(dev)
+    x = torch.randn(6, 16, device=dev, requires_grad=True)
+    # empty edge set: every row is exactly zero, gradients flow as zeros
+    y = layer(x, torch.zeros(2, 0, dtype=torch.int64, device=dev))
+    assert (y == 0).all()
+    y.sum().backward()
+    assert (x.grad == 0).all()
+    assert tuple(layer.attn_output_weights.shape) == (0, 2, 2)
+    # out-of-range node id is rejected before any kernel touches it
+    with pytest.raises(ValueError, match='outside'):
+        layer(x, torch.tensor([[0, 9], [1, 2]], device=dev))
+    with pytest.raises(ValueError, match='int64'):
+        layer(x, torch.tensor([[0], [1]], dtype=torch.int32, device=dev))
+
+
+@pytest.mark.parametrize('shape', [(3000, 30000, 20, 128, 4), (2000, 24000, 20, 256, 8),
+                                   (1500, 9000, 20, 128, 8), (500, 4000, 7, 24, 3)],
+                         ids=['cora_like', 'cfg4_like', 'cfg3_like', 'odd'])
+def test_seeded_vs_oracle(shape, dev):
+    """Larger seeded graphs (uniform + one hub + isolated nodes) against the numpy oracle."""
+    from ampnet_amd import AMPConv
+    from oracle.ampconv_numpy import AMPConvOracle
+    N, E, L, D, H = shape
+    torch.manual_seed(11)
+    layer = AMPConv(D, H).to(dev)
+    with torch.no_grad():
+        layer.multi_head_attention.in_proj_bias.normal_(0, 0.1)
+        layer.multi_head_attention.out_proj.bias.normal_(0, 0.1)
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(N, L * D, generator=g)
+    dy = torch.randn(N, L * D, generator=g)
+    ei = torch.randint(0, N - 50, (2, E), generator=g)       # last 50 nodes isolated
+    ei[1, : E // 10] = 3                                      # hub: 10 % of the edges end at node 3
+    xg = x.to(dev).requires_grad_(True)
+    y = layer(xg, ei.to(dev))
+    (y * dy.to(dev)).sum().backward()
+    m = layer.multi_head_attention
+    o = AMPConvOracle(m.in_proj_weight.detach().cpu().numpy(), m.in_proj_bias.detach().cpu().numpy(),
+                      m.out_proj.weight.detach().cpu().numpy(), m.out_proj.bias.detach().cpu().numpy(),
+                      H, dtype=np.float64, edge_chunk=2048)
+    y_ref, _ = o.forward(x.numpy(), ei.numpy(), need_weights=False)
+    dx_ref, dWin, dbin, dWo, dbo = o.backward(dy.numpy())
+    yh = y.detach().cpu().numpy()
+    assert_close_scaled(yh, y_ref, 'y')
+    assert (yh[N - 50:] == 0).all()
+    assert_close_scaled(xg.grad.cpu().numpy(), dx_ref, 'dx')
+    gw, gb, gow, gob = _grads(layer)
+    assert_close_scaled(gw, dWin, 'g_in_proj_weight')
+    assert_close_scaled(gb, dbin, 'g_in_proj_bias')
+    assert_close_scaled(gow, dWo, 'g_out_proj_weight')
+    assert_close_scaled(gob, dbo, 'g_out_proj_bias')
+
+
+def test_properties_medium(dev):
+    """Size-independent properties: bitwise run-to-run determinism, invariance of the
+    mean to duplicating every edge, softmax rows summing to 1."""
+    from ampnet_amd import AMPConv
+    torch.manual_seed(5)
+    N, E, L, D, H = 20000, 200000, 20, 128, 8
+    layer = AMPConv(D, H).to(dev)
+    layer.retain_attention = False
+    x = torch.randn(N, L * D, device=dev)
+    ei = torch.randint(0, N, (2, E), device=dev)
+    with torch.no_grad():
+        y1 = layer(x, ei)
+        y2 = layer(x, ei.clone())
+        assert torch.equal(y1, y2)
+        y3 = layer(x, torch.cat([ei, ei], dim=1))
+        torch.testing.assert_close(y3, y1, rtol=1e-4, atol=1e-5)
+    layer.retain_attention = True
+    with torch.no_grad():
+        layer(x[:2000], ei[:, :5000] % 2000)
+        w = layer.attn_output_weights
+        torch.testing.assert_close(w.sum(-1), torch.ones_like(w[..., 0]), rtol=0, atol=1e-5)
