@@ -43,3 +43,11 @@ int ampconv_bwd_edge_src_generic(ampconv_view_t Q, ampconv_view_t K, ampconv_vie
                                  ampconv_view_t dO, const int32_t *cscptr, const int32_t *crow,
                                  const int32_t *rowptr, int64_t n_src, int L, int D, int H,
                                  ampconv_view_t dK, ampconv_view_t dV, hipStream_t stream);
+
+// ---- MFMA fast path (edge_mfma.hip): L <= 20, dh in {16, 32}, 16-byte aligned views
+bool ampconv_mfma_supported(int L, int D, int H);
+bool ampconv_mfma_views_ok(const ampconv_view_t *views, int n);
+int ampconv_fwd_edge_mfma(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
+                          const int32_t *rowptr, const int32_t *col, const int32_t *qidx,
+                          int64_t n_rows, int L, int D, int H, ampconv_view_t O,
+                          hipStream_t stream);

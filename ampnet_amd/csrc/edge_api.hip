@@ -37,6 +37,10 @@ extern "C" int ampconv_fwd_edge(ampconv_view_t Q, ampconv_view_t K, ampconv_view
   if (n_rows < 0) return AMPCONV_E_BADARG;
   if (n_rows == 0) return AMPCONV_OK;
   if (!view_ok(Q) || !view_ok(K) || !view_ok(V) || !view_ok(O) || !rowptr) return AMPCONV_E_BADARG;
+  const ampconv_view_t views[] = {Q, K, V, O};
+  if (!force_generic() && ampconv_mfma_supported(L, D, H) && ampconv_mfma_views_ok(views, 4))
+    return ampconv_fwd_edge_mfma(Q, K, V, rowptr, col, qidx, n_rows, L, D, H, O,
+                                 (hipStream_t)stream);
   return ampconv_fwd_edge_generic(Q, K, V, rowptr, col, qidx, n_rows, L, D, H, O,
                                   (hipStream_t)stream);
 }

@@ -1,0 +1,78 @@
+"""Developer micro-benchmark: time each C-ABI edge kernel on a synthetic uniform graph.
+
+    python tools/bench_kernels.py [N E L D H] [--generic]
+"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+from ampnet_amd import _lib, EdgeCSR  # noqa: E402
+from ampnet_amd.conv import functional as F_  # noqa: E402
+
+
+def timeit(fn, iters=5, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    args = [a for a in sys.argv[1:] if not a.startswith('--')]
+    N, E, L, D, H = (int(x) for x in args) if len(args) == 5 else (100000, 1000000, 20, 256, 8)
+    if '--generic' in sys.argv:
+        os.environ['AMPCONV_FORCE_GENERIC'] = '1'
+    dev = torch.device('cuda:0')
+    lib = _lib.load()
+    dh = D // H
+    torch.manual_seed(0)
+    qkv = torch.randn(N * L, 3 * D, device=dev)
+    dobar = torch.randn(N * L, D, device=dev)
+    ei = torch.randint(0, N, (2, E), device=dev)
+    t0 = time.time()
+    csr = EdgeCSR(ei, N)
+    torch.cuda.synchronize()
+    print(f'N={N} E={E} L={L} D={D} H={H}  csr build (cold) {1e3 * (time.time() - t0):.1f} ms')
+    print(f'csr build {timeit(lambda: EdgeCSR(ei, N, validate=False)):.3f} ms')
+    Qv, Kv, Vv = (F_._view(qkv, i * D, L, dh) for i in range(3))
+    obar = torch.empty(N * L, D, device=dev)
+    dqkv = torch.empty(N * L, 3 * D, device=dev)
+    dQv, dKv, dVv = (F_._view(dqkv, i * D, L, dh) for i in range(3))
+    dOv = F_._view(dobar, 0, L, dh)
+    st = torch.cuda.current_stream().cuda_stream
+    R = L * D * 4
+
+    def fwd():
+        _lib.check(lib.ampconv_fwd_edge(Qv, Kv, Vv, csr.rowptr.data_ptr(), csr.col.data_ptr(), None,
+                                        N, L, D, H, F_._view(obar, 0, L, dh), 0, st), 'fwd')
+
+    def bwd_dst():
+        _lib.check(lib.ampconv_bwd_edge_dst(Qv, Kv, Vv, dOv, csr.rowptr.data_ptr(), csr.col.data_ptr(),
+                                            N, L, D, H, dQv, 0, st), 'bwd_dst')
+
+    def bwd_src():
+        _lib.check(lib.ampconv_bwd_edge_src(Qv, Kv, Vv, dOv, csr.cscptr.data_ptr(), csr.crow.data_ptr(),
+                                            csr.rowptr.data_ptr(), N, L, D, H, dKv, dVv, 0, st), 'bwd_src')
+
+    for name, fn, nbytes, flops in (
+            ('fwd_edge', fwd, (2 * E + 2 * N) * R, 4 * L * L * D * E),
+            ('bwd_edge_dst', bwd_dst, (2 * E + 3 * N) * R, 6 * L * L * D * E),
+            ('bwd_edge_src', bwd_src, (2 * E + 4 * N) * R, 8 * L * L * D * E)):
+        ms = timeit(fn)
+        print(f'{name:14s} {ms:9.3f} ms  {E / ms / 1e3:8.2f} M edges/s  '
+              f'{nbytes / ms / 1e9:7.2f} TB/s alg  {flops / ms / 1e9:7.1f} TFLOP/s')
+
+
+if __name__ == '__main__':
+    main()
