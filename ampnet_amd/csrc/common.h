@@ -51,3 +51,11 @@ int ampconv_fwd_edge_mfma(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
                           const int32_t *rowptr, const int32_t *col, const int32_t *qidx,
                           int64_t n_rows, int L, int D, int H, ampconv_view_t O,
                           hipStream_t stream);
+int ampconv_bwd_edge_dst_mfma(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
+                              ampconv_view_t dO, const int32_t *rowptr, const int32_t *col,
+                              int64_t n_rows, int L, int D, int H, ampconv_view_t dQ,
+                              hipStream_t stream);
+int ampconv_bwd_edge_src_mfma(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
+                              ampconv_view_t dO, const int32_t *cscptr, const int32_t *crow,
+                              const int32_t *rowptr, int64_t n_src, int L, int D, int H,
+                              ampconv_view_t dK, ampconv_view_t dV, hipStream_t stream);

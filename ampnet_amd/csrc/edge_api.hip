@@ -54,6 +54,10 @@ extern "C" int ampconv_bwd_edge_dst(ampconv_view_t Q, ampconv_view_t K, ampconv_
   if (n_rows == 0) return AMPCONV_OK;
   if (!view_ok(Q) || !view_ok(K) || !view_ok(V) || !view_ok(dObar) || !view_ok(dQ) || !rowptr)
     return AMPCONV_E_BADARG;
+  const ampconv_view_t views[] = {Q, K, V, dObar, dQ};
+  if (!force_generic() && ampconv_mfma_supported(L, D, H) && ampconv_mfma_views_ok(views, 5))
+    return ampconv_bwd_edge_dst_mfma(Q, K, V, dObar, rowptr, col, n_rows, L, D, H, dQ,
+                                     (hipStream_t)stream);
   return ampconv_bwd_edge_dst_generic(Q, K, V, dObar, rowptr, col, n_rows, L, D, H, dQ,
                                       (hipStream_t)stream);
 }
@@ -69,6 +73,10 @@ extern "C" int ampconv_bwd_edge_src(ampconv_view_t Q, ampconv_view_t K, ampconv_
   if (!view_ok(Q) || !view_ok(K) || !view_ok(V) || !view_ok(dObar) || !view_ok(dK) ||
       !view_ok(dV) || !cscptr || !rowptr)
     return AMPCONV_E_BADARG;
+  const ampconv_view_t views[] = {Q, K, V, dObar, dK, dV};
+  if (!force_generic() && ampconv_mfma_supported(L, D, H) && ampconv_mfma_views_ok(views, 6))
+    return ampconv_bwd_edge_src_mfma(Q, K, V, dObar, cscptr, crow, rowptr, n_src, L, D, H, dK, dV,
+                                     (hipStream_t)stream);
   return ampconv_bwd_edge_src_generic(Q, K, V, dObar, cscptr, crow, rowptr, n_src, L, D, H, dK,
                                       dV, (hipStream_t)stream);
 }

@@ -146,6 +146,249 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void fwd_mfma(FwdArgs a) {
   }
 }
 
+struct BwdArgs {
+  ampconv_view_t Q, K, V, dO, dQ, dK, dV;
+  const int32_t *ptr;      // rowptr (dst pass) / cscptr (src pass)
+  const int32_t *idx;      // col (dst pass) / crow (src pass)
+  const int32_t *rowptr;   // dst CSR pointers (1/deg of a destination)
+  int64_t n_units;
+  int L, H;
+  float qscale;            // log2(e) / sqrt(dh)
+  float oscale;            // 1 / sqrt(dh) (dst pass) or ln 2 (src pass): final factor of dQ / dK
+};
+
+// ---- backward, destination pass: dQ[r], one wave per (destination, head).
+//   S^T = K Q^T, P^T = softmax;  dP^T = V dO^T;  delta = colsum(P^T o dP^T);
+//   dS^T = P^T o (dP^T - delta);  dQ^T += K^T dS^T   (dS^T C/D registers = B operand)
+template <int DH>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void bwd_dst_mfma(BwdArgs a) {
+  using C = TileCfg<DH>;
+  __shared__ __attribute__((aligned(16))) float lds_all[kWavesPerBlock][2][C::TILE_FLOATS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t unit = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  if (unit >= a.n_units) return;
+  const int64_t r = unit / a.H;
+  const int h = (int)(unit - r * a.H);
+  const int L = a.L, g = lane >> 4;
+  float *Kt = lds_all[wave][0], *Vt = lds_all[wave][1];
+  const int beg = a.ptr[r], end = a.ptr[r + 1];
+  const float inv = end > beg ? 1.f / (float)(end - beg) : 0.f;
+
+  float qB[2][C::KK], dOB[2][C::KK];
+  {
+    const float *qb = tile_ptr<const float>(a.Q, r, h);
+    const float *gb = tile_ptr<const float>(a.dO, r, h);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      rowop_from_global<DH>(qB[nt], qb, a.Q.row_stride, nt, true, a.qscale, L, lane);
+      rowop_from_global<DH>(dOB[nt], gb, a.dO.row_stride, nt, true, inv, L, lane);
+    }
+  }
+  if (L < kLmax) {
+    tile_zero<DH>(Kt, lane);
+    tile_zero<DH>(Vt, lane);
+  }
+  f32x4 dQT[C::MC][2];
+#pragma unroll
+  for (int mc = 0; mc < C::MC; ++mc) dQT[mc][0] = dQT[mc][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  TileRegs<DH> kr, vr;
+  if (beg < end) {
+    const int64_t s = a.idx[beg];
+    tile_load<DH>(kr, tile_ptr<const float>(a.K, s, h), a.K.row_stride, L, lane);
+    tile_load<DH>(vr, tile_ptr<const float>(a.V, s, h), a.V.row_stride, L, lane);
+  }
+  for (int p = beg; p < end; ++p) {
+    tile_to_lds<DH>(Kt, kr, 1.f, L, lane);
+    tile_to_lds<DH>(Vt, vr, 1.f, L, lane);
+    if (p + 1 < end) {
+      const int64_t s = a.idx[p + 1];
+      tile_load<DH>(kr, tile_ptr<const float>(a.K, s, h), a.K.row_stride, L, lane);
+      tile_load<DH>(vr, tile_ptr<const float>(a.V, s, h), a.V.row_stride, L, lane);
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    f32x4 S[2][2], dP[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      float kA[C::KK], vA[C::KK];
+      rowop_from_lds<DH>(kA, Kt, mt, lane);
+      rowop_from_lds<DH>(vA, Vt, mt, lane);
+      S[mt][0] = S[mt][1] = dP[mt][0] = dP[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < C::KK; ++kk) {
+        S[mt][0] = MFMA16(kA[kk], qB[0][kk], S[mt][0]);
+        S[mt][1] = MFMA16(kA[kk], qB[1][kk], S[mt][1]);
+        dP[mt][0] = MFMA16(vA[kk], dOB[0][kk], dP[mt][0]);
+        dP[mt][1] = MFMA16(vA[kk], dOB[1][kk], dP[mt][1]);
+      }
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      column_softmax(S[0][nt], S[1][nt], L, g);
+      float part = S[1][nt][0] * dP[1][nt][0];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) part = fmaf(S[0][nt][q], dP[0][nt][q], part);
+      const float delta = groups_sum(part);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) S[0][nt][q] *= dP[0][nt][q] - delta;     // S now holds dS^T
+      S[1][nt][0] *= dP[1][nt][0] - delta;
+    }
+#pragma unroll
+    for (int mc = 0; mc < C::MC; ++mc) {
+      float kC[5];
+      colop_from_lds<DH>(kC, Kt, mc, lane);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) dQT[mc][nt] = MFMA16(kC[s], S[0][nt][s], dQT[mc][nt]);
+        dQT[mc][nt] = MFMA16(kC[4], S[1][nt][0], dQT[mc][nt]);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  float *ob = tile_ptr<float>(a.dQ, r, h);
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int i = (lane & 15) + 16 * nt;
+    if (i < L) {
+#pragma unroll
+      for (int mc = 0; mc < C::MC; ++mc) {
+        float4 o = make_float4(dQT[mc][nt][0] * a.oscale, dQT[mc][nt][1] * a.oscale,
+                               dQT[mc][nt][2] * a.oscale, dQT[mc][nt][3] * a.oscale);
+        *reinterpret_cast<float4 *>(ob + (int64_t)i * a.dQ.row_stride + 4 * g + 16 * mc) = o;
+      }
+    }
+  }
+}
+
+// ---- backward, source pass: dK[s], dV[s], one wave per (source, head) over the CSC.
+//   S = Q K^T (destination tokens on MFMA rows, source tokens on columns), P = row softmax
+//   (16-lane DPP reductions), dP = dO V^T, dS = P o (dP - delta);
+//   dV^T += dO^T P,  dK^T += Q^T dS      (P / dS C/D registers = B operands)
+template <int DH>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void bwd_src_mfma(BwdArgs a) {
+  using C = TileCfg<DH>;
+  __shared__ __attribute__((aligned(16))) float lds_all[kWavesPerBlock][2][C::TILE_FLOATS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t unit = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  if (unit >= a.n_units) return;
+  const int64_t s = unit / a.H;
+  const int h = (int)(unit - s * a.H);
+  const int L = a.L, n = lane & 15;
+  float *Qt = lds_all[wave][0], *Gt = lds_all[wave][1];
+  const int beg = a.ptr[s], end = a.ptr[s + 1];
+
+  float kB[2][C::KK], vB[2][C::KK];
+  {
+    const float *kb = tile_ptr<const float>(a.K, s, h);
+    const float *vb = tile_ptr<const float>(a.V, s, h);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      rowop_from_global<DH>(kB[nt], kb, a.K.row_stride, nt, true, 1.f, L, lane);
+      rowop_from_global<DH>(vB[nt], vb, a.V.row_stride, nt, true, 1.f, L, lane);
+    }
+  }
+  if (L < kLmax) {
+    tile_zero<DH>(Qt, lane);
+    tile_zero<DH>(Gt, lane);
+  }
+  f32x4 dKT[C::MC][2], dVT[C::MC][2];
+#pragma unroll
+  for (int mc = 0; mc < C::MC; ++mc)
+    dKT[mc][0] = dKT[mc][1] = dVT[mc][0] = dVT[mc][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  TileRegs<DH> qr, gr;
+  float inv = 0.f;
+  if (beg < end) {
+    const int64_t d = a.idx[beg];
+    inv = 1.f / (float)(a.rowptr[d + 1] - a.rowptr[d]);
+    tile_load<DH>(qr, tile_ptr<const float>(a.Q, d, h), a.Q.row_stride, L, lane);
+    tile_load<DH>(gr, tile_ptr<const float>(a.dO, d, h), a.dO.row_stride, L, lane);
+  }
+  for (int p = beg; p < end; ++p) {
+    tile_to_lds<DH>(Qt, qr, a.qscale, L, lane);
+    tile_to_lds<DH>(Gt, gr, inv, L, lane);
+    if (p + 1 < end) {
+      const int64_t d = a.idx[p + 1];
+      inv = 1.f / (float)(a.rowptr[d + 1] - a.rowptr[d]);
+      tile_load<DH>(qr, tile_ptr<const float>(a.Q, d, h), a.Q.row_stride, L, lane);
+      tile_load<DH>(gr, tile_ptr<const float>(a.dO, d, h), a.dO.row_stride, L, lane);
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    f32x4 S[2][2], dP[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      float qA[C::KK], gA[C::KK];
+      rowop_from_lds<DH>(qA, Qt, mt, lane);
+      rowop_from_lds<DH>(gA, Gt, mt, lane);
+      S[mt][0] = S[mt][1] = dP[mt][0] = dP[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < C::KK; ++kk) {
+        S[mt][0] = MFMA16(qA[kk], kB[0][kk], S[mt][0]);
+        S[mt][1] = MFMA16(qA[kk], kB[1][kk], S[mt][1]);
+        dP[mt][0] = MFMA16(gA[kk], vB[0][kk], dP[mt][0]);
+        dP[mt][1] = MFMA16(gA[kk], vB[1][kk], dP[mt][1]);
+      }
+    }
+    // row softmax over the source tokens: columns n (+16 for tile 1) across the 16 lanes
+    const bool v0 = n < L, v1 = 16 + n < L;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+      for (int q = 0; q < (mt == 0 ? 4 : 1); ++q) {
+        const float s0 = v0 ? S[mt][0][q] : -INFINITY, s1 = v1 ? S[mt][1][q] : -INFINITY;
+        const float m = row16_max(fmaxf(s0, s1));
+        float p0 = fast_exp2(s0 - m), p1 = fast_exp2(s1 - m);
+        const float rinv = 1.f / row16_sum(p0 + p1);
+        p0 *= rinv;
+        p1 *= rinv;
+        const float delta = row16_sum(fmaf(p0, dP[mt][0][q], p1 * dP[mt][1][q]));
+        S[mt][0][q] = p0;
+        S[mt][1][q] = p1;
+        dP[mt][0][q] = p0 * (dP[mt][0][q] - delta);       // dP now holds dS
+        dP[mt][1][q] = p1 * (dP[mt][1][q] - delta);
+      }
+    }
+#pragma unroll
+    for (int mc = 0; mc < C::MC; ++mc) {
+      float gC[5], qC[5];
+      colop_from_lds<DH>(gC, Gt, mc, lane);
+      colop_from_lds<DH>(qC, Qt, mc, lane);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          dVT[mc][nt] = MFMA16(gC[t], S[0][nt][t], dVT[mc][nt]);
+          dKT[mc][nt] = MFMA16(qC[t], dP[0][nt][t], dKT[mc][nt]);
+        }
+        dVT[mc][nt] = MFMA16(gC[4], S[1][nt][0], dVT[mc][nt]);
+        dKT[mc][nt] = MFMA16(qC[4], dP[1][nt][0], dKT[mc][nt]);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+
+  const int g = lane >> 4;
+  float *kb = tile_ptr<float>(a.dK, s, h), *vb = tile_ptr<float>(a.dV, s, h);
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int j = n + 16 * nt;
+    if (j < L) {
+#pragma unroll
+      for (int mc = 0; mc < C::MC; ++mc) {
+        float4 k4 = make_float4(dKT[mc][nt][0] * a.oscale, dKT[mc][nt][1] * a.oscale,
+                                dKT[mc][nt][2] * a.oscale, dKT[mc][nt][3] * a.oscale);
+        float4 v4 = make_float4(dVT[mc][nt][0], dVT[mc][nt][1], dVT[mc][nt][2], dVT[mc][nt][3]);
+        *reinterpret_cast<float4 *>(kb + (int64_t)j * a.dK.row_stride + 4 * g + 16 * mc) = k4;
+        *reinterpret_cast<float4 *>(vb + (int64_t)j * a.dV.row_stride + 4 * g + 16 * mc) = v4;
+      }
+    }
+  }
+}
+
 inline bool aligned16(const ampconv_view_t &v) {
   return ((uintptr_t)v.ptr % 16 == 0) && (v.node_stride % 4 == 0) && (v.row_stride % 4 == 0) &&
          (v.head_stride % 4 == 0);
@@ -176,5 +419,45 @@ int ampconv_fwd_edge_mfma(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
     fwd_mfma<32><<<(unsigned)blocks, 64 * kWavesPerBlock, 0, stream>>>(a);
   else
     fwd_mfma<16><<<(unsigned)blocks, 64 * kWavesPerBlock, 0, stream>>>(a);
+  return ampconv_launch_status();
+}
+
+int ampconv_bwd_edge_dst_mfma(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
+                              ampconv_view_t dO, const int32_t *rowptr, const int32_t *col,
+                              int64_t n_rows, int L, int D, int H, ampconv_view_t dQ,
+                              hipStream_t stream) {
+  const int dh = D / H;
+  BwdArgs a{};
+  a.Q = Q; a.K = K; a.V = V; a.dO = dO; a.dQ = dQ;
+  a.ptr = rowptr; a.idx = col; a.rowptr = rowptr;
+  a.n_units = n_rows * H; a.L = L; a.H = H;
+  a.qscale = kLog2e / sqrtf((float)dh);
+  a.oscale = 1.f / sqrtf((float)dh);
+  const int64_t blocks = (a.n_units + kWavesPerBlock - 1) / kWavesPerBlock;
+  if (blocks > INT32_MAX) return AMPCONV_E_BADARG;
+  if (dh == 32)
+    bwd_dst_mfma<32><<<(unsigned)blocks, 64 * kWavesPerBlock, 0, stream>>>(a);
+  else
+    bwd_dst_mfma<16><<<(unsigned)blocks, 64 * kWavesPerBlock, 0, stream>>>(a);
+  return ampconv_launch_status();
+}
+
+int ampconv_bwd_edge_src_mfma(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
+                              ampconv_view_t dO, const int32_t *cscptr, const int32_t *crow,
+                              const int32_t *rowptr, int64_t n_src, int L, int D, int H,
+                              ampconv_view_t dK, ampconv_view_t dV, hipStream_t stream) {
+  const int dh = D / H;
+  BwdArgs a{};
+  a.Q = Q; a.K = K; a.V = V; a.dO = dO; a.dK = dK; a.dV = dV;
+  a.ptr = cscptr; a.idx = crow; a.rowptr = rowptr;
+  a.n_units = n_src * H; a.L = L; a.H = H;
+  a.qscale = kLog2e / sqrtf((float)dh);
+  a.oscale = 0.6931471805599453f;     // dK = ln2 * sum dS^T (Q * log2e / sqrt(dh))
+  const int64_t blocks = (a.n_units + kWavesPerBlock - 1) / kWavesPerBlock;
+  if (blocks > INT32_MAX) return AMPCONV_E_BADARG;
+  if (dh == 32)
+    bwd_src_mfma<32><<<(unsigned)blocks, 64 * kWavesPerBlock, 0, stream>>>(a);
+  else
+    bwd_src_mfma<16><<<(unsigned)blocks, 64 * kWavesPerBlock, 0, stream>>>(a);
   return ampconv_launch_status();
 }

@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""bench.py -- AMPConv edges/sec (forward + backward) on MI355X.
+
+One "step" = one pass of the hot path over one batch: CSR/CSC build of the
+batch's edge_index + one AMPConv layer forward + backward (gradients w.r.t. x
+and the four parameters), fp32, on a synthetic uniform random graph of the
+shape BASELINE.json names (config 4: 1 M nodes / 10 M edges, L=20 tokens,
+D=256, 8 heads).  With N > 1 GPUs every rank processes its OWN graph of that
+shape (one-subgraph-per-GPU data parallelism, weak scaling) and the parameter
+gradients are averaged with one RCCL all-reduce per step inside the timed
+region (experiments/cora_benchmark_graphsaint_distributed.py:63-94 as intended).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg4|cfg3|cora|tiny]
+
+Prints ONE JSON line on rank 0.  `roofline` prices the dominant kernel against
+the 8 TB/s HBM3E spec peak with durations measured live by HIP events on the
+launch stream over the timed region; `cpu_baseline` is the reference-shaped CPU
+restatement (oracle/ampconv_torch.py) timed on the host cores on a bounded
+sub-sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+WORKLOADS = {
+    # name: (N, E, L, D, H, description)
+    'cfg4': (1_000_000, 10_000_000, 20, 256, 8,
+             'BASELINE config 4: uniform random graph 1M nodes / 10M edges, L=20, D=256, H=8'),
+    'cfg3': (100_000, 1_000_000, 20, 128, 8,
+             'BASELINE config 3: uniform random graph 100k nodes / 1M edges, L=20, D=128, H=8'),
+    'cora': (2708, 10556, 20, 128, 4, 'BASELINE config 1/2 shape: Cora-sized random graph, L=20, D=128, H=4'),
+    'tiny': (2000, 20000, 20, 256, 8, 'smoke-sized graph of the config-4 layer shape'),
+}
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+class KernelTimer:
+    """HIP events (torch.cuda.Event on the launch stream = torch's current stream) around
+    each C-ABI edge kernel; installed into ampnet_amd.conv.functional for the timed steps."""
+
+    def __init__(self):
+        self.events = {}
+        self.enabled = False
+
+    def wrap(self, lib, name):
+        fn = getattr(lib, name)
+
+        def timed(*args):
+            if not self.enabled:
+                return fn(*args)
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = fn(*args)
+            e1.record()
+            self.events.setdefault(name, []).append((e0, e1))
+            return rc
+        return timed
+
+    def summary(self):
+        return {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in self.events.items() if v}
+
+
+class TimedLib:
+    def __init__(self, lib, timer):
+        self._lib = lib
+        for n in ('ampconv_fwd_edge', 'ampconv_bwd_edge_dst', 'ampconv_bwd_edge_src'):
+            setattr(self, n, timer.wrap(lib, n))
+
+    def __getattr__(self, name):
+        return getattr(self._lib, name)
+
+
+def make_batch(N, E, L, D, seed, dev):
+    g = torch.Generator(device=dev).manual_seed(seed)
+    x = torch.randn(N, L * D, generator=g, device=dev, dtype=torch.float32)
+    ei = torch.randint(0, N, (2, E), generator=g, device=dev, dtype=torch.int64)
+    dy = torch.randn(N, L * D, generator=g, device=dev, dtype=torch.float32)
+    return x, ei, dy
+
+
+def host_cores():
+    """CPU threads this process may really use: affinity mask, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, int(os.environ.get('AMPCONV_CPU_THREADS', n))))
+
+
+def cpu_baseline(L, D, H, ratio):
+    """Reference-shaped CPU path (gather -> nn.MultiheadAttention -> scatter-mean), fwd+bwd,
+    on a bounded sub-sample with the workload's L, D, H and E/N."""
+    from oracle.ampconv_torch import RefShapedAMPConv
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    n_cpu = 3000
+    e_cpu = int(n_cpu * ratio)
+    torch.manual_seed(1)
+    layer = RefShapedAMPConv(D, H)
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(n_cpu, L * D, generator=g, requires_grad=True)
+    ei = torch.randint(0, n_cpu, (2, e_cpu), generator=g)
+    dy = torch.randn(n_cpu, L * D, generator=g)
+
+    def step(edges):
+        layer.zero_grad(set_to_none=True)
+        x.grad = None
+        y = layer(x, edges)
+        (y * dy).sum().backward()
+
+    step(ei[:, : e_cpu // 8])                 # warm-up on an eighth of the sample
+    best = float('inf')
+    for _ in range(2):
+        t0 = time.perf_counter()
+        step(ei)
+        best = min(best, time.perf_counter() - t0)
+    return {'value': e_cpu / best, 'unit': 'edges/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{n_cpu} nodes / {e_cpu} edges, L={L} D={D} H={H} fp32, fwd+bwd, best of 2, '
+                      f'torch {torch.__version__} CPU, {cores} threads'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--workload', default=os.environ.get('AMPCONV_BENCH_WORKLOAD', 'cfg4'))
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    assert torch.cuda.is_available(), 'bench.py needs a GPU'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)       # nccl == RCCL on ROCm
+
+    from ampnet_amd import AMPConv, graph_cache, _lib
+    from ampnet_amd.conv import functional as F_
+    from ampnet_amd.distributed import GradientAllReducer, broadcast_parameters
+
+    N, E, L, D, H, desc = WORKLOADS[args.workload]
+    R = L * D * 4
+    torch.manual_seed(1)
+    layer = AMPConv(D, H).to(dev)
+    layer.retain_attention = False                            # no [E, L, L] side output kept alive
+    with torch.no_grad():
+        layer.multi_head_attention.in_proj_bias.normal_(0, 0.1)
+        layer.multi_head_attention.out_proj.bias.normal_(0, 0.1)
+    if world > 1:
+        broadcast_parameters(layer, src=0)
+    reducer = GradientAllReducer(layer.parameters())
+
+    x, ei, dy = make_batch(N, E, L, D, 1234 + rank, dev)      # each rank: its own graph
+    x.requires_grad_(True)
+
+    timer = KernelTimer()
+    real_lib = _lib.load()
+    timed_lib = TimedLib(real_lib, timer)
+    orig_load = _lib.load
+    _lib.load = lambda: timed_lib                             # functional.py resolves the lib per call
+
+    def step():
+        graph_cache.clear()                                   # a new batch -> CSR build is in the step
+        layer.zero_grad(set_to_none=True)
+        x.grad = None
+        y = layer(x, ei)
+        y.backward(dy)
+        if world > 1:
+            reducer.allreduce()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    timer.enabled = False
+    _lib.load = orig_load
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    if rank == 0:
+        ms = timer.summary()
+        alg = {'ampconv_fwd_edge': (2 * E + 2 * N) * R, 'ampconv_bwd_edge_dst': (2 * E + 3 * N) * R,
+               'ampconv_bwd_edge_src': (2 * E + 4 * N) * R}
+        dom = max(ms, key=ms.get)
+        achieved = alg[dom] / (ms[dom] * 1e-3) / 1e9
+        value = world * E * args.steps / dt
+        b_alg = (6 * E + 15 * N) * R + 16 * E                 # whole layer, SURVEY.md 8d
+        out = {
+            'metric': 'AMPConv edges/sec (fwd+bwd)', 'value': value, 'unit': 'edges/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'{args.workload}: {desc}, one AMPConv layer fwd+bwd incl. CSR build, '
+                                   f'one graph per GPU' + (' + RCCL grad all-reduce' if world > 1 else ''),
+                       'N': N, 'E': E, 'L': L, 'D': D, 'H': H, 'parallelism': f'dp{world}'},
+            'layer_hbm': {'algorithmic_bytes_per_step': b_alg,
+                          'achieved_GBps_per_gpu': b_alg * args.steps / dt / 1e9,
+                          'frac_of_8TBps': b_alg * args.steps / dt / 1e9 / HBM_PEAK_GBS},
+            'kernels_ms': ms,
+            'roofline': {'kernel': dom, 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
+                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'algorithmic_bytes_per_launch': alg[dom], 'avg_launch_ms': ms[dom]},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            del x, dy
+            torch.cuda.empty_cache()
+            out['cpu_baseline'] = cpu_baseline(L, D, H, E / N)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
