@@ -30,12 +30,13 @@ struct FwdArgs {
 
 // softmax over the 20 source tokens of one destination-token column held as
 // (t0[0..3] = tokens 4g..4g+3, t1[0] = token 16+g) across the 4 lane groups g.
+template <bool FULL>
 __device__ __forceinline__ void column_softmax(f32x4 &t0, f32x4 &t1, int L, int g) {
-  if (L < kLmax) {
+  if (!FULL) {
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-      if (4 * g + q >= L) t0[q] = -INFINITY;
-    if (16 + g >= L) t1[0] = -INFINITY;
+      if (4 * g + q >= L) t0[q] = kNegBig;
+    if (16 + g >= L) t1[0] = kNegBig;
   }
   float m = fmaxf(fmaxf(fmaxf(t0[0], t0[1]), fmaxf(t0[2], t0[3])), t1[0]);
   m = groups_max(m);
@@ -44,13 +45,13 @@ __device__ __forceinline__ void column_softmax(f32x4 &t0, f32x4 &t1, int L, int 
   t1[0] = fast_exp2(t1[0] - m);
   float l = (t0[0] + t0[1]) + (t0[2] + t0[3]) + t1[0];
   l = groups_sum(l);
-  const float inv = 1.f / l;
+  const float inv = fast_rcp(l);
 #pragma unroll
   for (int q = 0; q < 4; ++q) t0[q] *= inv;
   t1[0] *= inv;
 }
 
-template <int DH>
+template <int DH, bool FULL>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void fwd_mfma(FwdArgs a) {
   using C = TileCfg<DH>;
   __shared__ __attribute__((aligned(16))) float lds_all[kWavesPerBlock][2][C::TILE_FLOATS];
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void fwd_mfma(FwdArgs a) {
     rowop_from_global<DH>(qB[0], qb, a.Q.row_stride, 0, true, a.qscale, L, lane);
     rowop_from_global<DH>(qB[1], qb, a.Q.row_stride, 1, true, a.qscale, L, lane);
   }
-  if (L < kLmax) {      // token rows >= L of the images are read by the MFMAs: keep them finite
+  if (!FULL) {          // token rows >= L of the images are read by the MFMAs: keep them finite
     tile_zero<DH>(Kt, lane);
     tile_zero<DH>(Vt, lane);
   }
@@ -82,19 +83,18 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void fwd_mfma(FwdArgs a) {
 #pragma unroll
   for (int mc = 0; mc < C::MC; ++mc) OT[mc][0] = OT[mc][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  TileRegs<DH> kr, vr;
+  PairRegs<DH> kv;
   if (beg < end) {
     const int64_t s = a.col[beg];
-    tile_load<DH>(kr, tile_ptr<const float>(a.K, s, h), a.K.row_stride, L, lane);
-    tile_load<DH>(vr, tile_ptr<const float>(a.V, s, h), a.V.row_stride, L, lane);
+    pair_load<DH, FULL>(kv, tile_ptr<const float>(a.K, s, h), a.K.row_stride,
+                        tile_ptr<const float>(a.V, s, h), a.V.row_stride, L, lane);
   }
   for (int p = beg; p < end; ++p) {
-    tile_to_lds<DH>(Kt, kr, 1.f, L, lane);
-    tile_to_lds<DH>(Vt, vr, 1.f, L, lane);
+    pair_to_lds<DH, FULL>(Kt, kv, 1.f, 1.f, L, lane);
     if (p + 1 < end) {                         // next edge's tiles fly while this one computes
       const int64_t s = a.col[p + 1];
-      tile_load<DH>(kr, tile_ptr<const float>(a.K, s, h), a.K.row_stride, L, lane);
-      tile_load<DH>(vr, tile_ptr<const float>(a.V, s, h), a.V.row_stride, L, lane);
+      pair_load<DH, FULL>(kv, tile_ptr<const float>(a.K, s, h), a.K.row_stride,
+                          tile_ptr<const float>(a.V, s, h), a.V.row_stride, L, lane);
     }
     __builtin_amdgcn_wave_barrier();
 
@@ -111,8 +111,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void fwd_mfma(FwdArgs a) {
         S[mt][1] = MFMA16(kA[kk], qB[1][kk], S[mt][1]);
       }
     }
-    column_softmax(S[0][0], S[1][0], L, g);
-    column_softmax(S[0][1], S[1][1], L, g);
+    column_softmax<FULL>(S[0][0], S[1][0], L, g);
+    column_softmax<FULL>(S[0][1], S[1][1], L, g);
 
     // O^T[channel tile mc][destination-token tile nt] += V^T P^T
 #pragma unroll
@@ -160,7 +160,7 @@ struct BwdArgs {
 // ---- backward, destination pass: dQ[r], one wave per (destination, head).
 //   S^T = K Q^T, P^T = softmax;  dP^T = V dO^T;  delta = colsum(P^T o dP^T);
 //   dS^T = P^T o (dP^T - delta);  dQ^T += K^T dS^T   (dS^T C/D registers = B operand)
-template <int DH>
+template <int DH, bool FULL>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void bwd_dst_mfma(BwdArgs a) {
   using C = TileCfg<DH>;
   __shared__ __attribute__((aligned(16))) float lds_all[kWavesPerBlock][2][C::TILE_FLOATS];
@@ -184,7 +184,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void bwd_dst_mfma(BwdArgs a) {
       rowop_from_global<DH>(dOB[nt], gb, a.dO.row_stride, nt, true, inv, L, lane);
     }
   }
-  if (L < kLmax) {
+  if (!FULL) {
     tile_zero<DH>(Kt, lane);
     tile_zero<DH>(Vt, lane);
   }
@@ -192,19 +192,18 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void bwd_dst_mfma(BwdArgs a) {
 #pragma unroll
   for (int mc = 0; mc < C::MC; ++mc) dQT[mc][0] = dQT[mc][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  TileRegs<DH> kr, vr;
+  PairRegs<DH> kv;
   if (beg < end) {
     const int64_t s = a.idx[beg];
-    tile_load<DH>(kr, tile_ptr<const float>(a.K, s, h), a.K.row_stride, L, lane);
-    tile_load<DH>(vr, tile_ptr<const float>(a.V, s, h), a.V.row_stride, L, lane);
+    pair_load<DH, FULL>(kv, tile_ptr<const float>(a.K, s, h), a.K.row_stride,
+                        tile_ptr<const float>(a.V, s, h), a.V.row_stride, L, lane);
   }
   for (int p = beg; p < end; ++p) {
-    tile_to_lds<DH>(Kt, kr, 1.f, L, lane);
-    tile_to_lds<DH>(Vt, vr, 1.f, L, lane);
+    pair_to_lds<DH, FULL>(Kt, kv, 1.f, 1.f, L, lane);
     if (p + 1 < end) {
       const int64_t s = a.idx[p + 1];
-      tile_load<DH>(kr, tile_ptr<const float>(a.K, s, h), a.K.row_stride, L, lane);
-      tile_load<DH>(vr, tile_ptr<const float>(a.V, s, h), a.V.row_stride, L, lane);
+      pair_load<DH, FULL>(kv, tile_ptr<const float>(a.K, s, h), a.K.row_stride,
+                          tile_ptr<const float>(a.V, s, h), a.V.row_stride, L, lane);
     }
     __builtin_amdgcn_wave_barrier();
 
@@ -225,7 +224,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void bwd_dst_mfma(BwdArgs a) {
     }
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
-      column_softmax(S[0][nt], S[1][nt], L, g);
+      column_softmax<FULL>(S[0][nt], S[1][nt], L, g);
       float part = S[1][nt][0] * dP[1][nt][0];
 #pragma unroll
       for (int q = 0; q < 4; ++q) part = fmaf(S[0][nt][q], dP[0][nt][q], part);
@@ -267,7 +266,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void bwd_dst_mfma(BwdArgs a) {
 //   S = Q K^T (destination tokens on MFMA rows, source tokens on columns), P = row softmax
 //   (16-lane DPP reductions), dP = dO V^T, dS = P o (dP - delta);
 //   dV^T += dO^T P,  dK^T += Q^T dS      (P / dS C/D registers = B operands)
-template <int DH>
+template <int DH, bool FULL>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void bwd_src_mfma(BwdArgs a) {
   using C = TileCfg<DH>;
   __shared__ __attribute__((aligned(16))) float lds_all[kWavesPerBlock][2][C::TILE_FLOATS];
@@ -290,7 +289,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void bwd_src_mfma(BwdArgs a) {
       rowop_from_global<DH>(vB[nt], vb, a.V.row_stride, nt, true, 1.f, L, lane);
     }
   }
-  if (L < kLmax) {
+  if (!FULL) {
     tile_zero<DH>(Qt, lane);
     tile_zero<DH>(Gt, lane);
   }
@@ -299,22 +298,21 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void bwd_src_mfma(BwdArgs a) {
   for (int mc = 0; mc < C::MC; ++mc)
     dKT[mc][0] = dKT[mc][1] = dVT[mc][0] = dVT[mc][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  TileRegs<DH> qr, gr;
+  PairRegs<DH> qg;
   float inv = 0.f;
   if (beg < end) {
     const int64_t d = a.idx[beg];
     inv = 1.f / (float)(a.rowptr[d + 1] - a.rowptr[d]);
-    tile_load<DH>(qr, tile_ptr<const float>(a.Q, d, h), a.Q.row_stride, L, lane);
-    tile_load<DH>(gr, tile_ptr<const float>(a.dO, d, h), a.dO.row_stride, L, lane);
+    pair_load<DH, FULL>(qg, tile_ptr<const float>(a.Q, d, h), a.Q.row_stride,
+                        tile_ptr<const float>(a.dO, d, h), a.dO.row_stride, L, lane);
   }
   for (int p = beg; p < end; ++p) {
-    tile_to_lds<DH>(Qt, qr, a.qscale, L, lane);
-    tile_to_lds<DH>(Gt, gr, inv, L, lane);
+    pair_to_lds<DH, FULL>(Qt, qg, a.qscale, inv, L, lane);
     if (p + 1 < end) {
       const int64_t d = a.idx[p + 1];
       inv = 1.f / (float)(a.rowptr[d + 1] - a.rowptr[d]);
-      tile_load<DH>(qr, tile_ptr<const float>(a.Q, d, h), a.Q.row_stride, L, lane);
-      tile_load<DH>(gr, tile_ptr<const float>(a.dO, d, h), a.dO.row_stride, L, lane);
+      pair_load<DH, FULL>(qg, tile_ptr<const float>(a.Q, d, h), a.Q.row_stride,
+                          tile_ptr<const float>(a.dO, d, h), a.dO.row_stride, L, lane);
     }
     __builtin_amdgcn_wave_barrier();
 
@@ -339,10 +337,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void bwd_src_mfma(BwdArgs a) {
     for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
       for (int q = 0; q < (mt == 0 ? 4 : 1); ++q) {
-        const float s0 = v0 ? S[mt][0][q] : -INFINITY, s1 = v1 ? S[mt][1][q] : -INFINITY;
+        const float s0 = v0 ? S[mt][0][q] : kNegBig, s1 = v1 ? S[mt][1][q] : kNegBig;
         const float m = row16_max(fmaxf(s0, s1));
         float p0 = fast_exp2(s0 - m), p1 = fast_exp2(s1 - m);
-        const float rinv = 1.f / row16_sum(p0 + p1);
+        const float rinv = fast_rcp(row16_sum(p0 + p1));
         p0 *= rinv;
         p1 *= rinv;
         const float delta = row16_sum(fmaf(p0, dP[mt][0][q], p1 * dP[mt][1][q]));
@@ -415,10 +413,11 @@ int ampconv_fwd_edge_mfma(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
   FwdArgs a{Q, K, V, O, rowptr, col, qidx, n_rows * H, L, H, kLog2e / sqrtf((float)dh)};
   const int64_t blocks = (a.n_units + kWavesPerBlock - 1) / kWavesPerBlock;
   if (blocks > INT32_MAX) return AMPCONV_E_BADARG;
-  if (dh == 32)
-    fwd_mfma<32><<<(unsigned)blocks, 64 * kWavesPerBlock, 0, stream>>>(a);
-  else
-    fwd_mfma<16><<<(unsigned)blocks, 64 * kWavesPerBlock, 0, stream>>>(a);
+  const dim3 grid((unsigned)blocks), block(64 * kWavesPerBlock);
+  if (dh == 32 && L == kLmax) fwd_mfma<32, true><<<grid, block, 0, stream>>>(a);
+  else if (dh == 32) fwd_mfma<32, false><<<grid, block, 0, stream>>>(a);
+  else if (L == kLmax) fwd_mfma<16, true><<<grid, block, 0, stream>>>(a);
+  else fwd_mfma<16, false><<<grid, block, 0, stream>>>(a);
   return ampconv_launch_status();
 }
 
@@ -435,10 +434,11 @@ int ampconv_bwd_edge_dst_mfma(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t
   a.oscale = 1.f / sqrtf((float)dh);
   const int64_t blocks = (a.n_units + kWavesPerBlock - 1) / kWavesPerBlock;
   if (blocks > INT32_MAX) return AMPCONV_E_BADARG;
-  if (dh == 32)
-    bwd_dst_mfma<32><<<(unsigned)blocks, 64 * kWavesPerBlock, 0, stream>>>(a);
-  else
-    bwd_dst_mfma<16><<<(unsigned)blocks, 64 * kWavesPerBlock, 0, stream>>>(a);
+  const dim3 grid((unsigned)blocks), block(64 * kWavesPerBlock);
+  if (dh == 32 && L == kLmax) bwd_dst_mfma<32, true><<<grid, block, 0, stream>>>(a);
+  else if (dh == 32) bwd_dst_mfma<32, false><<<grid, block, 0, stream>>>(a);
+  else if (L == kLmax) bwd_dst_mfma<16, true><<<grid, block, 0, stream>>>(a);
+  else bwd_dst_mfma<16, false><<<grid, block, 0, stream>>>(a);
   return ampconv_launch_status();
 }
 
@@ -455,9 +455,10 @@ int ampconv_bwd_edge_src_mfma(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t
   a.oscale = 0.6931471805599453f;     // dK = ln2 * sum dS^T (Q * log2e / sqrt(dh))
   const int64_t blocks = (a.n_units + kWavesPerBlock - 1) / kWavesPerBlock;
   if (blocks > INT32_MAX) return AMPCONV_E_BADARG;
-  if (dh == 32)
-    bwd_src_mfma<32><<<(unsigned)blocks, 64 * kWavesPerBlock, 0, stream>>>(a);
-  else
-    bwd_src_mfma<16><<<(unsigned)blocks, 64 * kWavesPerBlock, 0, stream>>>(a);
+  const dim3 grid((unsigned)blocks), block(64 * kWavesPerBlock);
+  if (dh == 32 && L == kLmax) bwd_src_mfma<32, true><<<grid, block, 0, stream>>>(a);
+  else if (dh == 32) bwd_src_mfma<32, false><<<grid, block, 0, stream>>>(a);
+  else if (L == kLmax) bwd_src_mfma<16, true><<<grid, block, 0, stream>>>(a);
+  else bwd_src_mfma<16, false><<<grid, block, 0, stream>>>(a);
   return ampconv_launch_status();
 }

@@ -91,6 +91,51 @@ __device__ __forceinline__ void tile_zero(float *lds, int lane) {
   for (int i = lane; i < TileCfg<DH>::TILE_FLOATS; i += AMPCONV_WAVE) lds[i] = 0.f;
 }
 
+// ---- two tiles (A then B, 2 x 20 token rows) streamed together: 40 rows = 5 full wave-wide
+// loads at DH=32 (no predicated partial load), 3 at DH=16.  FULL = (L == 20): no row guards.
+template <int DH>
+struct PairRegs {
+  static constexpr int NP = (2 * kLmax + TileCfg<DH>::RPI - 1) / TileCfg<DH>::RPI;
+  float4 v[NP];
+};
+
+template <int DH, bool FULL>
+__device__ __forceinline__ void pair_load(PairRegs<DH> &t, const float *baseA, int64_t strideA,
+                                          const float *baseB, int64_t strideB, int L, int lane) {
+  using C = TileCfg<DH>;
+  const int r = lane / C::CH, q = lane % C::CH;
+#pragma unroll
+  for (int i = 0; i < PairRegs<DH>::NP; ++i) {
+    const int R = r + C::RPI * i;
+    const bool isB = R >= kLmax;
+    const int j = isB ? R - kLmax : R;
+    const bool valid = (R < 2 * kLmax) && (FULL || j < L);
+    const float *p = isB ? baseB + (int64_t)j * strideB : baseA + (int64_t)j * strideA;
+    if (valid) t.v[i] = *reinterpret_cast<const float4 *>(p + 4 * q);
+  }
+}
+
+// registers -> the two swizzled LDS images (image B directly behind image A), scaled
+template <int DH, bool FULL>
+__device__ __forceinline__ void pair_to_lds(float *ldsA, const PairRegs<DH> &t, float mulA, float mulB,
+                                            int L, int lane) {
+  using C = TileCfg<DH>;
+  const int r = lane / C::CH, q = lane % C::CH;
+#pragma unroll
+  for (int i = 0; i < PairRegs<DH>::NP; ++i) {
+    const int R = r + C::RPI * i;
+    const bool isB = R >= kLmax;
+    const int j = isB ? R - kLmax : R;
+    const bool valid = (R < 2 * kLmax) && (FULL || j < L);
+    if (valid) {
+      const float mul = isB ? mulB : mulA;
+      float4 x = t.v[i];
+      x.x *= mul; x.y *= mul; x.z *= mul; x.w *= mul;
+      *reinterpret_cast<float4 *>(ldsA + (isB ? C::TILE_FLOATS : 0) + j * DH + ((q ^ swz<DH>(j)) << 2)) = x;
+    }
+  }
+}
+
 // token held by MFMA row m of row-tile mt (quarter map for tile 1; always a valid row < 20)
 __device__ __forceinline__ int row_token(int mt, int m) { return mt == 0 ? m : 16 + (m >> 2); }
 // token held by (k-step, ks) of a column operand / by (reg, lane group) of a C/D tile pair
@@ -169,3 +214,5 @@ __device__ __forceinline__ float row16_sum(float x) {
 }
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+constexpr float kNegBig = -1.0e30f;   // mask value: exp2(kNegBig - m) == 0, no inf/NaN arithmetic

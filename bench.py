@@ -215,6 +215,13 @@ def main():
         achieved = alg[dom] / (ms[dom] * 1e-3) / 1e9
         value = world * E * args.steps / dt
         b_alg = (6 * E + 15 * N) * R + 16 * E                 # whole layer, SURVEY.md 8d
+        traffic = None                                         # PMC-measured HBM bytes per launch
+        try:                                                   # (profiles/pmc_traffic.json, same workload)
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
+            if pmc.get('workload') == args.workload:
+                traffic = pmc['kernels'][dom]['traffic_bytes']
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             'metric': 'AMPConv edges/sec (fwd+bwd)', 'value': value, 'unit': 'edges/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -228,7 +235,7 @@ def main():
                           'frac_of_8TBps': b_alg * args.steps / dt / 1e9 / HBM_PEAK_GBS},
             'kernels_ms': ms,
             'roofline': {'kernel': dom, 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': None,
+                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'algorithmic_bytes_per_launch': alg[dom], 'avg_launch_ms': ms[dom]},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -163,8 +163,9 @@ def test_edge_cases(dev):
 
 
 @pytest.mark.parametrize('shape', [(3000, 30000, 20, 128, 4), (2000, 24000, 20, 256, 8),
-                                   (1500, 9000, 20, 128, 8), (500, 4000, 7, 24, 3)],
-                         ids=['cora_like', 'cfg4_like', 'cfg3_like', 'odd'])
+                                   (1500, 9000, 20, 128, 8), (500, 4000, 7, 24, 3),
+                                   (800, 6000, 13, 64, 2), (800, 6000, 17, 64, 4), (600, 5000, 3, 32, 2)],
+                         ids=['cora_like', 'cfg4_like', 'cfg3_like', 'odd', 'L13_dh32', 'L17_dh16', 'L3_dh16'])
 def test_seeded_vs_oracle(shape, dev):
     """Larger seeded graphs (uniform + one hub + isolated nodes) against the numpy oracle."""
     from ampnet_amd import AMPConv
@@ -221,3 +222,65 @@ def test_properties_medium(dev):
         layer(x[:2000], ei[:, :5000] % 2000)
         w = layer.attn_output_weights
         torch.testing.assert_close(w.sum(-1), torch.ones_like(w[..., 0]), rtol=0, atol=1e-5)
+
+
+def _oracle_rows(layer, x, ei, rows, H):
+    """Oracle forward for a few destination rows of a big graph: the sub-problem made of the
+    in-edges of `rows` (sources relabelled) reproduces those rows exactly."""
+    from oracle.ampconv_numpy import AMPConvOracle
+    src, dst = ei[0].cpu().numpy(), ei[1].cpu().numpy()
+    sel = np.isin(dst, rows)
+    s_sub, d_sub = src[sel], dst[sel]
+    nodes = np.unique(np.concatenate([rows, s_sub]))
+    relabel = {int(n): i for i, n in enumerate(nodes)}
+    ei_sub = np.array([[relabel[int(s)] for s in s_sub], [relabel[int(d)] for d in d_sub]], dtype=np.int64)
+    m = layer.multi_head_attention
+    o = AMPConvOracle(m.in_proj_weight.detach().cpu().numpy(), m.in_proj_bias.detach().cpu().numpy(),
+                      m.out_proj.weight.detach().cpu().numpy(), m.out_proj.bias.detach().cpu().numpy(),
+                      H, dtype=np.float64)
+    y_sub, _ = o.forward(x[torch.from_numpy(nodes).to(x.device)].cpu().numpy(), ei_sub, need_weights=False)
+    return y_sub[[relabel[int(r)] for r in rows]]
+
+
+def test_full_size_config3(dev, monkeypatch):
+    """BASELINE config 3 at full size (100k nodes / 1M edges, L=20, D=128, H=8):
+    sampled destination rows against the oracle, MFMA kernels against the independent
+    shape-generic kernels (forward and every gradient), run-to-run bitwise determinism."""
+    from ampnet_amd import AMPConv, graph_cache
+    N, E, L, D, H = 100_000, 1_000_000, 20, 128, 8
+    torch.manual_seed(21)
+    layer = AMPConv(D, H).to(dev)
+    layer.retain_attention = False
+    with torch.no_grad():
+        layer.multi_head_attention.in_proj_bias.normal_(0, 0.1)
+        layer.multi_head_attention.out_proj.bias.normal_(0, 0.1)
+    g = torch.Generator(device=dev).manual_seed(22)
+    x = torch.randn(N, L * D, device=dev, generator=g)
+    dy = torch.randn(N, L * D, device=dev, generator=g)
+    ei = torch.randint(0, N, (2, E), device=dev, generator=g)
+    ei[1, :3000] = 77                                         # a 3000-in-edge hub
+
+    def run():
+        graph_cache.clear()
+        layer.zero_grad(set_to_none=True)
+        xg = x.clone().requires_grad_(True)
+        y = layer(xg, ei)
+        y.backward(dy)
+        m = layer.multi_head_attention
+        return [t.detach().clone() for t in (y, xg.grad, m.in_proj_weight.grad, m.in_proj_bias.grad,
+                                             m.out_proj.weight.grad, m.out_proj.bias.grad)]
+
+    fast = run()
+    again = run()
+    for a, b in zip(fast, again):
+        assert torch.equal(a, b), 'not bitwise reproducible'
+    rows = np.array([77, 0, 1, 5, 4242, 99_999, 31_337, 12_345])
+    y_ref = _oracle_rows(layer, x, ei, rows, H)
+    assert_close_scaled(fast[0][torch.from_numpy(rows).to(dev)].cpu().numpy(), y_ref, 'y[sampled rows]')
+    monkeypatch.setenv('AMPCONV_FORCE_GENERIC', '1')
+    slow = run()
+    names = ['y', 'dx', 'g_in_proj_weight', 'g_in_proj_bias', 'g_out_proj_weight', 'g_out_proj_bias']
+    for n, a, b in zip(names, fast, slow):
+        assert_close_scaled(a.cpu().numpy(), b.cpu().numpy(), n + ' (mfma vs generic)')
+    deg = torch.bincount(ei[1], minlength=N)
+    assert (fast[0][deg == 0] == 0).all()
