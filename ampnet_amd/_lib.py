@@ -7,10 +7,15 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libampconv.so')
+LIB_PATH = os.environ.get('AMPCONV_LIB_PATH', os.path.join(_HERE, 'libampconv.so'))   # override: dev A/B builds
 
 AMPCONV_F32 = 0
 AMPCONV_BF16 = 1
+AMPCONV_F32_EXACT = 2      # native fp32 MFMA
+AMPCONV_F32_BF16X9 = 3     # fp32 operands split exactly into 3 bf16, 9 partial products
+AMPCONV_F32_BF16X6 = 4     # ... 6 partial products
+PRECISIONS = {'default': AMPCONV_F32, 'exact': AMPCONV_F32_EXACT, 'bf16x9': AMPCONV_F32_BF16X9,
+              'bf16x6': AMPCONV_F32_BF16X6}
 COLSUM_BLOCKS = 1024      # scratch blocks of ampconv_masked_colsum (csrc/node_ops.hip)
 
 
@@ -27,7 +32,7 @@ SIGNATURES = {
     'ampconv_version': (_i32, []),
     'ampconv_error_string': (ctypes.c_char_p, [_i32]),
     'ampconv_csr_workspace_bytes': (_sz, [_i64, _i64]),
-    'ampconv_csr_build': (_i32, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'ampconv_csr_build': (_i32, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'ampconv_fwd_edge': (_i32, [View, View, View, _vp, _vp, _vp, _i64, _i32, _i32, _i32, View, _i32, _vp]),
     'ampconv_bwd_edge_dst': (_i32, [View, View, View, View, _vp, _vp, _i64, _i32, _i32, _i32, View, _i32, _vp]),
     'ampconv_bwd_edge_src': (_i32, [View, View, View, View, _vp, _vp, _vp, _i64, _i32, _i32, _i32,

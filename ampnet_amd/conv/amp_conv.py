@@ -55,6 +55,9 @@ class AMPConv(MessagePassing):
         self._attn_output = None
         self._attn_output_weights = None
         self.retain_attention = True            # keep what the lazy per-edge outputs need
+        # how fp32 products run on the matrix cores: 'default' | 'exact' | 'bf16x9' | 'bf16x6'
+        # (include/ampconv.h, dtype codes); inputs, outputs and accumulation are fp32 in every mode
+        self.precision = 'default'
         self.num_heads = num_heads
         self.embed_dim = embed_dim
         # parameter container only: same init RNG consumption and state-dict keys as the reference
@@ -95,7 +98,8 @@ class AMPConv(MessagePassing):
         if edge_index.device != x.device:
             raise ValueError(f'edge_index is on {edge_index.device} but x is on {x.device}')
         csr = graph_cache.get(edge_index, x.size(0))
-        y, qkv, _ = F_.AMPConvFunction.apply(x, x, *self._params(), csr, self.num_heads, True)
+        y, qkv, _ = F_.AMPConvFunction.apply(x, x, *self._params(), csr, self.num_heads, True,
+                                             _lib.PRECISIONS[self.precision])
         L = x.size(1) // self.embed_dim
         self._set_attn_ctx(qkv, None, edge_index, L, shared=True)
         return y
@@ -109,7 +113,8 @@ class AMPConv(MessagePassing):
             raise ValueError(f'x_i {tuple(x_i.shape)} and x_j {tuple(x_j.shape)} differ')
         E = x_i.size(0)
         csr = EdgeCSR.identity(E, x_i.device)
-        y, q, kv = F_.AMPConvFunction.apply(x_i, x_j, *self._params(), csr, self.num_heads, False)
+        y, q, kv = F_.AMPConvFunction.apply(x_i, x_j, *self._params(), csr, self.num_heads, False,
+                                            _lib.PRECISIONS[self.precision])
         ar = torch.arange(E, dtype=torch.int64, device=x_i.device)
         L = x_i.size(1) // self.embed_dim
         self._set_attn_ctx(q, kv, torch.stack([ar, ar]), L, shared=False)
@@ -171,7 +176,8 @@ class AMPConv(MessagePassing):
             qidx = edge_index[1].to(torch.int32).contiguous()
             o = torch.empty(E * L, D, dtype=torch.float32, device=edge_index.device)
             with torch.cuda.device(edge_index.device):
-                F_.edge_forward(Qv, Kv, Vv, ident, E, L, D, H, o, qidx=qidx)
+                F_.edge_forward(Qv, Kv, Vv, ident, E, L, D, H, o, qidx=qidx,
+                                dtype=_lib.PRECISIONS[self.precision])
             m = self.multi_head_attention
             with torch.no_grad():
                 self._attn_output = torch.addmm(m.out_proj.bias, o, m.out_proj.weight.t()).view(E, L, D)

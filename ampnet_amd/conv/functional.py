@@ -32,10 +32,10 @@ def _ptr(t):
     return t.data_ptr() if t is not None else None
 
 
-def edge_forward(Q, K, V, csr, n_rows, L, D, H, out2d, qidx=None):
+def edge_forward(Q, K, V, csr, n_rows, L, D, H, out2d, qidx=None, dtype=_lib.AMPCONV_F32):
     lib = _lib.load()
     rc = lib.ampconv_fwd_edge(Q, K, V, csr.rowptr.data_ptr(), csr.col.data_ptr(), _ptr(qidx),
-                              n_rows, L, D, H, _view(out2d, 0, L, D // H), _lib.AMPCONV_F32, _stream())
+                              n_rows, L, D, H, _view(out2d, 0, L, D // H), dtype, _stream())
     _lib.check(rc, 'ampconv_fwd_edge')
 
 
@@ -48,7 +48,7 @@ class AMPConvFunction(torch.autograd.Function):
     the pre-gathered x_i / x_j with an identity graph."""
 
     @staticmethod
-    def forward(ctx, xq, xkv, w_in, b_in, w_out, b_out, csr, num_heads, shared):
+    def forward(ctx, xq, xkv, w_in, b_in, w_out, b_out, csr, num_heads, shared, dtype=_lib.AMPCONV_F32):
         lib = _lib.load()
         D = w_out.size(0)
         H = int(num_heads)
@@ -69,12 +69,13 @@ class AMPConvFunction(torch.autograd.Function):
                 Qv = _view(qkv, 0, L, dh)
                 Kv, Vv = _view(kv, 0, L, dh), _view(kv, D, L, dh)
             obar = torch.empty(Nq * L, D, dtype=xq.dtype, device=xq.device)
-            edge_forward(Qv, Kv, Vv, csr, Nq, L, D, H, obar)
+            edge_forward(Qv, Kv, Vv, csr, Nq, L, D, H, obar, dtype=dtype)
             y = torch.addmm(b_out, obar, w_out.t())
             rc = lib.ampconv_mask_rows(y.data_ptr(), csr.rowptr.data_ptr(), Nq, L * D, _stream())
             _lib.check(rc, 'ampconv_mask_rows')
+        ctx.set_materialize_grads(False)     # no zero-filled [N*L, 3D] gradient for the qkv side output
         ctx.save_for_backward(xq2, xkv2, w_in, w_out, qkv, kv, obar)
-        ctx.csr, ctx.dims, ctx.shared = csr, (Nq, Nk, L, D, H), shared
+        ctx.csr, ctx.dims, ctx.shared, ctx.dtype = csr, (Nq, Nk, L, D, H), shared, dtype
         ctx.mark_non_differentiable(qkv)
         if kv is not None:
             ctx.mark_non_differentiable(kv)
@@ -83,6 +84,8 @@ class AMPConvFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy, _dqkv=None, _dkv=None):
         lib = _lib.load()
+        if dy is None:
+            return (None,) * 10
         xq2, xkv2, w_in, w_out, qkv, kv, obar = ctx.saved_tensors
         csr, shared = ctx.csr, ctx.shared
         Nq, Nk, L, D, H = ctx.dims
@@ -112,11 +115,11 @@ class AMPConvFunction(torch.autograd.Function):
                 Qv, Kv, Vv = _view(qkv, 0, L, dh), _view(kv, 0, L, dh), _view(kv, D, L, dh)
                 dQv, dKv, dVv = _view(dqkv, 0, L, dh), _view(dkv, 0, L, dh), _view(dkv, D, L, dh)
             rc = lib.ampconv_bwd_edge_dst(Qv, Kv, Vv, dOv, csr.rowptr.data_ptr(), csr.col.data_ptr(),
-                                          Nq, L, D, H, dQv, _lib.AMPCONV_F32, _stream())
+                                          Nq, L, D, H, dQv, ctx.dtype, _stream())
             _lib.check(rc, 'ampconv_bwd_edge_dst')
             rc = lib.ampconv_bwd_edge_src(Qv, Kv, Vv, dOv, csr.cscptr.data_ptr(), csr.crow.data_ptr(),
-                                          csr.rowptr.data_ptr(), Nk, L, D, H, dKv, dVv,
-                                          _lib.AMPCONV_F32, _stream())
+                                          csr.cinv.data_ptr(), Nk, L, D, H, dKv, dVv,
+                                          ctx.dtype, _stream())
             _lib.check(rc, 'ampconv_bwd_edge_src')
             del dobar
             if shared:
@@ -129,7 +132,7 @@ class AMPConvFunction(torch.autograd.Function):
                 db_in = torch.cat([dqkv.sum(dim=0), dkv.sum(dim=0)])
                 dxq = dqkv.mm(w_in[:D]).view(Nq, L * D) if need_xq else None
                 dxkv = dkv.mm(w_in[D:]).view(Nk, L * D) if need_xkv else None
-        return dxq, dxkv, dw_in, db_in, dw_out, db_out, None, None, None
+        return dxq, dxkv, dw_in, db_in, dw_out, db_out, None, None, None, None
 
 
 def attention_weights(Qv, Kv, edge_index, L, D, H):

@@ -11,9 +11,22 @@ bool force_generic() {
   return e && e[0] == '1';
 }
 int check_common(int L, int D, int H, int dtype) {
-  if (dtype != AMPCONV_F32) return AMPCONV_E_DTYPE;
+  if (dtype != AMPCONV_F32 && dtype != AMPCONV_F32_EXACT && dtype != AMPCONV_F32_BF16X9 &&
+      dtype != AMPCONV_F32_BF16X6)
+    return AMPCONV_E_DTYPE;
   if (L <= 0 || D <= 0 || H <= 0 || D % H != 0) return AMPCONV_E_BADARG;
   return AMPCONV_OK;
+}
+// number of bf16 partial products of the split path to use (9 / 6), or 0 for native fp32 MFMA
+int split_products(int dtype, int L, int D, int H) {
+  if (dtype == AMPCONV_F32) {
+    const char *e = std::getenv("AMPCONV_F32_MODE");
+    if (e && e[0] == 'e') dtype = AMPCONV_F32_EXACT;
+    else if (e && e[0] == 'b' && e[5] == '6') dtype = AMPCONV_F32_BF16X6;
+    else dtype = AMPCONV_F32_BF16X9;
+  }
+  if (dtype == AMPCONV_F32_EXACT || !ampconv_split_supported(L, D, H)) return 0;
+  return dtype == AMPCONV_F32_BF16X6 ? 6 : 9;
 }
 }  // namespace
 
@@ -38,9 +51,13 @@ extern "C" int ampconv_fwd_edge(ampconv_view_t Q, ampconv_view_t K, ampconv_view
   if (n_rows == 0) return AMPCONV_OK;
   if (!view_ok(Q) || !view_ok(K) || !view_ok(V) || !view_ok(O) || !rowptr) return AMPCONV_E_BADARG;
   const ampconv_view_t views[] = {Q, K, V, O};
-  if (!force_generic() && ampconv_mfma_supported(L, D, H) && ampconv_mfma_views_ok(views, 4))
+  if (!force_generic() && ampconv_mfma_supported(L, D, H) && ampconv_mfma_views_ok(views, 4)) {
+    if (const int np = split_products(dtype, L, D, H))
+      return ampconv_fwd_edge_split(np, Q, K, V, rowptr, col, qidx, n_rows, L, D, H, O,
+                                    (hipStream_t)stream);
     return ampconv_fwd_edge_mfma(Q, K, V, rowptr, col, qidx, n_rows, L, D, H, O,
                                  (hipStream_t)stream);
+  }
   return ampconv_fwd_edge_generic(Q, K, V, rowptr, col, qidx, n_rows, L, D, H, O,
                                   (hipStream_t)stream);
 }
@@ -55,28 +72,36 @@ extern "C" int ampconv_bwd_edge_dst(ampconv_view_t Q, ampconv_view_t K, ampconv_
   if (!view_ok(Q) || !view_ok(K) || !view_ok(V) || !view_ok(dObar) || !view_ok(dQ) || !rowptr)
     return AMPCONV_E_BADARG;
   const ampconv_view_t views[] = {Q, K, V, dObar, dQ};
-  if (!force_generic() && ampconv_mfma_supported(L, D, H) && ampconv_mfma_views_ok(views, 5))
+  if (!force_generic() && ampconv_mfma_supported(L, D, H) && ampconv_mfma_views_ok(views, 5)) {
+    if (const int np = split_products(dtype, L, D, H))
+      return ampconv_bwd_edge_dst_split(np, Q, K, V, dObar, rowptr, col, n_rows, L, D, H, dQ,
+                                        (hipStream_t)stream);
     return ampconv_bwd_edge_dst_mfma(Q, K, V, dObar, rowptr, col, n_rows, L, D, H, dQ,
                                      (hipStream_t)stream);
+  }
   return ampconv_bwd_edge_dst_generic(Q, K, V, dObar, rowptr, col, n_rows, L, D, H, dQ,
                                       (hipStream_t)stream);
 }
 
 extern "C" int ampconv_bwd_edge_src(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
                                     ampconv_view_t dObar, const int32_t *cscptr,
-                                    const int32_t *crow, const int32_t *rowptr, int64_t n_src,
+                                    const int32_t *crow, const float *cinv, int64_t n_src,
                                     int L, int D, int H, ampconv_view_t dK, ampconv_view_t dV,
                                     int dtype, void *stream) {
   if (int rc = check_common(L, D, H, dtype)) return rc;
   if (n_src < 0) return AMPCONV_E_BADARG;
   if (n_src == 0) return AMPCONV_OK;
   if (!view_ok(Q) || !view_ok(K) || !view_ok(V) || !view_ok(dObar) || !view_ok(dK) ||
-      !view_ok(dV) || !cscptr || !rowptr)
+      !view_ok(dV) || !cscptr || !cinv)
     return AMPCONV_E_BADARG;
   const ampconv_view_t views[] = {Q, K, V, dObar, dK, dV};
-  if (!force_generic() && ampconv_mfma_supported(L, D, H) && ampconv_mfma_views_ok(views, 6))
-    return ampconv_bwd_edge_src_mfma(Q, K, V, dObar, cscptr, crow, rowptr, n_src, L, D, H, dK, dV,
+  if (!force_generic() && ampconv_mfma_supported(L, D, H) && ampconv_mfma_views_ok(views, 6)) {
+    if (const int np = split_products(dtype, L, D, H))
+      return ampconv_bwd_edge_src_split(np, Q, K, V, dObar, cscptr, crow, cinv, n_src, L, D, H,
+                                        dK, dV, (hipStream_t)stream);
+    return ampconv_bwd_edge_src_mfma(Q, K, V, dObar, cscptr, crow, cinv, n_src, L, D, H, dK, dV,
                                      (hipStream_t)stream);
-  return ampconv_bwd_edge_src_generic(Q, K, V, dObar, cscptr, crow, rowptr, n_src, L, D, H, dK,
+  }
+  return ampconv_bwd_edge_src_generic(Q, K, V, dObar, cscptr, crow, cinv, n_src, L, D, H, dK,
                                       dV, (hipStream_t)stream);
 }

@@ -22,7 +22,7 @@ struct BwdArgs {
   ampconv_view_t Q, K, V, dO, dQ, dK, dV;
   const int32_t *ptr;     // rowptr (dst pass) or cscptr (src pass)
   const int32_t *idx;     // col (dst pass) or crow (src pass)
-  const int32_t *rowptr;  // dst CSR pointer (src pass: 1/deg of each destination)
+  const float *cinv;      // src pass: 1/in-degree of the destination of each CSC edge
   int L, dh, dhp, H;
   float scale;
 };
@@ -175,8 +175,7 @@ __global__ __launch_bounds__(AMPCONV_WAVE) void bwd_src_generic(BwdArgs a) {
   zero_tile(dVs, T, lane);
   for (int p = beg; p < end; ++p) {
     const int64_t d = a.idx[p];
-    const int deg = a.rowptr[d + 1] - a.rowptr[d];
-    const float inv = 1.f / (float)deg;
+    const float inv = a.cinv[p];
     __syncthreads();
     load_tile(Qs, tile_ptr<const float>(a.Q, d, h), L, dh, dhp, a.Q.row_stride, a.scale, lane);
     load_tile(dOs, tile_ptr<const float>(a.dO, d, h), L, dh, dhp, a.dO.row_stride, inv, lane);
@@ -271,7 +270,7 @@ int ampconv_bwd_edge_dst_generic(ampconv_view_t Q, ampconv_view_t K, ampconv_vie
   if (n_rows * H > INT32_MAX) return AMPCONV_E_BADARG;
   BwdArgs a{};
   a.Q = Q; a.K = K; a.V = V; a.dO = dO; a.dQ = dQ;
-  a.ptr = rowptr; a.idx = col; a.rowptr = rowptr;
+  a.ptr = rowptr; a.idx = col; a.cinv = nullptr;
   a.L = L; a.dh = D / H; a.dhp = pad_odd(a.dh); a.H = H;
   a.scale = 1.f / sqrtf((float)a.dh);
   size_t lds = ((size_t)5 * L * a.dhp + 2 * L) * sizeof(float);
@@ -282,14 +281,14 @@ int ampconv_bwd_edge_dst_generic(ampconv_view_t Q, ampconv_view_t K, ampconv_vie
 
 int ampconv_bwd_edge_src_generic(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
                                  ampconv_view_t dO, const int32_t *cscptr, const int32_t *crow,
-                                 const int32_t *rowptr, int64_t n_src, int L, int D, int H,
+                                 const float *cinv, int64_t n_src, int L, int D, int H,
                                  ampconv_view_t dK, ampconv_view_t dV, hipStream_t stream) {
   if (int rc = check_shape(L, D, H)) return rc;
   if (n_src == 0) return AMPCONV_OK;
   if (n_src * H > INT32_MAX) return AMPCONV_E_BADARG;
   BwdArgs a{};
   a.Q = Q; a.K = K; a.V = V; a.dO = dO; a.dK = dK; a.dV = dV;
-  a.ptr = cscptr; a.idx = crow; a.rowptr = rowptr;
+  a.ptr = cscptr; a.idx = crow; a.cinv = cinv;
   a.L = L; a.dh = D / H; a.dhp = pad_odd(a.dh); a.H = H;
   a.scale = 1.f / sqrtf((float)a.dh);
   size_t lds = ((size_t)6 * L * a.dhp + 2 * L) * sizeof(float);

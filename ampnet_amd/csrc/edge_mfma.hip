@@ -18,7 +18,25 @@
 namespace {
 
 constexpr float kLog2e = 1.4426950408889634f;
-constexpr int kWavesPerBlock = 4;
+#ifndef AMPCONV_WPB
+#define AMPCONV_WPB 4
+#endif
+constexpr int kWavesPerBlock = AMPCONV_WPB;
+// prefetch depth (edges in flight per wave) of the three kernels' register rings
+#ifndef AMPCONV_PF_FWD
+#define AMPCONV_PF_FWD 1
+#endif
+#ifndef AMPCONV_PF_DST
+#define AMPCONV_PF_DST 1
+#endif
+#ifndef AMPCONV_PF_SRC
+#define AMPCONV_PF_SRC 1
+#endif
+#ifdef AMPCONV_SETPRIO
+#define PRIO(x) __builtin_amdgcn_s_setprio(x)
+#else
+#define PRIO(x)
+#endif
 
 struct FwdArgs {
   ampconv_view_t Q, K, V, O;
@@ -51,7 +69,7 @@ __device__ __forceinline__ void column_softmax(f32x4 &t0, f32x4 &t1, int L, int 
   t1[0] *= inv;
 }
 
-template <int DH, bool FULL>
+template <int DH, bool FULL, int PF>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void fwd_mfma(FwdArgs a) {
   using C = TileCfg<DH>;
   __shared__ __attribute__((aligned(16))) float lds_all[kWavesPerBlock][2][C::TILE_FLOATS];
@@ -83,22 +101,25 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void fwd_mfma(FwdArgs a) {
 #pragma unroll
   for (int mc = 0; mc < C::MC; ++mc) OT[mc][0] = OT[mc][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  PairRegs<DH> kv;
-  if (beg < end) {
-    const int64_t s = a.col[beg];
-    pair_load<DH, FULL>(kv, tile_ptr<const float>(a.K, s, h), a.K.row_stride,
+  // register ring: the tiles of the next PF edges are in flight while one edge computes
+  PairRegs<DH> ring[PF];
+  IdxWindow win;
+  if (beg < end) idxwin_load<false>(win, a.col, nullptr, beg, end, lane);
+  auto fetch = [&](PairRegs<DH> &buf, int p) {
+    const int64_t s = idxwin_get<false>(win, a.col, nullptr, p, end, lane, nullptr);
+    pair_load<DH, FULL>(buf, tile_ptr<const float>(a.K, s, h), a.K.row_stride,
                         tile_ptr<const float>(a.V, s, h), a.V.row_stride, L, lane);
-  }
-  for (int p = beg; p < end; ++p) {
+  };
+#pragma unroll
+  for (int k = 0; k < PF; ++k)
+    if (beg + k < end) fetch(ring[k], beg + k);
+  auto step = [&](PairRegs<DH> &kv, int p) {
     pair_to_lds<DH, FULL>(Kt, kv, 1.f, 1.f, L, lane);
-    if (p + 1 < end) {                         // next edge's tiles fly while this one computes
-      const int64_t s = a.col[p + 1];
-      pair_load<DH, FULL>(kv, tile_ptr<const float>(a.K, s, h), a.K.row_stride,
-                          tile_ptr<const float>(a.V, s, h), a.V.row_stride, L, lane);
-    }
+    if (p + PF < end) fetch(kv, p + PF);
     __builtin_amdgcn_wave_barrier();
 
     // S^T tiles [source-token tile mt][destination-token tile nt]
+    PRIO(1);
     f32x4 S[2][2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
@@ -111,8 +132,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void fwd_mfma(FwdArgs a) {
         S[mt][1] = MFMA16(kA[kk], qB[1][kk], S[mt][1]);
       }
     }
+    PRIO(0);
     column_softmax<FULL>(S[0][0], S[1][0], L, g);
     column_softmax<FULL>(S[0][1], S[1][1], L, g);
+    PRIO(1);
 
     // O^T[channel tile mc][destination-token tile nt] += V^T P^T
 #pragma unroll
@@ -126,7 +149,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void fwd_mfma(FwdArgs a) {
         OT[mc][nt] = MFMA16(vA[4], S[1][nt][0], OT[mc][nt]);
       }
     }
+    PRIO(0);
     __builtin_amdgcn_wave_barrier();
+  };
+  for (int p0 = beg; p0 < end; p0 += PF) {
+#pragma unroll
+    for (int k = 0; k < PF; ++k)
+      if (p0 + k < end) step(ring[k], p0 + k);
   }
 
   // O^T C/D layout: lane (i' = lane & 15, g), reg q -> channel 4g + q + 16 mc, token i' + 16 nt
@@ -146,11 +175,28 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void fwd_mfma(FwdArgs a) {
   }
 }
 
+#ifdef AMPCONV_STAMPS
+// diagnostic build: per-phase s_memtime sums of bwd_src_mfma, written to a device buffer that
+// nothing else reads (tools/stamp_bwd_src.py); never part of the product build
+__device__ unsigned long long g_stamp_sums[8 * 4096];
+#define STAMP_DECL unsigned long long st_last, st_now, st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; \
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
+#define STAMP(i) do { __builtin_amdgcn_sched_barrier(0); \
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_now)::"memory"); \
+  __builtin_amdgcn_sched_barrier(0); st_acc[i] += st_now - st_last; st_last = st_now; } while (0)
+#define STAMP_FLUSH(unit) do { if ((unit) < 4096 && lane == 0) for (int i_ = 0; i_ < 8; ++i_) \
+  g_stamp_sums[(unit) * 8 + i_] = st_acc[i_]; } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_FLUSH(unit)
+#endif
+
 struct BwdArgs {
   ampconv_view_t Q, K, V, dO, dQ, dK, dV;
   const int32_t *ptr;      // rowptr (dst pass) / cscptr (src pass)
   const int32_t *idx;      // col (dst pass) / crow (src pass)
-  const int32_t *rowptr;   // dst CSR pointers (1/deg of a destination)
+  const float *cinv;       // src pass: 1/in-degree of the destination of each CSC edge
   int64_t n_units;
   int L, H;
   float qscale;            // log2(e) / sqrt(dh)
@@ -160,8 +206,15 @@ struct BwdArgs {
 // ---- backward, destination pass: dQ[r], one wave per (destination, head).
 //   S^T = K Q^T, P^T = softmax;  dP^T = V dO^T;  delta = colsum(P^T o dP^T);
 //   dS^T = P^T o (dP^T - delta);  dQ^T += K^T dS^T   (dS^T C/D registers = B operand)
-template <int DH, bool FULL>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void bwd_dst_mfma(BwdArgs a) {
+#ifdef AMPCONV_OCC
+#define LB_DST __launch_bounds__(64 * kWavesPerBlock, 4)
+#define LB_SRC __launch_bounds__(64 * kWavesPerBlock, 3)
+#else
+#define LB_DST __launch_bounds__(64 * kWavesPerBlock)
+#define LB_SRC __launch_bounds__(64 * kWavesPerBlock)
+#endif
+template <int DH, bool FULL, int PF>
+__global__ LB_DST void bwd_dst_mfma(BwdArgs a) {
   using C = TileCfg<DH>;
   __shared__ __attribute__((aligned(16))) float lds_all[kWavesPerBlock][2][C::TILE_FLOATS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -192,59 +245,72 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void bwd_dst_mfma(BwdArgs a) {
 #pragma unroll
   for (int mc = 0; mc < C::MC; ++mc) dQT[mc][0] = dQT[mc][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  PairRegs<DH> kv;
-  if (beg < end) {
-    const int64_t s = a.idx[beg];
-    pair_load<DH, FULL>(kv, tile_ptr<const float>(a.K, s, h), a.K.row_stride,
+  PairRegs<DH> ring[PF];
+  IdxWindow win;
+  if (beg < end) idxwin_load<false>(win, a.idx, nullptr, beg, end, lane);
+  auto fetch = [&](PairRegs<DH> &buf, int p) {
+    const int64_t s = idxwin_get<false>(win, a.idx, nullptr, p, end, lane, nullptr);
+    pair_load<DH, FULL>(buf, tile_ptr<const float>(a.K, s, h), a.K.row_stride,
                         tile_ptr<const float>(a.V, s, h), a.V.row_stride, L, lane);
-  }
-  for (int p = beg; p < end; ++p) {
+  };
+#pragma unroll
+  for (int k = 0; k < PF; ++k)
+    if (beg + k < end) fetch(ring[k], beg + k);
+  auto step = [&](PairRegs<DH> &kv, int p) {
     pair_to_lds<DH, FULL>(Kt, kv, 1.f, 1.f, L, lane);
-    if (p + 1 < end) {
-      const int64_t s = a.idx[p + 1];
-      pair_load<DH, FULL>(kv, tile_ptr<const float>(a.K, s, h), a.K.row_stride,
-                          tile_ptr<const float>(a.V, s, h), a.V.row_stride, L, lane);
-    }
+    if (p + PF < end) fetch(kv, p + PF);
     __builtin_amdgcn_wave_barrier();
 
-    f32x4 S[2][2], dP[2][2];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      float kA[C::KK], vA[C::KK];
-      rowop_from_lds<DH>(kA, Kt, mt, lane);
-      rowop_from_lds<DH>(vA, Vt, mt, lane);
-      S[mt][0] = S[mt][1] = dP[mt][0] = dP[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int kk = 0; kk < C::KK; ++kk) {
-        S[mt][0] = MFMA16(kA[kk], qB[0][kk], S[mt][0]);
-        S[mt][1] = MFMA16(kA[kk], qB[1][kk], S[mt][1]);
-        dP[mt][0] = MFMA16(vA[kk], dOB[0][kk], dP[mt][0]);
-        dP[mt][1] = MFMA16(vA[kk], dOB[1][kk], dP[mt][1]);
-      }
-    }
+    // the destination-token columns of the two column tiles are independent (the softmax runs
+    // along the source tokens = MFMA rows), so the tiles are processed one after the other
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
-      column_softmax<FULL>(S[0][nt], S[1][nt], L, g);
-      float part = S[1][nt][0] * dP[1][nt][0];
+      PRIO(1);
+      f32x4 S0, S1, dP0, dP1;                    // row tiles 0 / 1 of this column tile
+      S0 = S1 = dP0 = dP1 = f32x4{0.f, 0.f, 0.f, 0.f};
+      {
+        float kA[C::KK], vA[C::KK];
+        rowop_from_lds<DH>(kA, Kt, 0, lane);
+        rowop_from_lds<DH>(vA, Vt, 0, lane);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) part = fmaf(S[0][nt][q], dP[0][nt][q], part);
+        for (int kk = 0; kk < C::KK; ++kk) {
+          S0 = MFMA16(kA[kk], qB[nt][kk], S0);
+          dP0 = MFMA16(vA[kk], dOB[nt][kk], dP0);
+        }
+        rowop_from_lds<DH>(kA, Kt, 1, lane);
+        rowop_from_lds<DH>(vA, Vt, 1, lane);
+#pragma unroll
+        for (int kk = 0; kk < C::KK; ++kk) {
+          S1 = MFMA16(kA[kk], qB[nt][kk], S1);
+          dP1 = MFMA16(vA[kk], dOB[nt][kk], dP1);
+        }
+      }
+      PRIO(0);
+      column_softmax<FULL>(S0, S1, L, g);
+      float part = S1[0] * dP1[0];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) part = fmaf(S0[q], dP0[q], part);
       const float delta = groups_sum(part);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) S[0][nt][q] *= dP[0][nt][q] - delta;     // S now holds dS^T
-      S[1][nt][0] *= dP[1][nt][0] - delta;
-    }
+      for (int q = 0; q < 4; ++q) S0[q] *= dP0[q] - delta;     // S now holds dS^T
+      S1[0] *= dP1[0] - delta;
+      PRIO(1);
 #pragma unroll
-    for (int mc = 0; mc < C::MC; ++mc) {
-      float kC[5];
-      colop_from_lds<DH>(kC, Kt, mc, lane);
+      for (int mc = 0; mc < C::MC; ++mc) {
+        float kC[5];
+        colop_from_lds<DH>(kC, Kt, mc, lane);
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-#pragma unroll
-        for (int s = 0; s < 4; ++s) dQT[mc][nt] = MFMA16(kC[s], S[0][nt][s], dQT[mc][nt]);
-        dQT[mc][nt] = MFMA16(kC[4], S[1][nt][0], dQT[mc][nt]);
+        for (int t = 0; t < 4; ++t) dQT[mc][nt] = MFMA16(kC[t], S0[t], dQT[mc][nt]);
+        dQT[mc][nt] = MFMA16(kC[4], S1[0], dQT[mc][nt]);
       }
     }
+    PRIO(0);
     __builtin_amdgcn_wave_barrier();
+  };
+  for (int p0 = beg; p0 < end; p0 += PF) {
+#pragma unroll
+    for (int k = 0; k < PF; ++k)
+      if (p0 + k < end) step(ring[k], p0 + k);
   }
 
   float *ob = tile_ptr<float>(a.dQ, r, h);
@@ -266,8 +332,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void bwd_dst_mfma(BwdArgs a) {
 //   S = Q K^T (destination tokens on MFMA rows, source tokens on columns), P = row softmax
 //   (16-lane DPP reductions), dP = dO V^T, dS = P o (dP - delta);
 //   dV^T += dO^T P,  dK^T += Q^T dS      (P / dS C/D registers = B operands)
-template <int DH, bool FULL>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void bwd_src_mfma(BwdArgs a) {
+template <int DH, bool FULL, int PF>
+__global__ LB_SRC void bwd_src_mfma(BwdArgs a) {
   using C = TileCfg<DH>;
   __shared__ __attribute__((aligned(16))) float lds_all[kWavesPerBlock][2][C::TILE_FLOATS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -298,77 +364,93 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void bwd_src_mfma(BwdArgs a) {
   for (int mc = 0; mc < C::MC; ++mc)
     dKT[mc][0] = dKT[mc][1] = dVT[mc][0] = dVT[mc][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  PairRegs<DH> qg;
-  float inv = 0.f;
-  if (beg < end) {
-    const int64_t d = a.idx[beg];
-    inv = 1.f / (float)(a.rowptr[d + 1] - a.rowptr[d]);
-    pair_load<DH, FULL>(qg, tile_ptr<const float>(a.Q, d, h), a.Q.row_stride,
+  STAMP_DECL
+  PairRegs<DH> ring[PF];
+  float ring_inv[PF];
+  IdxWindow win;
+  if (beg < end) idxwin_load<true>(win, a.idx, a.cinv, beg, end, lane);
+  auto fetch = [&](PairRegs<DH> &buf, float &inv, int p) {
+    const int64_t d = idxwin_get<true>(win, a.idx, a.cinv, p, end, lane, &inv);
+    pair_load<DH, FULL>(buf, tile_ptr<const float>(a.Q, d, h), a.Q.row_stride,
                         tile_ptr<const float>(a.dO, d, h), a.dO.row_stride, L, lane);
-  }
-  for (int p = beg; p < end; ++p) {
+  };
+#pragma unroll
+  for (int k = 0; k < PF; ++k)
+    if (beg + k < end) fetch(ring[k], ring_inv[k], beg + k);
+  auto step = [&](PairRegs<DH> &qg, float &inv, int p) {
+    STAMP(0);
     pair_to_lds<DH, FULL>(Qt, qg, a.qscale, inv, L, lane);
-    if (p + 1 < end) {
-      const int64_t d = a.idx[p + 1];
-      inv = 1.f / (float)(a.rowptr[d + 1] - a.rowptr[d]);
-      pair_load<DH, FULL>(qg, tile_ptr<const float>(a.Q, d, h), a.Q.row_stride,
-                          tile_ptr<const float>(a.dO, d, h), a.dO.row_stride, L, lane);
-    }
+    STAMP(1);
+    if (p + PF < end) fetch(qg, inv, p + PF);
+    STAMP(2);
     __builtin_amdgcn_wave_barrier();
 
-    f32x4 S[2][2], dP[2][2];
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      float qA[C::KK], gA[C::KK];
-      rowop_from_lds<DH>(qA, Qt, mt, lane);
-      rowop_from_lds<DH>(gA, Gt, mt, lane);
-      S[mt][0] = S[mt][1] = dP[mt][0] = dP[mt][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int kk = 0; kk < C::KK; ++kk) {
-        S[mt][0] = MFMA16(qA[kk], kB[0][kk], S[mt][0]);
-        S[mt][1] = MFMA16(qA[kk], kB[1][kk], S[mt][1]);
-        dP[mt][0] = MFMA16(gA[kk], vB[0][kk], dP[mt][0]);
-        dP[mt][1] = MFMA16(gA[kk], vB[1][kk], dP[mt][1]);
-      }
-    }
-    // row softmax over the source tokens: columns n (+16 for tile 1) across the 16 lanes
+    PRIO(1);
+    // the destination-token rows of the two row tiles are independent (the softmax runs along
+    // the source tokens = lanes), so the tiles are processed one after the other: half the live
+    // score registers
     const bool v0 = n < L, v1 = 16 + n < L;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
+      f32x4 S0, S1, dP0, dP1;
+      S0 = S1 = dP0 = dP1 = f32x4{0.f, 0.f, 0.f, 0.f};
+      {
+        float qA[C::KK], gA[C::KK];
+        rowop_from_lds<DH>(qA, Qt, mt, lane);
+        rowop_from_lds<DH>(gA, Gt, mt, lane);
+#pragma unroll
+        for (int kk = 0; kk < C::KK; ++kk) {
+          S0 = MFMA16(qA[kk], kB[0][kk], S0);
+          S1 = MFMA16(qA[kk], kB[1][kk], S1);
+          dP0 = MFMA16(gA[kk], vB[0][kk], dP0);
+          dP1 = MFMA16(gA[kk], vB[1][kk], dP1);
+        }
+      }
+      STAMP(3);
+      PRIO(0);
+      // row softmax over the source tokens: columns n (+16 for tile 1) across the 16 lanes
 #pragma unroll
       for (int q = 0; q < (mt == 0 ? 4 : 1); ++q) {
-        const float s0 = v0 ? S[mt][0][q] : kNegBig, s1 = v1 ? S[mt][1][q] : kNegBig;
+        const float s0 = v0 ? S0[q] : kNegBig, s1 = v1 ? S1[q] : kNegBig;
         const float m = row16_max(fmaxf(s0, s1));
         float p0 = fast_exp2(s0 - m), p1 = fast_exp2(s1 - m);
         const float rinv = fast_rcp(row16_sum(p0 + p1));
         p0 *= rinv;
         p1 *= rinv;
-        const float delta = row16_sum(fmaf(p0, dP[mt][0][q], p1 * dP[mt][1][q]));
-        S[mt][0][q] = p0;
-        S[mt][1][q] = p1;
-        dP[mt][0][q] = p0 * (dP[mt][0][q] - delta);       // dP now holds dS
-        dP[mt][1][q] = p1 * (dP[mt][1][q] - delta);
+        const float delta = row16_sum(fmaf(p0, dP0[q], p1 * dP1[q]));
+        S0[q] = p0;
+        S1[q] = p1;
+        dP0[q] = p0 * (dP0[q] - delta);       // dP now holds dS
+        dP1[q] = p1 * (dP1[q] - delta);
       }
-    }
+      STAMP(4);
+      PRIO(1);
+      const int ks = lane >> 4;
 #pragma unroll
-    for (int mc = 0; mc < C::MC; ++mc) {
-      float gC[5], qC[5];
-      colop_from_lds<DH>(gC, Gt, mc, lane);
-      colop_from_lds<DH>(qC, Qt, mc, lane);
+      for (int t = (mt == 0 ? 0 : 4); t < (mt == 0 ? 4 : 5); ++t) {
+        const int q = mt == 0 ? t : 0;
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          dVT[mc][nt] = MFMA16(gC[t], S[0][nt][t], dVT[mc][nt]);
-          dKT[mc][nt] = MFMA16(qC[t], dP[0][nt][t], dKT[mc][nt]);
+        for (int mc = 0; mc < C::MC; ++mc) {
+          const int idx = lds_idx<DH>(col_token(t, ks), (lane & 15) + 16 * mc);
+          const float gC = Gt[idx], qC = Qt[idx];
+          dVT[mc][0] = MFMA16(gC, S0[q], dVT[mc][0]);
+          dVT[mc][1] = MFMA16(gC, S1[q], dVT[mc][1]);
+          dKT[mc][0] = MFMA16(qC, dP0[q], dKT[mc][0]);
+          dKT[mc][1] = MFMA16(qC, dP1[q], dKT[mc][1]);
         }
-        dVT[mc][nt] = MFMA16(gC[4], S[1][nt][0], dVT[mc][nt]);
-        dKT[mc][nt] = MFMA16(qC[4], dP[1][nt][0], dKT[mc][nt]);
       }
     }
+    STAMP(5);
+    PRIO(0);
     __builtin_amdgcn_wave_barrier();
+  };
+  for (int p0 = beg; p0 < end; p0 += PF) {
+#pragma unroll
+    for (int k = 0; k < PF; ++k)
+      if (p0 + k < end) step(ring[k], ring_inv[k], p0 + k);
   }
 
+  STAMP_FLUSH(unit);
   const int g = lane >> 4;
   float *kb = tile_ptr<float>(a.dK, s, h), *vb = tile_ptr<float>(a.dV, s, h);
 #pragma unroll
@@ -414,10 +496,10 @@ int ampconv_fwd_edge_mfma(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
   const int64_t blocks = (a.n_units + kWavesPerBlock - 1) / kWavesPerBlock;
   if (blocks > INT32_MAX) return AMPCONV_E_BADARG;
   const dim3 grid((unsigned)blocks), block(64 * kWavesPerBlock);
-  if (dh == 32 && L == kLmax) fwd_mfma<32, true><<<grid, block, 0, stream>>>(a);
-  else if (dh == 32) fwd_mfma<32, false><<<grid, block, 0, stream>>>(a);
-  else if (L == kLmax) fwd_mfma<16, true><<<grid, block, 0, stream>>>(a);
-  else fwd_mfma<16, false><<<grid, block, 0, stream>>>(a);
+  if (dh == 32 && L == kLmax) fwd_mfma<32, true, AMPCONV_PF_FWD><<<grid, block, 0, stream>>>(a);
+  else if (dh == 32) fwd_mfma<32, false, 1><<<grid, block, 0, stream>>>(a);
+  else if (L == kLmax) fwd_mfma<16, true, AMPCONV_PF_FWD><<<grid, block, 0, stream>>>(a);
+  else fwd_mfma<16, false, 1><<<grid, block, 0, stream>>>(a);
   return ampconv_launch_status();
 }
 
@@ -428,37 +510,43 @@ int ampconv_bwd_edge_dst_mfma(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t
   const int dh = D / H;
   BwdArgs a{};
   a.Q = Q; a.K = K; a.V = V; a.dO = dO; a.dQ = dQ;
-  a.ptr = rowptr; a.idx = col; a.rowptr = rowptr;
+  a.ptr = rowptr; a.idx = col; a.cinv = nullptr;
   a.n_units = n_rows * H; a.L = L; a.H = H;
   a.qscale = kLog2e / sqrtf((float)dh);
   a.oscale = 1.f / sqrtf((float)dh);
   const int64_t blocks = (a.n_units + kWavesPerBlock - 1) / kWavesPerBlock;
   if (blocks > INT32_MAX) return AMPCONV_E_BADARG;
   const dim3 grid((unsigned)blocks), block(64 * kWavesPerBlock);
-  if (dh == 32 && L == kLmax) bwd_dst_mfma<32, true><<<grid, block, 0, stream>>>(a);
-  else if (dh == 32) bwd_dst_mfma<32, false><<<grid, block, 0, stream>>>(a);
-  else if (L == kLmax) bwd_dst_mfma<16, true><<<grid, block, 0, stream>>>(a);
-  else bwd_dst_mfma<16, false><<<grid, block, 0, stream>>>(a);
+  if (dh == 32 && L == kLmax) bwd_dst_mfma<32, true, AMPCONV_PF_DST><<<grid, block, 0, stream>>>(a);
+  else if (dh == 32) bwd_dst_mfma<32, false, 1><<<grid, block, 0, stream>>>(a);
+  else if (L == kLmax) bwd_dst_mfma<16, true, AMPCONV_PF_DST><<<grid, block, 0, stream>>>(a);
+  else bwd_dst_mfma<16, false, 1><<<grid, block, 0, stream>>>(a);
   return ampconv_launch_status();
 }
 
 int ampconv_bwd_edge_src_mfma(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
                               ampconv_view_t dO, const int32_t *cscptr, const int32_t *crow,
-                              const int32_t *rowptr, int64_t n_src, int L, int D, int H,
+                              const float *cinv, int64_t n_src, int L, int D, int H,
                               ampconv_view_t dK, ampconv_view_t dV, hipStream_t stream) {
   const int dh = D / H;
   BwdArgs a{};
   a.Q = Q; a.K = K; a.V = V; a.dO = dO; a.dK = dK; a.dV = dV;
-  a.ptr = cscptr; a.idx = crow; a.rowptr = rowptr;
+  a.ptr = cscptr; a.idx = crow; a.cinv = cinv;
   a.n_units = n_src * H; a.L = L; a.H = H;
   a.qscale = kLog2e / sqrtf((float)dh);
   a.oscale = 0.6931471805599453f;     // dK = ln2 * sum dS^T (Q * log2e / sqrt(dh))
   const int64_t blocks = (a.n_units + kWavesPerBlock - 1) / kWavesPerBlock;
   if (blocks > INT32_MAX) return AMPCONV_E_BADARG;
   const dim3 grid((unsigned)blocks), block(64 * kWavesPerBlock);
-  if (dh == 32 && L == kLmax) bwd_src_mfma<32, true><<<grid, block, 0, stream>>>(a);
-  else if (dh == 32) bwd_src_mfma<32, false><<<grid, block, 0, stream>>>(a);
-  else if (L == kLmax) bwd_src_mfma<16, true><<<grid, block, 0, stream>>>(a);
-  else bwd_src_mfma<16, false><<<grid, block, 0, stream>>>(a);
+  if (dh == 32 && L == kLmax) bwd_src_mfma<32, true, AMPCONV_PF_SRC><<<grid, block, 0, stream>>>(a);
+  else if (dh == 32) bwd_src_mfma<32, false, 1><<<grid, block, 0, stream>>>(a);
+  else if (L == kLmax) bwd_src_mfma<16, true, AMPCONV_PF_SRC><<<grid, block, 0, stream>>>(a);
+  else bwd_src_mfma<16, false, 1><<<grid, block, 0, stream>>>(a);
   return ampconv_launch_status();
 }
+
+#ifdef AMPCONV_STAMPS
+extern "C" int ampconv_debug_read_stamps(unsigned long long *host_out, int n) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamp_sums), sizeof(unsigned long long) * n);
+}
+#endif

@@ -37,6 +37,15 @@ __global__ void gather_other(const int32_t *__restrict__ perm, const int64_t *__
   other[p] = (int32_t)v;
 }
 
+// cinv[p] = 1 / in-degree of the destination of CSC edge p
+__global__ void edge_inv_degree(const int32_t *__restrict__ crow, const int32_t *__restrict__ rowptr,
+                                int64_t E, float *__restrict__ cinv) {
+  int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= E) return;
+  const int d = crow[p];
+  cinv[p] = 1.f / (float)(rowptr[d + 1] - rowptr[d]);
+}
+
 // ptr[n] = first sorted position whose key is >= n (lower bound); ptr[N] = E
 __global__ void fill_ptr(const int32_t *__restrict__ sorted_keys, int64_t E, int64_t N,
                          int32_t *__restrict__ ptr) {
@@ -74,7 +83,7 @@ extern "C" size_t ampconv_csr_workspace_bytes(int64_t N, int64_t E) {
 
 extern "C" int ampconv_csr_build(const int64_t *edge_index, int64_t E, int64_t N, int32_t *rowptr,
                                  int32_t *col, int32_t *eperm, int32_t *cscptr, int32_t *crow,
-                                 int32_t *cperm, int32_t *oob, void *workspace,
+                                 int32_t *cperm, float *cinv, int32_t *oob, void *workspace,
                                  size_t workspace_bytes, void *stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (N <= 0 || E < 0 || N > INT32_MAX || E >= INT32_MAX) return AMPCONV_E_BADARG;
@@ -123,5 +132,6 @@ extern "C" int ampconv_csr_build(const int64_t *edge_index, int64_t E, int64_t N
   if (err != hipSuccess) return (int)err;
   gather_other<<<grid, T, 0, stream>>>(cperm, dst, E, N, crow);
   fill_ptr<<<gridn, T, 0, stream>>>(keys_out, E, N, cscptr);
+  if (cinv) edge_inv_degree<<<grid, T, 0, stream>>>(crow, rowptr, E, cinv);
   return ampconv_launch_status();
 }

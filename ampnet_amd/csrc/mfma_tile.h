@@ -110,8 +110,10 @@ __device__ __forceinline__ void pair_load(PairRegs<DH> &t, const float *baseA, i
     const bool isB = R >= kLmax;
     const int j = isB ? R - kLmax : R;
     const bool valid = (R < 2 * kLmax) && (FULL || j < L);
-    const float *p = isB ? baseB + (int64_t)j * strideB : baseA + (int64_t)j * strideA;
-    if (valid) t.v[i] = *reinterpret_cast<const float4 *>(p + 4 * q);
+    // per-lane part as a 32-bit element offset (loop invariant), tile base uniform per edge
+    const unsigned off = (unsigned)j * (unsigned)(isB ? strideB : strideA) + 4u * (unsigned)q;
+    const float *p = (isB ? baseB : baseA) + off;
+    if (valid) t.v[i] = *reinterpret_cast<const float4 *>(p);
   }
 }
 
@@ -134,6 +136,31 @@ __device__ __forceinline__ void pair_to_lds(float *ldsA, const PairRegs<DH> &t, 
       *reinterpret_cast<float4 *>(ldsA + (isB ? C::TILE_FLOATS : 0) + j * DH + ((q ^ swz<DH>(j)) << 2)) = x;
     }
   }
+}
+
+// ---- neighbour indices of a segment, 64 at a time: one coalesced vector load per window and a
+// v_readlane per edge instead of a dependent scalar memory load per edge (a scalar-cache miss
+// on col[p] stalls the whole wave for ~2-3 k cycles before its tile loads can even be issued)
+struct IdxWindow {
+  int c0;     // first CSR/CSC position held by the window
+  int idx;    // lane l holds idx[c0 + l]
+  float w;    // lane l holds weight[c0 + l] (source pass: 1/in-degree of the edge's destination)
+};
+template <bool WEIGHTS>
+__device__ __forceinline__ void idxwin_load(IdxWindow &win, const int32_t *idx, const float *wts, int c0,
+                                            int end, int lane) {
+  win.c0 = c0;
+  const int q = c0 + lane < end ? c0 + lane : end - 1;
+  win.idx = idx[q];
+  if (WEIGHTS) win.w = wts[q];
+}
+template <bool WEIGHTS>
+__device__ __forceinline__ int idxwin_get(IdxWindow &win, const int32_t *idx, const float *wts, int p,
+                                          int end, int lane, float *w) {
+  if (p - win.c0 >= AMPCONV_WAVE) idxwin_load<WEIGHTS>(win, idx, wts, p, end, lane);   // wave-uniform
+  const int k = p - win.c0;
+  if (WEIGHTS) *w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, win.w), k));
+  return __builtin_amdgcn_readlane(win.idx, k);
 }
 
 // token held by MFMA row m of row-tile mt (quarter map for tile 1; always a valid row < 20)

@@ -17,7 +17,8 @@ def _stream():
 
 
 class EdgeCSR:
-    """dst-sorted CSR (rowptr, col, eperm) + src-sorted CSC (cscptr, crow, cperm), int32."""
+    """dst-sorted CSR (rowptr, col, eperm) + src-sorted CSC (cscptr, crow, cperm), int32,
+    and cinv[p] = 1 / in-degree(crow[p]) (fp32)."""
 
     def __init__(self, edge_index, num_nodes, validate=True):
         if edge_index.dim() != 2 or edge_index.size(0) != 2:
@@ -38,13 +39,15 @@ class EdgeCSR:
         self.eperm = torch.empty(max(E, 1), **i32)
         self.crow = torch.empty(max(E, 1), **i32)
         self.cperm = torch.empty(max(E, 1), **i32)
+        self.cinv = torch.empty(max(E, 1), dtype=torch.float32, device=dev)
         oob = torch.zeros(1, **i32)
         with torch.cuda.device(dev):
             ws_bytes = lib.ampconv_csr_workspace_bytes(N, E) if E > 0 else 0
             ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
             rc = lib.ampconv_csr_build(ei.data_ptr(), E, N, self.rowptr.data_ptr(), self.col.data_ptr(),
                                        self.eperm.data_ptr(), self.cscptr.data_ptr(), self.crow.data_ptr(),
-                                       self.cperm.data_ptr(), oob.data_ptr(), ws.data_ptr(), ws_bytes,
+                                       self.cperm.data_ptr(), self.cinv.data_ptr(), oob.data_ptr(), ws.data_ptr(),
+                                       ws_bytes,
                                        _stream())
         _lib.check(rc, 'ampconv_csr_build')
         if validate and E > 0 and int(oob.item()) != 0:
@@ -58,6 +61,7 @@ class EdgeCSR:
         self.num_nodes, self.num_edges, self.device = n, n, device
         self.rowptr = self.cscptr = ar
         self.col = self.crow = self.eperm = self.cperm = ar[:max(n, 1)]
+        self.cinv = torch.ones(max(n, 1), dtype=torch.float32, device=device)
         return self
 
 

@@ -40,7 +40,17 @@ enum {
   AMPCONV_E_WORKSPACE = -3 /* workspace too small */
 };
 
-enum { AMPCONV_F32 = 0, AMPCONV_BF16 = 1 };
+/* dtype codes.  All AMPCONV_F32* codes take and return fp32 tensors; they differ in how the
+ * per-edge products are evaluated on the matrix cores:
+ *   AMPCONV_F32_EXACT   v_mfma_f32_16x16x4_f32 (native fp32 MFMA, 1/16 of the bf16 rate)
+ *   AMPCONV_F32_BF16X9  every fp32 operand split EXACTLY into 3 bf16 terms, all 9 partial
+ *                       products on v_mfma_f32_16x16x32_bf16, fp32 accumulate: no operand
+ *                       rounding at all (error = fp32 accumulation only)
+ *   AMPCONV_F32_BF16X6  as X9 without the three partial products of order <= 2^-24
+ *   AMPCONV_F32         library default: AMPCONV_F32_MODE=exact|bf16x9|bf16x6 in the
+ *                       environment, else bf16x9 where the shape supports it (dh = 32), else exact */
+enum { AMPCONV_F32 = 0, AMPCONV_BF16 = 1, AMPCONV_F32_EXACT = 2, AMPCONV_F32_BF16X9 = 3,
+       AMPCONV_F32_BF16X6 = 4 };
 
 /*
  * Strided view of a per-node token matrix: element (node n, token l, head h,
@@ -65,13 +75,15 @@ const char *ampconv_error_string(int code);
  * every later floating-point sum has a fixed order:
  *   dst-sorted CSR: rowptr[N+1], col[E] (source of each sorted edge),
  *                   eperm[E] (original edge id at each sorted position)
- *   src-sorted CSC: cscptr[N+1], crow[E] (destination), cperm[E]
+ *   src-sorted CSC: cscptr[N+1], crow[E] (destination), cperm[E],
+ *                   cinv[E] = 1 / in-degree(crow[p]) (the weight of edge p in its
+ *                   destination's mean, read sequentially by the source pass)
  * `oob` (device int32) is set non-zero if any index is outside [0, N); such
  * indices are clamped so that no kernel faults.  */
 size_t ampconv_csr_workspace_bytes(int64_t N, int64_t E);
 int ampconv_csr_build(const int64_t *edge_index, int64_t E, int64_t N,
                       int32_t *rowptr, int32_t *col, int32_t *eperm,
-                      int32_t *cscptr, int32_t *crow, int32_t *cperm,
+                      int32_t *cscptr, int32_t *crow, int32_t *cperm, float *cinv,
                       int32_t *oob, void *workspace, size_t workspace_bytes,
                       void *stream);
 
@@ -92,7 +104,7 @@ int ampconv_fwd_edge(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
  * dObar is the gradient w.r.t. the MEAN (the kernels apply 1/deg).
  * _dst: one pass over the dst-sorted CSR, writes dQ[r] for every row.
  * _src: one pass over the src-sorted CSC, writes dK[s], dV[s] for every source;
- *       `rowptr` is the dst-CSR pointer array (for 1/deg of each destination).
+ *       `cinv[p]` = 1/in-degree of the destination of CSC edge p (ampconv_csr_build).
  * No atomics: every output row is owned by one wavefront.  */
 int ampconv_bwd_edge_dst(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
                          ampconv_view_t dObar, const int32_t *rowptr,
@@ -100,7 +112,7 @@ int ampconv_bwd_edge_dst(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
                          ampconv_view_t dQ, int dtype, void *stream);
 int ampconv_bwd_edge_src(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
                          ampconv_view_t dObar, const int32_t *cscptr,
-                         const int32_t *crow, const int32_t *rowptr,
+                         const int32_t *crow, const float *cinv,
                          int64_t n_src, int L, int D, int H, ampconv_view_t dK,
                          ampconv_view_t dV, int dtype, void *stream);
 

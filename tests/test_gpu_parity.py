@@ -26,9 +26,10 @@ def dev():
     return torch.device('cuda:0')
 
 
-def _layer(g, dev, prefix=''):
+def _layer(g, dev, prefix='', mode='default'):
     from ampnet_amd import AMPConv
     layer = AMPConv(int(g['D']), int(g['H'])).to(dev)
+    layer.precision = mode
     sd = {'multi_head_attention.in_proj_weight': torch.from_numpy(g[prefix + 'in_proj_weight']),
           'multi_head_attention.in_proj_bias': torch.from_numpy(g[prefix + 'in_proj_bias']),
           'multi_head_attention.out_proj.weight': torch.from_numpy(g[prefix + 'out_proj_weight']),
@@ -43,8 +44,8 @@ def _grads(layer):
             m.out_proj.weight.grad.cpu().numpy(), m.out_proj.bias.grad.cpu().numpy())
 
 
-def _check_single(g, dev):
-    layer = _layer(g, dev)
+def _check_single(g, dev, mode='default'):
+    layer = _layer(g, dev, mode=mode)
     x = torch.from_numpy(g['x']).to(dev).requires_grad_(True)
     ei = torch.from_numpy(g['edge_index']).to(dev)
     y = layer(x, ei)
@@ -69,9 +70,12 @@ def _check_single(g, dev):
     return layer, x, ei
 
 
+@pytest.mark.parametrize('mode', ['exact', 'bf16x9', 'bf16x6'])
 @pytest.mark.parametrize('path', SINGLE, ids=[os.path.basename(p)[:-4] for p in SINGLE])
-def test_golden_single_layer(path, dev):
-    _check_single(load_golden(path), dev)
+def test_golden_single_layer(path, mode, dev):
+    # every way of running the fp32 products on the matrix cores (include/ampconv.h dtype codes)
+    # must reproduce the reference's outputs at the same fp32 tolerance
+    _check_single(load_golden(path), dev, mode)
 
 
 @pytest.mark.parametrize('path', SINGLE[:4], ids=[os.path.basename(p)[:-4] for p in SINGLE[:4]])
@@ -284,3 +288,41 @@ def test_full_size_config3(dev, monkeypatch):
         assert_close_scaled(a.cpu().numpy(), b.cpu().numpy(), n + ' (mfma vs generic)')
     deg = torch.bincount(ei[1], minlength=N)
     assert (fast[0][deg == 0] == 0).all()
+
+
+def test_split_precision_is_fp32_grade(dev):
+    """The bf16-split MFMA modes against an fp64 oracle: their error must be of the size of
+    the native-fp32-MFMA path's own error (both are fp32 accumulations of exact products for
+    bf16x9), far inside the stated tolerance."""
+    from ampnet_amd import AMPConv
+    from oracle.ampconv_numpy import AMPConvOracle
+    N, E, L, D, H = 1500, 15000, 20, 256, 8
+    torch.manual_seed(31)
+    layer = AMPConv(D, H).to(dev)
+    with torch.no_grad():
+        layer.multi_head_attention.in_proj_bias.normal_(0, 0.1)
+        layer.multi_head_attention.out_proj.bias.normal_(0, 0.1)
+    g = torch.Generator().manual_seed(32)
+    x = torch.randn(N, L * D, generator=g) * 2.0
+    dy = torch.randn(N, L * D, generator=g)
+    ei = torch.randint(0, N, (2, E), generator=g)
+    m = layer.multi_head_attention
+    o = AMPConvOracle(m.in_proj_weight.detach().cpu().numpy(), m.in_proj_bias.detach().cpu().numpy(),
+                      m.out_proj.weight.detach().cpu().numpy(), m.out_proj.bias.detach().cpu().numpy(),
+                      H, dtype=np.float64, edge_chunk=2048)
+    y_ref, _ = o.forward(x.numpy(), ei.numpy(), need_weights=False)
+    dx_ref = o.backward(dy.numpy())[0]
+    err = {}
+    for mode in ('exact', 'bf16x9', 'bf16x6'):
+        layer.precision = mode
+        layer.zero_grad(set_to_none=True)
+        xg = x.to(dev).requires_grad_(True)
+        y = layer(xg, ei.to(dev))
+        y.backward(dy.to(dev))
+        err[mode] = (np.abs(y.detach().cpu().numpy() - y_ref).max() / np.abs(y_ref).max(),
+                     np.abs(xg.grad.cpu().numpy() - dx_ref).max() / np.abs(dx_ref).max())
+    print('max abs error / max |ref| (y, dx):', err)
+    for k in range(2):
+        assert err['bf16x9'][k] <= 2.0 * err['exact'][k] + 1e-7
+        assert err['bf16x6'][k] <= 4.0 * err['exact'][k] + 3e-7
+        assert err['exact'][k] < 2e-5

@@ -33,6 +33,10 @@ def main():
     N, E, L, D, H = (int(x) for x in args) if len(args) == 5 else (100000, 1000000, 20, 256, 8)
     if '--generic' in sys.argv:
         os.environ['AMPCONV_FORCE_GENERIC'] = '1'
+    dt = 0
+    for a in sys.argv:
+        if a.startswith('--mode='):
+            dt = _lib.PRECISIONS[a.split('=')[1]]
     dev = torch.device('cuda:0')
     lib = _lib.load()
     dh = D // H
@@ -43,7 +47,7 @@ def main():
     t0 = time.time()
     csr = EdgeCSR(ei, N)
     torch.cuda.synchronize()
-    print(f'N={N} E={E} L={L} D={D} H={H}  csr build (cold) {1e3 * (time.time() - t0):.1f} ms')
+    print(f'mode={dt} N={N} E={E} L={L} D={D} H={H}  csr build (cold) {1e3 * (time.time() - t0):.1f} ms')
     print(f'csr build {timeit(lambda: EdgeCSR(ei, N, validate=False)):.3f} ms')
     Qv, Kv, Vv = (F_._view(qkv, i * D, L, dh) for i in range(3))
     obar = torch.empty(N * L, D, device=dev)
@@ -55,15 +59,15 @@ def main():
 
     def fwd():
         _lib.check(lib.ampconv_fwd_edge(Qv, Kv, Vv, csr.rowptr.data_ptr(), csr.col.data_ptr(), None,
-                                        N, L, D, H, F_._view(obar, 0, L, dh), 0, st), 'fwd')
+                                        N, L, D, H, F_._view(obar, 0, L, dh), dt, st), 'fwd')
 
     def bwd_dst():
         _lib.check(lib.ampconv_bwd_edge_dst(Qv, Kv, Vv, dOv, csr.rowptr.data_ptr(), csr.col.data_ptr(),
-                                            N, L, D, H, dQv, 0, st), 'bwd_dst')
+                                            N, L, D, H, dQv, dt, st), 'bwd_dst')
 
     def bwd_src():
         _lib.check(lib.ampconv_bwd_edge_src(Qv, Kv, Vv, dOv, csr.cscptr.data_ptr(), csr.crow.data_ptr(),
-                                            csr.rowptr.data_ptr(), N, L, D, H, dKv, dVv, 0, st), 'bwd_src')
+                                            csr.cinv.data_ptr(), N, L, D, H, dKv, dVv, dt, st), 'bwd_src')
 
     for name, fn, nbytes, flops in (
             ('fwd_edge', fwd, (2 * E + 2 * N) * R, 4 * L * L * D * E),
