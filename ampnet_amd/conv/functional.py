@@ -32,6 +32,22 @@ def _ptr(t):
     return t.data_ptr() if t is not None else None
 
 
+def _tn_matmul(a, b, chunks=128):
+    """a^T @ b for tall operands a [M, p], b [M, q] (the weight-gradient GEMMs, reduction over
+    the N*L node-token rows).  rocBLAS runs the single [p, M] x [M, q] product at 65-95 TFLOP/s
+    at M = 2e7; splitting the reduction into `chunks` batched GEMMs + one sum runs at
+    ~150 TFLOP/s (measured on MI355X, tools/bench_dw.py) and sums pairwise, i.e. more accurately."""
+    M = a.size(0)
+    if M < (1 << 18):
+        return a.t().mm(b)
+    per = M // chunks
+    main = per * chunks
+    out = torch.bmm(a[:main].view(chunks, per, -1).transpose(1, 2), b[:main].view(chunks, per, -1)).sum(0)
+    if main < M:
+        out += a[main:].t().mm(b[main:])
+    return out
+
+
 def edge_forward(Q, K, V, csr, n_rows, L, D, H, out2d, qidx=None, dtype=_lib.AMPCONV_F32):
     lib = _lib.load()
     rc = lib.ampconv_fwd_edge(Q, K, V, csr.rowptr.data_ptr(), csr.col.data_ptr(), _ptr(qidx),
@@ -101,7 +117,7 @@ class AMPConvFunction(torch.autograd.Function):
                                            scratch.data_ptr(), _stream())
             _lib.check(rc, 'ampconv_masked_colsum')
             db_out = scratch[:D].clone()
-            dw_out = dy2.t().mm(obar)
+            dw_out = _tn_matmul(dy2, obar)
             dobar = dy2.mm(w_out)                                          # [Nq*L, D]
             dOv = _view(dobar, 0, L, dh)
             if shared:
@@ -123,12 +139,12 @@ class AMPConvFunction(torch.autograd.Function):
             _lib.check(rc, 'ampconv_bwd_edge_src')
             del dobar
             if shared:
-                dw_in = dqkv.t().mm(xq2)
+                dw_in = _tn_matmul(dqkv, xq2)
                 db_in = dqkv.sum(dim=0)
                 dxq = dqkv.mm(w_in).view(Nq, L * D) if need_xq else None
                 dxkv = None
             else:
-                dw_in = torch.cat([dqkv.t().mm(xq2), dkv.t().mm(xkv2)], dim=0)
+                dw_in = torch.cat([_tn_matmul(dqkv, xq2), _tn_matmul(dkv, xkv2)], dim=0)
                 db_in = torch.cat([dqkv.sum(dim=0), dkv.sum(dim=0)])
                 dxq = dqkv.mm(w_in[:D]).view(Nq, L * D) if need_xq else None
                 dxkv = dkv.mm(w_in[D:]).view(Nk, L * D) if need_xkv else None

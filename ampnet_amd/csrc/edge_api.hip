@@ -21,9 +21,10 @@ int check_common(int L, int D, int H, int dtype) {
 int split_products(int dtype, int L, int D, int H) {
   if (dtype == AMPCONV_F32) {
     const char *e = std::getenv("AMPCONV_F32_MODE");
-    if (e && e[0] == 'e') dtype = AMPCONV_F32_EXACT;
-    else if (e && e[0] == 'b' && e[5] == '6') dtype = AMPCONV_F32_BF16X6;
-    else dtype = AMPCONV_F32_BF16X9;
+    if (e && e[0] == 'b' && e[1] == 'f' && e[2] == '1' && e[3] == '6' && e[4] == 'x')
+      dtype = e[5] == '6' ? AMPCONV_F32_BF16X6 : AMPCONV_F32_BF16X9;
+    else
+      dtype = AMPCONV_F32_EXACT;
   }
   if (dtype == AMPCONV_F32_EXACT || !ampconv_split_supported(L, D, H)) return 0;
   return dtype == AMPCONV_F32_BF16X6 ? 6 : 9;

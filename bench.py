@@ -141,14 +141,15 @@ def main():
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
-    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0)) % max(1, torch.cuda.device_count())
     world = int(os.environ.get('WORLD_SIZE', 1))
     assert torch.cuda.is_available(), 'bench.py needs a GPU'
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)       # nccl == RCCL on ROCm
+        backend = os.environ.get('AMPCONV_DIST_BACKEND', 'nccl')   # nccl == RCCL on ROCm (gloo: tests only)
+        dist.init_process_group(backend, **({'device_id': dev} if backend == 'nccl' else {}))
 
     from ampnet_amd import AMPConv, graph_cache, _lib
     from ampnet_amd.conv import functional as F_
