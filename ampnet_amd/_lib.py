@@ -16,6 +16,7 @@ AMPCONV_F32_BF16X9 = 3     # fp32 operands split exactly into 3 bf16, 9 partial 
 AMPCONV_F32_BF16X6 = 4     # ... 6 partial products
 PRECISIONS = {'default': AMPCONV_F32, 'exact': AMPCONV_F32_EXACT, 'bf16x9': AMPCONV_F32_BF16X9,
               'bf16x6': AMPCONV_F32_BF16X6}
+HUB_CHUNK = 256            # edges per chunk of a long CSR/CSC segment (include/ampconv.h, long segments)
 COLSUM_BLOCKS = 1024      # scratch blocks of ampconv_masked_colsum (csrc/node_ops.hip)
 
 
@@ -33,10 +34,14 @@ SIGNATURES = {
     'ampconv_error_string': (ctypes.c_char_p, [_i32]),
     'ampconv_csr_workspace_bytes': (_sz, [_i64, _i64]),
     'ampconv_csr_build': (_i32, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    'ampconv_fwd_edge': (_i32, [View, View, View, _vp, _vp, _vp, _i64, _i32, _i32, _i32, View, _i32, _vp]),
-    'ampconv_bwd_edge_dst': (_i32, [View, View, View, View, _vp, _vp, _i64, _i32, _i32, _i32, View, _i32, _vp]),
+    'ampconv_hub_plan_bytes': (_sz, [_i64, _i32]),
+    'ampconv_hub_plan': (_i32, [_vp, _i64, _i64, _i32, _vp, _vp]),
+    'ampconv_hub_workspace_bytes': (_sz, [_i64, _i32, _i32, _i32]),
+    'ampconv_fwd_edge': (_i32, [View, View, View, _vp, _vp, _vp, _i64, _i32, _i32, _i32, View, _vp, _i64, _vp, _i32, _vp]),
+    'ampconv_bwd_edge_dst': (_i32, [View, View, View, View, _vp, _vp, _i64, _i32, _i32, _i32, View, _vp, _i64, _vp,
+                                    _i32, _vp]),
     'ampconv_bwd_edge_src': (_i32, [View, View, View, View, _vp, _vp, _vp, _i64, _i32, _i32, _i32,
-                                    View, View, _i32, _vp]),
+                                    View, View, _vp, _i64, _vp, _i32, _vp]),
     'ampconv_attn_weights': (_i32, [View, View, _vp, _i64, _i32, _i32, _i32, _vp, _i32, _vp]),
     'ampconv_segment_mean': (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _vp]),
     'ampconv_mask_rows': (_i32, [_vp, _vp, _i64, _i64, _vp]),

@@ -50,8 +50,10 @@ def _tn_matmul(a, b, chunks=128):
 
 def edge_forward(Q, K, V, csr, n_rows, L, D, H, out2d, qidx=None, dtype=_lib.AMPCONV_F32):
     lib = _lib.load()
+    plan, nch, ws = csr.hub_args('dst', L, D, 1) if qidx is None else (None, 0, None)
     rc = lib.ampconv_fwd_edge(Q, K, V, csr.rowptr.data_ptr(), csr.col.data_ptr(), _ptr(qidx),
-                              n_rows, L, D, H, _view(out2d, 0, L, D // H), dtype, _stream())
+                              n_rows, L, D, H, _view(out2d, 0, L, D // H), plan, nch, _ptr(ws),
+                              dtype, _stream())
     _lib.check(rc, 'ampconv_fwd_edge')
 
 
@@ -130,11 +132,13 @@ class AMPConvFunction(torch.autograd.Function):
                 dkv = torch.empty(Nk * L, 2 * D, dtype=torch.float32, device=dev)
                 Qv, Kv, Vv = _view(qkv, 0, L, dh), _view(kv, 0, L, dh), _view(kv, D, L, dh)
                 dQv, dKv, dVv = _view(dqkv, 0, L, dh), _view(dkv, 0, L, dh), _view(dkv, D, L, dh)
+            plan, nch, ws = csr.hub_args('dst', L, D, 1)
             rc = lib.ampconv_bwd_edge_dst(Qv, Kv, Vv, dOv, csr.rowptr.data_ptr(), csr.col.data_ptr(),
-                                          Nq, L, D, H, dQv, ctx.dtype, _stream())
+                                          Nq, L, D, H, dQv, plan, nch, _ptr(ws), ctx.dtype, _stream())
             _lib.check(rc, 'ampconv_bwd_edge_dst')
+            plan, nch, ws = csr.hub_args('src', L, D, 2)
             rc = lib.ampconv_bwd_edge_src(Qv, Kv, Vv, dOv, csr.cscptr.data_ptr(), csr.crow.data_ptr(),
-                                          csr.cinv.data_ptr(), Nk, L, D, H, dKv, dVv,
+                                          csr.cinv.data_ptr(), Nk, L, D, H, dKv, dVv, plan, nch, _ptr(ws),
                                           ctx.dtype, _stream())
             _lib.check(rc, 'ampconv_bwd_edge_src')
             del dobar

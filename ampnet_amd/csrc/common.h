@@ -30,6 +30,41 @@ __device__ __forceinline__ float wave_sum(float x) {
   return x;
 }
 
+// ---- long segments ("hubs", BASELINE config 5): a CSR/CSC segment longer than `chunk` edges is
+// cut into chunks that separate waves reduce into partial tiles; an ordered combine pass adds
+// the partial tiles of one row (deterministic).  Descriptors are built by ampconv_hub_plan.
+struct HubDesc {
+  int32_t row, beg, end;   // row of the segment, CSR/CSC positions [beg, end) of this chunk
+  int32_t nfirst;          // number of chunks of the row if this is its first chunk, else 0
+};
+struct HubArgs {
+  const int32_t *header;   // plan header {n_chunks, chunk, 0, 0}; descriptors follow at header + 4
+  int mode;                // 0: no plan, 1: main pass (rows longer than header[1] are skipped),
+                           // 2: hub pass (one unit per (chunk, head), writes partial tiles)
+};
+
+// unit -> (row, head, edge range); returns false if this wave has nothing to do
+__device__ __forceinline__ bool map_unit(const HubArgs &hub, const int32_t *ptr, int64_t unit, int H,
+                                         int64_t &row, int64_t &out_node, int &h, int &beg, int &end,
+                                         int &deg) {
+  const int64_t u = unit / H;
+  h = (int)(unit - u * H);
+  if (hub.mode == 2) {
+    const HubDesc d = reinterpret_cast<const HubDesc *>(hub.header + 4)[u];
+    row = d.row;
+    out_node = u;
+    beg = d.beg;
+    end = d.end;
+    deg = ptr[row + 1] - ptr[row];
+    return true;
+  }
+  row = out_node = u;
+  beg = ptr[u];
+  end = ptr[u + 1];
+  deg = end - beg;
+  return !(hub.mode == 1 && deg > hub.header[1]);
+}
+
 // ---- internal entry points (edge_generic.hip / edge_mfma.hip), dispatched by edge_api.hip
 int ampconv_fwd_edge_generic(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
                              const int32_t *rowptr, const int32_t *col, const int32_t *qidx,
@@ -49,16 +84,16 @@ bool ampconv_mfma_supported(int L, int D, int H);
 bool ampconv_mfma_views_ok(const ampconv_view_t *views, int n);
 int ampconv_fwd_edge_mfma(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
                           const int32_t *rowptr, const int32_t *col, const int32_t *qidx,
-                          int64_t n_rows, int L, int D, int H, ampconv_view_t O,
+                          int64_t n_rows, int L, int D, int H, ampconv_view_t O, HubArgs hub,
                           hipStream_t stream);
 int ampconv_bwd_edge_dst_mfma(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
                               ampconv_view_t dO, const int32_t *rowptr, const int32_t *col,
-                              int64_t n_rows, int L, int D, int H, ampconv_view_t dQ,
+                              int64_t n_rows, int L, int D, int H, ampconv_view_t dQ, HubArgs hub,
                               hipStream_t stream);
 int ampconv_bwd_edge_src_mfma(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
                               ampconv_view_t dO, const int32_t *cscptr, const int32_t *crow,
                               const float *cinv, int64_t n_src, int L, int D, int H,
-                              ampconv_view_t dK, ampconv_view_t dV, hipStream_t stream);
+                              ampconv_view_t dK, ampconv_view_t dV, HubArgs hub, hipStream_t stream);
 
 // ---- split-operand bf16 MFMA path (edge_mfma_split.hip): L <= 20, dh == 32; nprod = 9 or 6
 bool ampconv_split_supported(int L, int D, int H);
@@ -73,3 +108,8 @@ int ampconv_bwd_edge_src_split(int nprod, ampconv_view_t Q, ampconv_view_t K, am
                                ampconv_view_t dO, const int32_t *cscptr, const int32_t *crow,
                                const float *cinv, int64_t n_src, int L, int D, int H,
                                ampconv_view_t dK, ampconv_view_t dV, hipStream_t stream);
+
+// hub.hip
+int ampconv_hub_combine(const void *plan, int64_t n_chunks, const float *P, ampconv_view_t out,
+                        const int32_t *ptr_for_mean, int L, int D, int H, float scale,
+                        hipStream_t stream);

@@ -18,6 +18,13 @@ int check_common(int L, int D, int H, int dtype) {
   return AMPCONV_OK;
 }
 // number of bf16 partial products of the split path to use (9 / 6), or 0 for native fp32 MFMA
+// partial-tile view of the hub workspace: chunk c, token l, channel cc at P[(c*L + l)*D + cc]
+ampconv_view_t partial_view(void *ws, int64_t tile, int64_t n_chunks, int L, int D, int H) {
+  return ampconv_view_t{(float *)ws + tile * n_chunks * L * D, (int64_t)L * D, (int64_t)D,
+                        (int64_t)(D / H)};
+}
+HubArgs hub_args(const void *plan, int mode) { return HubArgs{(const int32_t *)plan, mode}; }
+
 int split_products(int dtype, int L, int D, int H) {
   if (dtype == AMPCONV_F32) {
     const char *e = std::getenv("AMPCONV_F32_MODE");
@@ -45,7 +52,8 @@ extern "C" const char *ampconv_error_string(int code) {
 
 extern "C" int ampconv_fwd_edge(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
                                 const int32_t *rowptr, const int32_t *col, const int32_t *qidx,
-                                int64_t n_rows, int L, int D, int H, ampconv_view_t O, int dtype,
+                                int64_t n_rows, int L, int D, int H, ampconv_view_t O,
+                                const void *hub_plan, int64_t hub_chunks, void *hub_ws, int dtype,
                                 void *stream) {
   if (int rc = check_common(L, D, H, dtype)) return rc;
   if (n_rows < 0) return AMPCONV_E_BADARG;
@@ -56,7 +64,19 @@ extern "C" int ampconv_fwd_edge(ampconv_view_t Q, ampconv_view_t K, ampconv_view
     if (const int np = split_products(dtype, L, D, H))
       return ampconv_fwd_edge_split(np, Q, K, V, rowptr, col, qidx, n_rows, L, D, H, O,
                                     (hipStream_t)stream);
-    return ampconv_fwd_edge_mfma(Q, K, V, rowptr, col, qidx, n_rows, L, D, H, O,
+    if (hub_plan && hub_chunks > 0 && hub_ws && !qidx) {      // long segments: main + hub + combine
+      HubArgs hm = hub_args(hub_plan, 1), hh = hub_args(hub_plan, 2);
+      if (int rc = ampconv_fwd_edge_mfma(Q, K, V, rowptr, col, nullptr, n_rows, L, D, H, O, hm,
+                                         (hipStream_t)stream))
+        return rc;
+      ampconv_view_t P = partial_view(hub_ws, 0, hub_chunks, L, D, H);
+      if (int rc = ampconv_fwd_edge_mfma(Q, K, V, rowptr, col, nullptr, hub_chunks, L, D, H, P, hh,
+                                         (hipStream_t)stream))
+        return rc;
+      return ampconv_hub_combine(hub_plan, hub_chunks, (const float *)P.ptr, O, rowptr, L, D, H, 1.f,
+                                 (hipStream_t)stream);
+    }
+    return ampconv_fwd_edge_mfma(Q, K, V, rowptr, col, qidx, n_rows, L, D, H, O, HubArgs{nullptr, 0},
                                  (hipStream_t)stream);
   }
   return ampconv_fwd_edge_generic(Q, K, V, rowptr, col, qidx, n_rows, L, D, H, O,
@@ -66,7 +86,8 @@ extern "C" int ampconv_fwd_edge(ampconv_view_t Q, ampconv_view_t K, ampconv_view
 extern "C" int ampconv_bwd_edge_dst(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
                                     ampconv_view_t dObar, const int32_t *rowptr,
                                     const int32_t *col, int64_t n_rows, int L, int D, int H,
-                                    ampconv_view_t dQ, int dtype, void *stream) {
+                                    ampconv_view_t dQ, const void *hub_plan, int64_t hub_chunks,
+                                    void *hub_ws, int dtype, void *stream) {
   if (int rc = check_common(L, D, H, dtype)) return rc;
   if (n_rows < 0) return AMPCONV_E_BADARG;
   if (n_rows == 0) return AMPCONV_OK;
@@ -77,8 +98,20 @@ extern "C" int ampconv_bwd_edge_dst(ampconv_view_t Q, ampconv_view_t K, ampconv_
     if (const int np = split_products(dtype, L, D, H))
       return ampconv_bwd_edge_dst_split(np, Q, K, V, dObar, rowptr, col, n_rows, L, D, H, dQ,
                                         (hipStream_t)stream);
+    if (hub_plan && hub_chunks > 0 && hub_ws) {
+      HubArgs hm = hub_args(hub_plan, 1), hh = hub_args(hub_plan, 2);
+      if (int rc = ampconv_bwd_edge_dst_mfma(Q, K, V, dObar, rowptr, col, n_rows, L, D, H, dQ, hm,
+                                             (hipStream_t)stream))
+        return rc;
+      ampconv_view_t P = partial_view(hub_ws, 0, hub_chunks, L, D, H);
+      if (int rc = ampconv_bwd_edge_dst_mfma(Q, K, V, dObar, rowptr, col, hub_chunks, L, D, H, P, hh,
+                                             (hipStream_t)stream))
+        return rc;
+      return ampconv_hub_combine(hub_plan, hub_chunks, (const float *)P.ptr, dQ, nullptr, L, D, H,
+                                 1.f / sqrtf((float)(D / H)), (hipStream_t)stream);
+    }
     return ampconv_bwd_edge_dst_mfma(Q, K, V, dObar, rowptr, col, n_rows, L, D, H, dQ,
-                                     (hipStream_t)stream);
+                                     HubArgs{nullptr, 0}, (hipStream_t)stream);
   }
   return ampconv_bwd_edge_dst_generic(Q, K, V, dObar, rowptr, col, n_rows, L, D, H, dQ,
                                       (hipStream_t)stream);
@@ -88,6 +121,7 @@ extern "C" int ampconv_bwd_edge_src(ampconv_view_t Q, ampconv_view_t K, ampconv_
                                     ampconv_view_t dObar, const int32_t *cscptr,
                                     const int32_t *crow, const float *cinv, int64_t n_src,
                                     int L, int D, int H, ampconv_view_t dK, ampconv_view_t dV,
+                                    const void *hub_plan, int64_t hub_chunks, void *hub_ws,
                                     int dtype, void *stream) {
   if (int rc = check_common(L, D, H, dtype)) return rc;
   if (n_src < 0) return AMPCONV_E_BADARG;
@@ -100,8 +134,24 @@ extern "C" int ampconv_bwd_edge_src(ampconv_view_t Q, ampconv_view_t K, ampconv_
     if (const int np = split_products(dtype, L, D, H))
       return ampconv_bwd_edge_src_split(np, Q, K, V, dObar, cscptr, crow, cinv, n_src, L, D, H,
                                         dK, dV, (hipStream_t)stream);
+    if (hub_plan && hub_chunks > 0 && hub_ws) {
+      HubArgs hm = hub_args(hub_plan, 1), hh = hub_args(hub_plan, 2);
+      if (int rc = ampconv_bwd_edge_src_mfma(Q, K, V, dObar, cscptr, crow, cinv, n_src, L, D, H, dK, dV,
+                                             hm, (hipStream_t)stream))
+        return rc;
+      ampconv_view_t PK = partial_view(hub_ws, 0, hub_chunks, L, D, H);
+      ampconv_view_t PV = partial_view(hub_ws, 1, hub_chunks, L, D, H);
+      if (int rc = ampconv_bwd_edge_src_mfma(Q, K, V, dObar, cscptr, crow, cinv, hub_chunks, L, D, H, PK,
+                                             PV, hh, (hipStream_t)stream))
+        return rc;
+      if (int rc = ampconv_hub_combine(hub_plan, hub_chunks, (const float *)PK.ptr, dK, nullptr, L, D, H,
+                                       0.6931471805599453f, (hipStream_t)stream))
+        return rc;
+      return ampconv_hub_combine(hub_plan, hub_chunks, (const float *)PV.ptr, dV, nullptr, L, D, H, 1.f,
+                                 (hipStream_t)stream);
+    }
     return ampconv_bwd_edge_src_mfma(Q, K, V, dObar, cscptr, crow, cinv, n_src, L, D, H, dK, dV,
-                                     (hipStream_t)stream);
+                                     HubArgs{nullptr, 0}, (hipStream_t)stream);
   }
   return ampconv_bwd_edge_src_generic(Q, K, V, dObar, cscptr, crow, cinv, n_src, L, D, H, dK,
                                       dV, (hipStream_t)stream);

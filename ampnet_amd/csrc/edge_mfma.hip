@@ -41,7 +41,8 @@ constexpr int kWavesPerBlock = AMPCONV_WPB;
 struct FwdArgs {
   ampconv_view_t Q, K, V, O;
   const int32_t *rowptr, *col, *qidx;
-  int64_t n_units;   // n_rows * H
+  HubArgs hub;
+  int64_t n_units;   // n_rows * H (hub pass: chunks * H)
   int L, H;
   float qscale;      // log2(e) / sqrt(dh)
 };
@@ -76,12 +77,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void fwd_mfma(FwdArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t unit = (int64_t)blockIdx.x * kWavesPerBlock + wave;
   if (unit >= a.n_units) return;
-  const int64_t r = unit / a.H;
-  const int h = (int)(unit - r * a.H);
+  int64_t r, onode;
+  int h, beg, end, deg;
+  if (!map_unit(a.hub, a.rowptr, unit, a.H, r, onode, h, beg, end, deg)) return;
   const int L = a.L, g = lane >> 4;
   float *Kt = lds_all[wave][0], *Vt = lds_all[wave][1];
-
-  const int beg = a.rowptr[r], end = a.rowptr[r + 1];
   const int64_t d = a.qidx ? a.qidx[r] : r;
 
   // fixed side: Q^T as the B operand (columns = destination tokens), pre-scaled so that
@@ -159,8 +159,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void fwd_mfma(FwdArgs a) {
   }
 
   // O^T C/D layout: lane (i' = lane & 15, g), reg q -> channel 4g + q + 16 mc, token i' + 16 nt
-  const float inv = end > beg ? 1.f / (float)(end - beg) : 0.f;
-  float *ob = tile_ptr<float>(a.O, r, h);
+  // hub pass: unnormalised partial tile, the combine pass applies 1/deg
+  const float inv = a.hub.mode == 2 ? 1.f : (deg > 0 ? 1.f / (float)deg : 0.f);
+  float *ob = tile_ptr<float>(a.O, onode, h);
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
     const int i = (lane & 15) + 16 * nt;
@@ -194,6 +195,7 @@ __device__ unsigned long long g_stamp_sums[8 * 4096];
 
 struct BwdArgs {
   ampconv_view_t Q, K, V, dO, dQ, dK, dV;
+  HubArgs hub;
   const int32_t *ptr;      // rowptr (dst pass) / cscptr (src pass)
   const int32_t *idx;      // col (dst pass) / crow (src pass)
   const float *cinv;       // src pass: 1/in-degree of the destination of each CSC edge
@@ -220,12 +222,13 @@ __global__ LB_DST void bwd_dst_mfma(BwdArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t unit = (int64_t)blockIdx.x * kWavesPerBlock + wave;
   if (unit >= a.n_units) return;
-  const int64_t r = unit / a.H;
-  const int h = (int)(unit - r * a.H);
+  int64_t r, onode;
+  int h, beg, end, deg;
+  if (!map_unit(a.hub, a.ptr, unit, a.H, r, onode, h, beg, end, deg)) return;
   const int L = a.L, g = lane >> 4;
   float *Kt = lds_all[wave][0], *Vt = lds_all[wave][1];
-  const int beg = a.ptr[r], end = a.ptr[r + 1];
-  const float inv = end > beg ? 1.f / (float)(end - beg) : 0.f;
+  const float inv = deg > 0 ? 1.f / (float)deg : 0.f;       // dO is the gradient of the MEAN
+  const float oscale = a.hub.mode == 2 ? 1.f : a.oscale;   // hub pass: the combine pass scales
 
   float qB[2][C::KK], dOB[2][C::KK];
   {
@@ -313,15 +316,15 @@ __global__ LB_DST void bwd_dst_mfma(BwdArgs a) {
       if (p0 + k < end) step(ring[k], p0 + k);
   }
 
-  float *ob = tile_ptr<float>(a.dQ, r, h);
+  float *ob = tile_ptr<float>(a.dQ, onode, h);
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
     const int i = (lane & 15) + 16 * nt;
     if (i < L) {
 #pragma unroll
       for (int mc = 0; mc < C::MC; ++mc) {
-        float4 o = make_float4(dQT[mc][nt][0] * a.oscale, dQT[mc][nt][1] * a.oscale,
-                               dQT[mc][nt][2] * a.oscale, dQT[mc][nt][3] * a.oscale);
+        float4 o = make_float4(dQT[mc][nt][0] * oscale, dQT[mc][nt][1] * oscale,
+                               dQT[mc][nt][2] * oscale, dQT[mc][nt][3] * oscale);
         *reinterpret_cast<float4 *>(ob + (int64_t)i * a.dQ.row_stride + 4 * g + 16 * mc) = o;
       }
     }
@@ -339,11 +342,12 @@ __global__ LB_SRC void bwd_src_mfma(BwdArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t unit = (int64_t)blockIdx.x * kWavesPerBlock + wave;
   if (unit >= a.n_units) return;
-  const int64_t s = unit / a.H;
-  const int h = (int)(unit - s * a.H);
+  int64_t s, onode;
+  int h, beg, end, deg;
+  if (!map_unit(a.hub, a.ptr, unit, a.H, s, onode, h, beg, end, deg)) return;
   const int L = a.L, n = lane & 15;
   float *Qt = lds_all[wave][0], *Gt = lds_all[wave][1];
-  const int beg = a.ptr[s], end = a.ptr[s + 1];
+  const float oscale = a.hub.mode == 2 ? 1.f : a.oscale;
 
   float kB[2][C::KK], vB[2][C::KK];
   {
@@ -452,15 +456,15 @@ __global__ LB_SRC void bwd_src_mfma(BwdArgs a) {
 
   STAMP_FLUSH(unit);
   const int g = lane >> 4;
-  float *kb = tile_ptr<float>(a.dK, s, h), *vb = tile_ptr<float>(a.dV, s, h);
+  float *kb = tile_ptr<float>(a.dK, onode, h), *vb = tile_ptr<float>(a.dV, onode, h);
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
     const int j = n + 16 * nt;
     if (j < L) {
 #pragma unroll
       for (int mc = 0; mc < C::MC; ++mc) {
-        float4 k4 = make_float4(dKT[mc][nt][0] * a.oscale, dKT[mc][nt][1] * a.oscale,
-                                dKT[mc][nt][2] * a.oscale, dKT[mc][nt][3] * a.oscale);
+        float4 k4 = make_float4(dKT[mc][nt][0] * oscale, dKT[mc][nt][1] * oscale,
+                                dKT[mc][nt][2] * oscale, dKT[mc][nt][3] * oscale);
         float4 v4 = make_float4(dVT[mc][nt][0], dVT[mc][nt][1], dVT[mc][nt][2], dVT[mc][nt][3]);
         *reinterpret_cast<float4 *>(kb + (int64_t)j * a.dK.row_stride + 4 * g + 16 * mc) = k4;
         *reinterpret_cast<float4 *>(vb + (int64_t)j * a.dV.row_stride + 4 * g + 16 * mc) = v4;
@@ -489,10 +493,10 @@ bool ampconv_mfma_views_ok(const ampconv_view_t *views, int n) {
 
 int ampconv_fwd_edge_mfma(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
                           const int32_t *rowptr, const int32_t *col, const int32_t *qidx,
-                          int64_t n_rows, int L, int D, int H, ampconv_view_t O,
+                          int64_t n_rows, int L, int D, int H, ampconv_view_t O, HubArgs hub,
                           hipStream_t stream) {
   const int dh = D / H;
-  FwdArgs a{Q, K, V, O, rowptr, col, qidx, n_rows * H, L, H, kLog2e / sqrtf((float)dh)};
+  FwdArgs a{Q, K, V, O, rowptr, col, qidx, hub, n_rows * H, L, H, kLog2e / sqrtf((float)dh)};
   const int64_t blocks = (a.n_units + kWavesPerBlock - 1) / kWavesPerBlock;
   if (blocks > INT32_MAX) return AMPCONV_E_BADARG;
   const dim3 grid((unsigned)blocks), block(64 * kWavesPerBlock);
@@ -505,10 +509,11 @@ int ampconv_fwd_edge_mfma(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
 
 int ampconv_bwd_edge_dst_mfma(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
                               ampconv_view_t dO, const int32_t *rowptr, const int32_t *col,
-                              int64_t n_rows, int L, int D, int H, ampconv_view_t dQ,
+                              int64_t n_rows, int L, int D, int H, ampconv_view_t dQ, HubArgs hub,
                               hipStream_t stream) {
   const int dh = D / H;
   BwdArgs a{};
+  a.hub = hub;
   a.Q = Q; a.K = K; a.V = V; a.dO = dO; a.dQ = dQ;
   a.ptr = rowptr; a.idx = col; a.cinv = nullptr;
   a.n_units = n_rows * H; a.L = L; a.H = H;
@@ -527,9 +532,10 @@ int ampconv_bwd_edge_dst_mfma(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t
 int ampconv_bwd_edge_src_mfma(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
                               ampconv_view_t dO, const int32_t *cscptr, const int32_t *crow,
                               const float *cinv, int64_t n_src, int L, int D, int H,
-                              ampconv_view_t dK, ampconv_view_t dV, hipStream_t stream) {
+                              ampconv_view_t dK, ampconv_view_t dV, HubArgs hub, hipStream_t stream) {
   const int dh = D / H;
   BwdArgs a{};
+  a.hub = hub;
   a.Q = Q; a.K = K; a.V = V; a.dO = dO; a.dK = dK; a.dV = dV;
   a.ptr = cscptr; a.idx = crow; a.cinv = cinv;
   a.n_units = n_src * H; a.L = L; a.H = H;

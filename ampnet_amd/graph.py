@@ -49,8 +49,26 @@ class EdgeCSR:
                                        self.cperm.data_ptr(), self.cinv.data_ptr(), oob.data_ptr(), ws.data_ptr(),
                                        ws_bytes,
                                        _stream())
-        _lib.check(rc, 'ampconv_csr_build')
-        if validate and E > 0 and int(oob.item()) != 0:
+            _lib.check(rc, 'ampconv_csr_build')
+            # long-segment plans (hubs of power-law graphs): one for the dst-sorted CSR, one for the
+            # src-sorted CSC; their chunk counts come back with the bounds flag in ONE read-back
+            self.hub_dst = self.hub_src = None
+            self.hub_dst_chunks = self.hub_src_chunks = 0
+            if E > _lib.HUB_CHUNK:
+                nb = lib.ampconv_hub_plan_bytes(E, _lib.HUB_CHUNK)
+                plans = [torch.empty(nb // 4, **i32), torch.empty(nb // 4, **i32)]
+                for plan, ptr in zip(plans, (self.rowptr, self.cscptr)):
+                    _lib.check(lib.ampconv_hub_plan(ptr.data_ptr(), N, E, _lib.HUB_CHUNK, plan.data_ptr(),
+                                                    _stream()), 'ampconv_hub_plan')
+                bad, self.hub_dst_chunks, self.hub_src_chunks = torch.stack(
+                    [oob[0], plans[0][0], plans[1][0]]).tolist()
+                if self.hub_dst_chunks:
+                    self.hub_dst = plans[0][: 4 + 4 * self.hub_dst_chunks]
+                if self.hub_src_chunks:
+                    self.hub_src = plans[1][: 4 + 4 * self.hub_src_chunks]
+            else:
+                bad = int(oob.item()) if (validate and E > 0) else 0
+        if validate and E > 0 and bad != 0:
             raise ValueError(f'edge_index contains node ids outside [0, {N})')
 
     @classmethod
@@ -62,7 +80,18 @@ class EdgeCSR:
         self.rowptr = self.cscptr = ar
         self.col = self.crow = self.eperm = self.cperm = ar[:max(n, 1)]
         self.cinv = torch.ones(max(n, 1), dtype=torch.float32, device=device)
+        self.hub_dst = self.hub_src = None
+        self.hub_dst_chunks = self.hub_src_chunks = 0
         return self
+
+    def hub_args(self, side, L, D, n_tiles):
+        """(plan pointer, n_chunks, workspace tensor) of the 'dst' or 'src' long-segment plan."""
+        plan = self.hub_dst if side == 'dst' else self.hub_src
+        n = self.hub_dst_chunks if side == 'dst' else self.hub_src_chunks
+        if plan is None or n == 0:
+            return None, 0, None
+        ws = torch.empty(n * L * D * n_tiles, dtype=torch.float32, device=plan.device)
+        return plan.data_ptr(), n, ws
 
 
 class _Cache:

@@ -89,6 +89,18 @@ int ampconv_csr_build(const int64_t *edge_index, int64_t E, int64_t N,
                       int32_t *oob, void *workspace, size_t workspace_bytes,
                       void *stream);
 
+/* ---- long segments ("hubs": power-law graphs, BASELINE config 5) ---------------------------
+ * One wavefront per (row, head) runs as long as its longest segment.  A plan cuts every CSR
+ * (or CSC) segment longer than `chunk` edges into chunks; the edge kernels then reduce each
+ * chunk in its own wavefront into a partial tile in `hub_ws` and an ordered pass adds a row's
+ * partial tiles (fixed order: bitwise reproducible).  plan = int32 header {n_chunks, chunk, 0, 0}
+ * followed by 16-byte descriptors; the caller reads header[0] back once (n_chunks), sizes
+ * hub_ws with ampconv_hub_workspace_bytes and passes both to the edge calls (plan = NULL or
+ * n_chunks = 0: no splitting).  n_tiles = 1 (forward, dst pass) or 2 (src pass: dK and dV).  */
+size_t ampconv_hub_plan_bytes(int64_t E, int chunk);
+int ampconv_hub_plan(const int32_t *ptr, int64_t N, int64_t E, int chunk, void *plan, void *stream);
+size_t ampconv_hub_workspace_bytes(int64_t n_chunks, int L, int D, int n_tiles);
+
 /* ---- edge phase, forward ----------------------------------------------------
  * For every row r < n_rows (destination d = qidx ? qidx[r] : r) and head h:
  *   O[r,:,h] = (1/deg_r) * sum_{p in [rowptr[r], rowptr[r+1])}
@@ -99,7 +111,8 @@ int ampconv_csr_build(const int64_t *edge_index, int64_t E, int64_t N,
 int ampconv_fwd_edge(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
                      const int32_t *rowptr, const int32_t *col,
                      const int32_t *qidx, int64_t n_rows, int L, int D, int H,
-                     ampconv_view_t O, int dtype, void *stream);
+                     ampconv_view_t O, const void *hub_plan, int64_t hub_chunks,
+                     void *hub_ws, int dtype, void *stream);
 
 /* ---- edge phase, backward (autograd of the above; amp_conv.py has no custom
  * backward, cora_benchmark_graphsaint.py:110 calls loss.backward()) ------------
@@ -111,12 +124,14 @@ int ampconv_fwd_edge(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
 int ampconv_bwd_edge_dst(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
                          ampconv_view_t dObar, const int32_t *rowptr,
                          const int32_t *col, int64_t n_rows, int L, int D, int H,
-                         ampconv_view_t dQ, int dtype, void *stream);
+                         ampconv_view_t dQ, const void *hub_plan, int64_t hub_chunks,
+                         void *hub_ws, int dtype, void *stream);
 int ampconv_bwd_edge_src(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
                          ampconv_view_t dObar, const int32_t *cscptr,
                          const int32_t *crow, const float *cinv,
                          int64_t n_src, int L, int D, int H, ampconv_view_t dK,
-                         ampconv_view_t dV, int dtype, void *stream);
+                         ampconv_view_t dV, const void *hub_plan, int64_t hub_chunks,
+                         void *hub_ws, int dtype, void *stream);
 
 /* ---- per-edge side outputs, ORIGINAL edge order ------------------------------
  * attn_weights: W[e] = mean_h softmax_rows(Q[dst e,:,h] K[src e,:,h]^T/sqrt(dh)),

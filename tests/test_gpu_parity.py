@@ -185,6 +185,7 @@ def test_seeded_vs_oracle(shape, dev):
     dy = torch.randn(N, L * D, generator=g)
     ei = torch.randint(0, N - 50, (2, E), generator=g)       # last 50 nodes isolated
     ei[1, : E // 10] = 3                                      # hub: 10 % of the edges end at node 3
+    ei[0, E // 10: E // 5] = 7                                # ... and 10 % start at node 7 (CSC hub)
     xg = x.to(dev).requires_grad_(True)
     y = layer(xg, ei.to(dev))
     (y * dy.to(dev)).sum().backward()
@@ -263,6 +264,7 @@ def test_full_size_config3(dev, monkeypatch):
     dy = torch.randn(N, L * D, device=dev, generator=g)
     ei = torch.randint(0, N, (2, E), device=dev, generator=g)
     ei[1, :3000] = 77                                         # a 3000-in-edge hub
+    ei[0, 3000:5000] = 78                                     # a 2000-out-edge hub
 
     def run():
         graph_cache.clear()

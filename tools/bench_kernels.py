@@ -44,6 +44,9 @@ def main():
     qkv = torch.randn(N * L, 3 * D, device=dev)
     dobar = torch.randn(N * L, D, device=dev)
     ei = torch.randint(0, N, (2, E), device=dev)
+    if '--hub' in sys.argv:                       # 5 % of the edges end at node 3, 5 % start at node 5
+        ei[1, : E // 20] = 3
+        ei[0, E // 20: E // 10] = 5
     t0 = time.time()
     csr = EdgeCSR(ei, N)
     torch.cuda.synchronize()
@@ -57,17 +60,24 @@ def main():
     st = torch.cuda.current_stream().cuda_stream
     R = L * D * 4
 
+    keep = {}
+
+    def hub(side, tiles):
+        plan, n, ws = csr.hub_args(side, L, D, tiles)
+        keep[side] = ws
+        return plan, n, (ws.data_ptr() if ws is not None else None)
+
     def fwd():
         _lib.check(lib.ampconv_fwd_edge(Qv, Kv, Vv, csr.rowptr.data_ptr(), csr.col.data_ptr(), None,
-                                        N, L, D, H, F_._view(obar, 0, L, dh), dt, st), 'fwd')
+                                        N, L, D, H, F_._view(obar, 0, L, dh), *hub('dst', 1), dt, st), 'fwd')
 
     def bwd_dst():
         _lib.check(lib.ampconv_bwd_edge_dst(Qv, Kv, Vv, dOv, csr.rowptr.data_ptr(), csr.col.data_ptr(),
-                                            N, L, D, H, dQv, dt, st), 'bwd_dst')
+                                            N, L, D, H, dQv, *hub('dst', 1), dt, st), 'bwd_dst')
 
     def bwd_src():
         _lib.check(lib.ampconv_bwd_edge_src(Qv, Kv, Vv, dOv, csr.cscptr.data_ptr(), csr.crow.data_ptr(),
-                                            csr.cinv.data_ptr(), N, L, D, H, dKv, dVv, dt, st), 'bwd_src')
+                                            csr.cinv.data_ptr(), N, L, D, H, dKv, dVv, *hub('src', 2), dt, st), 'bwd_src')
 
     for name, fn, nbytes, flops in (
             ('fwd_edge', fwd, (2 * E + 2 * N) * R, 4 * L * L * D * E),
