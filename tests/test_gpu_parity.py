@@ -328,3 +328,50 @@ def test_split_precision_is_fp32_grade(dev):
         assert err['bf16x9'][k] <= 2.0 * err['exact'][k] + 1e-7
         assert err['bf16x6'][k] <= 4.0 * err['exact'][k] + 3e-7
         assert err['exact'][k] < 2e-5
+
+
+def _ddp_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)   # both ranks share cuda:0 here;
+    from ampnet_amd import AMPConv                                   # on the 8-GPU node: nccl = RCCL
+    from ampnet_amd.distributed import GradientAllReducer, broadcast_parameters
+    dev = torch.device('cuda:0')
+    torch.manual_seed(100 + rank)                                    # different init per rank ...
+    layer = AMPConv(128, 4).to(dev)
+    broadcast_parameters(layer, src=0)                               # ... made equal here
+    reducer = GradientAllReducer(layer.parameters())
+    opt = torch.optim.Adam(layer.parameters(), lr=1e-3)
+    g = torch.Generator().manual_seed(7 + rank)                      # one subgraph per rank
+    N, E, L = 300, 2500, 20
+    for step in range(2):
+        x = torch.randn(N, L * 128, generator=g).to(dev)
+        ei = torch.randint(0, N, (2, E), generator=g).to(dev)
+        opt.zero_grad()
+        layer(x, ei).pow(2).mean().backward()
+        if step == 0:
+            local = [p.grad.detach().cpu().clone() for p in layer.parameters()]
+        reducer.allreduce()
+        if step == 0:
+            avg = [p.grad.detach().cpu().clone() for p in layer.parameters()]
+        opt.step()
+    torch.save({'params': [p.detach().cpu() for p in layer.parameters()], 'local': local, 'avg': avg},
+               os.path.join(out_dir, f'r{rank}.pt'))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_step_two_ranks(dev, tmp_path):
+    """One-subgraph-per-rank data parallelism with the HIP layer (2 processes): averaged gradient
+    = mean of the per-rank gradients, identical parameters on both ranks after optimizer steps
+    (experiments/cora_benchmark_graphsaint_distributed.py:63-94 as intended)."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_ddp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r = [torch.load(os.path.join(tmp_path, f'r{i}.pt')) for i in range(2)]
+    for a, b in zip(r[0]['params'], r[1]['params']):
+        assert torch.equal(a, b)
+    for l0, l1, a0, a1 in zip(r[0]['local'], r[1]['local'], r[0]['avg'], r[1]['avg']):
+        torch.testing.assert_close(a0, (l0 + l1) / 2, rtol=1e-5, atol=1e-7)
+        assert torch.equal(a0, a1)
