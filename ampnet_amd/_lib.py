@@ -44,8 +44,8 @@ SIGNATURES = {
                                     View, View, _vp, _i64, _vp, _i32, _vp]),
     'ampconv_attn_weights': (_i32, [View, View, _vp, _i64, _i32, _i32, _i32, _vp, _i32, _vp]),
     'ampconv_segment_mean': (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _vp]),
-    'ampconv_mask_rows': (_i32, [_vp, _vp, _i64, _i64, _vp]),
-    'ampconv_masked_colsum': (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, _vp]),
+    'ampconv_mask_rows': (_i32, [_vp, _vp, _i64, _i64, _i32, _vp]),
+    'ampconv_masked_colsum': (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, _i32, _vp]),
 }
 
 _lib = None

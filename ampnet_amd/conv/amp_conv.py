@@ -75,8 +75,8 @@ class AMPConv(MessagePassing):
         if not x.is_cuda:
             raise ValueError('ampnet_amd.AMPConv runs on the GPU only (no CPU fallback): '
                              f'{name} is on {x.device}')
-        if x.dtype != torch.float32:
-            raise ValueError(f'{name} must be float32, got {x.dtype}')
+        if x.dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError(f'{name} must be float32 (or bfloat16 with a bfloat16 layer), got {x.dtype}')
         p = self.multi_head_attention.in_proj_weight
         if p.device != x.device:
             raise ValueError(f'parameters are on {p.device} but {name} is on {x.device}')
@@ -143,6 +143,10 @@ class AMPConv(MessagePassing):
 
     def _attn_views(self):
         q_buf, kv_buf, edge_index, L, shared = self._attn_ctx
+        if q_buf.dtype != torch.float32:              # side outputs are served in fp32
+            q_buf = q_buf.float()
+            kv_buf = None if kv_buf is None else kv_buf.float()
+            self._attn_ctx = (q_buf, kv_buf, edge_index, L, shared)
         D, dh = self.embed_dim, self.embed_dim // self.num_heads
         if shared:
             Qv, Kv, Vv = (F_._view(q_buf, i * D, L, dh) for i in range(3))
@@ -177,10 +181,11 @@ class AMPConv(MessagePassing):
             o = torch.empty(E * L, D, dtype=torch.float32, device=edge_index.device)
             with torch.cuda.device(edge_index.device):
                 F_.edge_forward(Qv, Kv, Vv, ident, E, L, D, H, o, qidx=qidx,
-                                dtype=_lib.PRECISIONS[self.precision])
+                                dtype=_lib.PRECISIONS[self.precision])   # fp32 views (see _attn_views)
             m = self.multi_head_attention
             with torch.no_grad():
-                self._attn_output = torch.addmm(m.out_proj.bias, o, m.out_proj.weight.t()).view(E, L, D)
+                self._attn_output = torch.addmm(m.out_proj.bias.float(), o,
+                                                m.out_proj.weight.float().t()).view(E, L, D)
         return self._attn_output
 
     @attn_output.setter

@@ -23,9 +23,9 @@ from ..graph import EdgeCSR, _stream
 
 def _view(buf2d, col_off, L, dh):
     """ampconv_view_t over columns [col_off, col_off + D) of a contiguous [rows*L, W] buffer."""
-    assert buf2d.is_contiguous() and buf2d.dtype == torch.float32
+    assert buf2d.is_contiguous() and buf2d.dtype in (torch.float32, torch.bfloat16)
     W = buf2d.size(1)
-    return _lib.View(buf2d.data_ptr() + 4 * col_off, L * W, W, dh)
+    return _lib.View(buf2d.data_ptr() + buf2d.element_size() * col_off, L * W, W, dh)
 
 
 def _ptr(t):
@@ -72,6 +72,10 @@ class AMPConvFunction(torch.autograd.Function):
         H = int(num_heads)
         dh = D // H
         L = xq.size(1) // D
+        if xq.dtype == torch.bfloat16:                   # bf16 storage: one mode only
+            dtype = _lib.AMPCONV_BF16
+            if w_in.dtype != torch.bfloat16:
+                raise ValueError('bf16 inputs need bf16 parameters: call layer.to(torch.bfloat16)')
         Nq, Nk = xq.size(0), xkv.size(0)
         xq2 = xq.contiguous().view(Nq * L, D)
         with torch.cuda.device(xq.device):
@@ -89,7 +93,8 @@ class AMPConvFunction(torch.autograd.Function):
             obar = torch.empty(Nq * L, D, dtype=xq.dtype, device=xq.device)
             edge_forward(Qv, Kv, Vv, csr, Nq, L, D, H, obar, dtype=dtype)
             y = torch.addmm(b_out, obar, w_out.t())
-            rc = lib.ampconv_mask_rows(y.data_ptr(), csr.rowptr.data_ptr(), Nq, L * D, _stream())
+            io = _lib.AMPCONV_BF16 if y.dtype == torch.bfloat16 else _lib.AMPCONV_F32
+            rc = lib.ampconv_mask_rows(y.data_ptr(), csr.rowptr.data_ptr(), Nq, L * D, io, _stream())
             _lib.check(rc, 'ampconv_mask_rows')
         ctx.set_materialize_grads(False)     # no zero-filled [N*L, 3D] gradient for the qkv side output
         ctx.save_for_backward(xq2, xkv2, w_in, w_out, qkv, kv, obar)
@@ -115,21 +120,22 @@ class AMPConvFunction(torch.autograd.Function):
             # out-projection: rows with no in-edge contribute nothing (their obar is 0, and
             # the bias gradient masks them explicitly)
             scratch = torch.empty((1 + _lib.COLSUM_BLOCKS) * D, dtype=torch.float32, device=dev)
+            io = _lib.AMPCONV_BF16 if dy2.dtype == torch.bfloat16 else _lib.AMPCONV_F32
             rc = lib.ampconv_masked_colsum(dy2.data_ptr(), csr.rowptr.data_ptr(), Nq, L, D,
-                                           scratch.data_ptr(), _stream())
+                                           scratch.data_ptr(), io, _stream())
             _lib.check(rc, 'ampconv_masked_colsum')
-            db_out = scratch[:D].clone()
+            db_out = scratch[:D].to(dy2.dtype)
             dw_out = _tn_matmul(dy2, obar)
             dobar = dy2.mm(w_out)                                          # [Nq*L, D]
             dOv = _view(dobar, 0, L, dh)
             if shared:
-                dqkv = torch.empty(Nq * L, 3 * D, dtype=torch.float32, device=dev)
+                dqkv = torch.empty(Nq * L, 3 * D, dtype=dy2.dtype, device=dev)
                 Qv, Kv, Vv = (_view(qkv, i * D, L, dh) for i in range(3))
                 dQv, dKv, dVv = (_view(dqkv, i * D, L, dh) for i in range(3))
                 dkv = None
             else:
-                dqkv = torch.empty(Nq * L, D, dtype=torch.float32, device=dev)
-                dkv = torch.empty(Nk * L, 2 * D, dtype=torch.float32, device=dev)
+                dqkv = torch.empty(Nq * L, D, dtype=dy2.dtype, device=dev)
+                dkv = torch.empty(Nk * L, 2 * D, dtype=dy2.dtype, device=dev)
                 Qv, Kv, Vv = _view(qkv, 0, L, dh), _view(kv, 0, L, dh), _view(kv, D, L, dh)
                 dQv, dKv, dVv = _view(dqkv, 0, L, dh), _view(dkv, 0, L, dh), _view(dkv, D, L, dh)
             plan, nch, ws = csr.hub_args('dst', L, D, 1)

@@ -111,5 +111,18 @@ int ampconv_bwd_edge_src_split(int nprod, ampconv_view_t Q, ampconv_view_t K, am
 
 // hub.hip
 int ampconv_hub_combine(const void *plan, int64_t n_chunks, const float *P, ampconv_view_t out,
-                        const int32_t *ptr_for_mean, int L, int D, int H, float scale,
+                        const int32_t *ptr_for_mean, int L, int D, int H, float scale, int out_bf16,
                         hipStream_t stream);
+
+// ---- bf16-storage path (edge_mfma_bf16.hip): L <= 20, dh == 32, 16-byte aligned bf16 views
+bool ampconv_bf16_supported(int L, int D, int H, const ampconv_view_t *views, int n);
+int ampconv_fwd_edge_bf16(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V, const int32_t *rowptr,
+                          const int32_t *col, const int32_t *qidx, int64_t n_rows, int L, int D, int H,
+                          ampconv_view_t O, HubArgs hub, hipStream_t stream);
+int ampconv_bwd_edge_dst_bf16(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V, ampconv_view_t dO,
+                              const int32_t *rowptr, const int32_t *col, int64_t n_rows, int L, int D,
+                              int H, ampconv_view_t dQ, HubArgs hub, hipStream_t stream);
+int ampconv_bwd_edge_src_bf16(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V, ampconv_view_t dO,
+                              const int32_t *cscptr, const int32_t *crow, const float *cinv,
+                              int64_t n_src, int L, int D, int H, ampconv_view_t dK, ampconv_view_t dV,
+                              HubArgs hub, hipStream_t stream);

@@ -12,7 +12,7 @@ bool force_generic() {
 }
 int check_common(int L, int D, int H, int dtype) {
   if (dtype != AMPCONV_F32 && dtype != AMPCONV_F32_EXACT && dtype != AMPCONV_F32_BF16X9 &&
-      dtype != AMPCONV_F32_BF16X6)
+      dtype != AMPCONV_F32_BF16X6 && dtype != AMPCONV_BF16)
     return AMPCONV_E_DTYPE;
   if (L <= 0 || D <= 0 || H <= 0 || D % H != 0) return AMPCONV_E_BADARG;
   return AMPCONV_OK;
@@ -60,6 +60,21 @@ extern "C" int ampconv_fwd_edge(ampconv_view_t Q, ampconv_view_t K, ampconv_view
   if (n_rows == 0) return AMPCONV_OK;
   if (!view_ok(Q) || !view_ok(K) || !view_ok(V) || !view_ok(O) || !rowptr) return AMPCONV_E_BADARG;
   const ampconv_view_t views[] = {Q, K, V, O};
+  if (dtype == AMPCONV_BF16) {
+    if (!ampconv_bf16_supported(L, D, H, views, 4)) return AMPCONV_E_DTYPE;
+    hipStream_t st = (hipStream_t)stream;
+    if (hub_plan && hub_chunks > 0 && hub_ws && !qidx) {
+      if (int rc = ampconv_fwd_edge_bf16(Q, K, V, rowptr, col, nullptr, n_rows, L, D, H, O,
+                                         hub_args(hub_plan, 1), st))
+        return rc;
+      ampconv_view_t P = partial_view(hub_ws, 0, hub_chunks, L, D, H);
+      if (int rc = ampconv_fwd_edge_bf16(Q, K, V, rowptr, col, nullptr, hub_chunks, L, D, H, P,
+                                         hub_args(hub_plan, 2), st))
+        return rc;
+      return ampconv_hub_combine(hub_plan, hub_chunks, (const float *)P.ptr, O, rowptr, L, D, H, 1.f, 1, st);
+    }
+    return ampconv_fwd_edge_bf16(Q, K, V, rowptr, col, qidx, n_rows, L, D, H, O, HubArgs{nullptr, 0}, st);
+  }
   if (!force_generic() && ampconv_mfma_supported(L, D, H) && ampconv_mfma_views_ok(views, 4)) {
     if (const int np = split_products(dtype, L, D, H))
       return ampconv_fwd_edge_split(np, Q, K, V, rowptr, col, qidx, n_rows, L, D, H, O,
@@ -73,7 +88,7 @@ extern "C" int ampconv_fwd_edge(ampconv_view_t Q, ampconv_view_t K, ampconv_view
       if (int rc = ampconv_fwd_edge_mfma(Q, K, V, rowptr, col, nullptr, hub_chunks, L, D, H, P, hh,
                                          (hipStream_t)stream))
         return rc;
-      return ampconv_hub_combine(hub_plan, hub_chunks, (const float *)P.ptr, O, rowptr, L, D, H, 1.f,
+      return ampconv_hub_combine(hub_plan, hub_chunks, (const float *)P.ptr, O, rowptr, L, D, H, 1.f, 0,
                                  (hipStream_t)stream);
     }
     return ampconv_fwd_edge_mfma(Q, K, V, rowptr, col, qidx, n_rows, L, D, H, O, HubArgs{nullptr, 0},
@@ -94,6 +109,22 @@ extern "C" int ampconv_bwd_edge_dst(ampconv_view_t Q, ampconv_view_t K, ampconv_
   if (!view_ok(Q) || !view_ok(K) || !view_ok(V) || !view_ok(dObar) || !view_ok(dQ) || !rowptr)
     return AMPCONV_E_BADARG;
   const ampconv_view_t views[] = {Q, K, V, dObar, dQ};
+  if (dtype == AMPCONV_BF16) {
+    if (!ampconv_bf16_supported(L, D, H, views, 5)) return AMPCONV_E_DTYPE;
+    hipStream_t st = (hipStream_t)stream;
+    if (hub_plan && hub_chunks > 0 && hub_ws) {
+      if (int rc = ampconv_bwd_edge_dst_bf16(Q, K, V, dObar, rowptr, col, n_rows, L, D, H, dQ,
+                                             hub_args(hub_plan, 1), st))
+        return rc;
+      ampconv_view_t P = partial_view(hub_ws, 0, hub_chunks, L, D, H);
+      if (int rc = ampconv_bwd_edge_dst_bf16(Q, K, V, dObar, rowptr, col, hub_chunks, L, D, H, P,
+                                             hub_args(hub_plan, 2), st))
+        return rc;
+      return ampconv_hub_combine(hub_plan, hub_chunks, (const float *)P.ptr, dQ, nullptr, L, D, H,
+                                 1.f / sqrtf((float)(D / H)), 1, st);
+    }
+    return ampconv_bwd_edge_dst_bf16(Q, K, V, dObar, rowptr, col, n_rows, L, D, H, dQ, HubArgs{nullptr, 0}, st);
+  }
   if (!force_generic() && ampconv_mfma_supported(L, D, H) && ampconv_mfma_views_ok(views, 5)) {
     if (const int np = split_products(dtype, L, D, H))
       return ampconv_bwd_edge_dst_split(np, Q, K, V, dObar, rowptr, col, n_rows, L, D, H, dQ,
@@ -108,7 +139,7 @@ extern "C" int ampconv_bwd_edge_dst(ampconv_view_t Q, ampconv_view_t K, ampconv_
                                              (hipStream_t)stream))
         return rc;
       return ampconv_hub_combine(hub_plan, hub_chunks, (const float *)P.ptr, dQ, nullptr, L, D, H,
-                                 1.f / sqrtf((float)(D / H)), (hipStream_t)stream);
+                                 1.f / sqrtf((float)(D / H)), 0, (hipStream_t)stream);
     }
     return ampconv_bwd_edge_dst_mfma(Q, K, V, dObar, rowptr, col, n_rows, L, D, H, dQ,
                                      HubArgs{nullptr, 0}, (hipStream_t)stream);
@@ -130,6 +161,26 @@ extern "C" int ampconv_bwd_edge_src(ampconv_view_t Q, ampconv_view_t K, ampconv_
       !view_ok(dV) || !cscptr || !cinv)
     return AMPCONV_E_BADARG;
   const ampconv_view_t views[] = {Q, K, V, dObar, dK, dV};
+  if (dtype == AMPCONV_BF16) {
+    if (!ampconv_bf16_supported(L, D, H, views, 6)) return AMPCONV_E_DTYPE;
+    hipStream_t st = (hipStream_t)stream;
+    if (hub_plan && hub_chunks > 0 && hub_ws) {
+      if (int rc = ampconv_bwd_edge_src_bf16(Q, K, V, dObar, cscptr, crow, cinv, n_src, L, D, H, dK, dV,
+                                             hub_args(hub_plan, 1), st))
+        return rc;
+      ampconv_view_t PK = partial_view(hub_ws, 0, hub_chunks, L, D, H);
+      ampconv_view_t PV = partial_view(hub_ws, 1, hub_chunks, L, D, H);
+      if (int rc = ampconv_bwd_edge_src_bf16(Q, K, V, dObar, cscptr, crow, cinv, hub_chunks, L, D, H, PK,
+                                             PV, hub_args(hub_plan, 2), st))
+        return rc;
+      if (int rc = ampconv_hub_combine(hub_plan, hub_chunks, (const float *)PK.ptr, dK, nullptr, L, D, H,
+                                       1.f / sqrtf((float)(D / H)), 1, st))
+        return rc;
+      return ampconv_hub_combine(hub_plan, hub_chunks, (const float *)PV.ptr, dV, nullptr, L, D, H, 1.f, 1, st);
+    }
+    return ampconv_bwd_edge_src_bf16(Q, K, V, dObar, cscptr, crow, cinv, n_src, L, D, H, dK, dV,
+                                     HubArgs{nullptr, 0}, st);
+  }
   if (!force_generic() && ampconv_mfma_supported(L, D, H) && ampconv_mfma_views_ok(views, 6)) {
     if (const int np = split_products(dtype, L, D, H))
       return ampconv_bwd_edge_src_split(np, Q, K, V, dObar, cscptr, crow, cinv, n_src, L, D, H,
@@ -145,9 +196,9 @@ extern "C" int ampconv_bwd_edge_src(ampconv_view_t Q, ampconv_view_t K, ampconv_
                                              PV, hh, (hipStream_t)stream))
         return rc;
       if (int rc = ampconv_hub_combine(hub_plan, hub_chunks, (const float *)PK.ptr, dK, nullptr, L, D, H,
-                                       0.6931471805599453f, (hipStream_t)stream))
+                                       0.6931471805599453f, 0, (hipStream_t)stream))
         return rc;
-      return ampconv_hub_combine(hub_plan, hub_chunks, (const float *)PV.ptr, dV, nullptr, L, D, H, 1.f,
+      return ampconv_hub_combine(hub_plan, hub_chunks, (const float *)PV.ptr, dV, nullptr, L, D, H, 1.f, 0,
                                  (hipStream_t)stream);
     }
     return ampconv_bwd_edge_src_mfma(Q, K, V, dObar, cscptr, crow, cinv, n_src, L, D, H, dK, dV,

@@ -25,18 +25,22 @@ __global__ void hub_plan_kernel(const int32_t *__restrict__ ptr, int64_t N, int 
 // out[row] = scale * sum_{k < n} P[c + k]   (chunk order), one block per first chunk
 __global__ void hub_combine_kernel(const HubDesc *__restrict__ descs, const float *__restrict__ P,
                                    ampconv_view_t out, const int32_t *__restrict__ ptr, int L, int D,
-                                   int dh, float scale) {
+                                   int dh, float scale, int out_bf16) {
   const int64_t c = blockIdx.x;
   const HubDesc d = descs[c];
   if (d.nfirst == 0) return;
   const int64_t LD = (int64_t)L * D;
   const float sc = ptr ? 1.f / (float)(ptr[d.row + 1] - ptr[d.row]) : scale;   // forward: the mean
-  float *o = reinterpret_cast<float *>(out.ptr) + (int64_t)d.row * out.node_stride;
+  const int64_t base = (int64_t)d.row * out.node_stride;
   for (int64_t e = threadIdx.x; e < LD; e += blockDim.x) {
     float acc = 0.f;
     for (int k = 0; k < d.nfirst; ++k) acc += P[(c + k) * LD + e];
     const int l = (int)(e / D), cc = (int)(e - (int64_t)l * D);
-    o[(int64_t)l * out.row_stride + (int64_t)(cc / dh) * out.head_stride + cc % dh] = acc * sc;
+    const int64_t off = base + (int64_t)l * out.row_stride + (int64_t)(cc / dh) * out.head_stride + cc % dh;
+    if (out_bf16)
+      reinterpret_cast<__bf16 *>(out.ptr)[off] = (__bf16)(acc * sc);
+    else
+      reinterpret_cast<float *>(out.ptr)[off] = acc * sc;
   }
 }
 
@@ -65,11 +69,11 @@ extern "C" size_t ampconv_hub_workspace_bytes(int64_t n_chunks, int L, int D, in
 }
 
 int ampconv_hub_combine(const void *plan, int64_t n_chunks, const float *P, ampconv_view_t out,
-                        const int32_t *ptr_for_mean, int L, int D, int H, float scale,
+                        const int32_t *ptr_for_mean, int L, int D, int H, float scale, int out_bf16,
                         hipStream_t stream) {
   if (n_chunks <= 0) return AMPCONV_OK;
   const HubDesc *descs = (const HubDesc *)((const int32_t *)plan + 4);
   hub_combine_kernel<<<(unsigned)n_chunks, 256, 0, stream>>>(descs, P, out, ptr_for_mean, L, D, D / H,
-                                                            scale);
+                                                            scale, out_bf16);
   return ampconv_launch_status();
 }

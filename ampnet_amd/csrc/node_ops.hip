@@ -22,15 +22,17 @@ __global__ void segment_mean_kernel(const float *__restrict__ msg,
   }
 }
 
-__global__ void mask_rows_kernel(float *__restrict__ Y, const int32_t *__restrict__ rowptr,
-                                 int64_t N, int64_t F) {
+template <typename T>
+__global__ void mask_rows_kernel(T *__restrict__ Y, const int32_t *__restrict__ rowptr, int64_t N,
+                                 int64_t F) {
   const int64_t n = blockIdx.x;
   if (rowptr[n + 1] != rowptr[n]) return;
-  for (int64_t f = threadIdx.x; f < F; f += blockDim.x) Y[n * F + f] = 0.f;
+  for (int64_t f = threadIdx.x; f < F; f += blockDim.x) Y[n * F + f] = (T)0.f;
 }
 
 // partial[b, c] = sum over rows n in block b's slice with deg>0, tokens l of dY[n, l, c]
-__global__ void masked_colsum_partial(const float *__restrict__ dY,
+template <typename T>
+__global__ void masked_colsum_partial(const T *__restrict__ dY,
                                       const int32_t *__restrict__ rowptr, int64_t N, int L, int D,
                                       int64_t rows_per_block, float *__restrict__ partial) {
   const int64_t n0 = (int64_t)blockIdx.x * rows_per_block;
@@ -39,8 +41,8 @@ __global__ void masked_colsum_partial(const float *__restrict__ dY,
     float acc = 0.f;
     for (int64_t n = n0; n < n1; ++n) {
       if (rowptr[n + 1] == rowptr[n]) continue;
-      const float *row = dY + n * (int64_t)L * D + c;
-      for (int l = 0; l < L; ++l) acc += row[(int64_t)l * D];
+      const T *row = dY + n * (int64_t)L * D + c;
+      for (int l = 0; l < L; ++l) acc += (float)row[(int64_t)l * D];
     }
     partial[(int64_t)blockIdx.x * D + c] = acc;
   }
@@ -66,20 +68,23 @@ extern "C" int ampconv_segment_mean(const float *msg, const int32_t *rowptr, con
   return ampconv_launch_status();
 }
 
-extern "C" int ampconv_mask_rows(float *Y, const int32_t *rowptr, int64_t N, int64_t F,
+extern "C" int ampconv_mask_rows(void *Y, const int32_t *rowptr, int64_t N, int64_t F, int dtype,
                                  void *stream) {
   if (N < 0 || F < 0 || N > INT32_MAX) return AMPCONV_E_BADARG;
   if (N == 0 || F == 0) return AMPCONV_OK;
   if (!Y || !rowptr) return AMPCONV_E_BADARG;
-  mask_rows_kernel<<<(unsigned)N, 256, 0, (hipStream_t)stream>>>(Y, rowptr, N, F);
+  if (dtype == AMPCONV_BF16)
+    mask_rows_kernel<<<(unsigned)N, 256, 0, (hipStream_t)stream>>>((__bf16 *)Y, rowptr, N, F);
+  else
+    mask_rows_kernel<<<(unsigned)N, 256, 0, (hipStream_t)stream>>>((float *)Y, rowptr, N, F);
   return ampconv_launch_status();
 }
 
 // `out` must have room for D floats followed by a scratch area of
 // AMPCONV_COLSUM_BLOCKS * D floats (see ampnet_amd/_lib.py); the two-step sum is
 // deterministic (fixed block slices, fixed order).
-extern "C" int ampconv_masked_colsum(const float *dY, const int32_t *rowptr, int64_t N, int L,
-                                     int D, float *out, void *stream) {
+extern "C" int ampconv_masked_colsum(const void *dY, const int32_t *rowptr, int64_t N, int L,
+                                     int D, float *out, int dtype, void *stream) {
   if (N < 0 || L <= 0 || D <= 0) return AMPCONV_E_BADARG;
   if (!out) return AMPCONV_E_BADARG;
   const int nblocks = 1024;
@@ -91,7 +96,12 @@ extern "C" int ampconv_masked_colsum(const float *dY, const int32_t *rowptr, int
   if (!dY || !rowptr) return AMPCONV_E_BADARG;
   const int64_t rpb = (N + nblocks - 1) / nblocks;
   const int used = (int)((N + rpb - 1) / rpb);
-  masked_colsum_partial<<<used, 256, 0, (hipStream_t)stream>>>(dY, rowptr, N, L, D, rpb, partial);
+  if (dtype == AMPCONV_BF16)
+    masked_colsum_partial<<<used, 256, 0, (hipStream_t)stream>>>((const __bf16 *)dY, rowptr, N, L, D, rpb,
+                                                               partial);
+  else
+    masked_colsum_partial<<<used, 256, 0, (hipStream_t)stream>>>((const float *)dY, rowptr, N, L, D, rpb,
+                                                               partial);
   colsum_final<<<(D + 255) / 256, 256, 0, (hipStream_t)stream>>>(partial, used, D, out);
   return ampconv_launch_status();
 }

@@ -37,7 +37,7 @@ class GradientAllReducer:
 
     def _buffer(self, like):
         if self._flat is None or self._flat.device != like.device:
-            self._flat = torch.empty(self.numel, dtype=torch.float32, device=like.device)
+            self._flat = torch.empty(self.numel, dtype=torch.float32, device=like.device)   # fp32 sum
         return self._flat
 
     def allreduce(self):
@@ -61,7 +61,7 @@ class GradientAllReducer:
             n = p.numel()
             g = flat[off:off + n].view_as(p)
             if p.grad is None:
-                p.grad = g.clone()
+                p.grad = g.to(p.dtype).clone()
             else:
                 p.grad.copy_(g)
             off += n

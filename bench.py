@@ -36,6 +36,9 @@ WORKLOADS = {
              'BASELINE config 4: uniform random graph 1M nodes / 10M edges, L=20, D=256, H=8'),
     'cfg3': (100_000, 1_000_000, 20, 128, 8,
              'BASELINE config 3: uniform random graph 100k nodes / 1M edges, L=20, D=128, H=8'),
+    'cfg5': (1 << 21, 40_000_000, 20, 256, 8,
+             'BASELINE config 5: RMAT (0.57,0.19,0.19,0.05) scale 21 = 2.1M nodes / 40M edges, L=20, D=256, H=8, '
+             'bf16 storage'),
     'cora': (2708, 10556, 20, 128, 4, 'BASELINE config 1/2 shape: Cora-sized random graph, L=20, D=128, H=4'),
     'tiny': (2000, 20000, 20, 256, 8, 'smoke-sized graph of the config-4 layer shape'),
 }
@@ -79,11 +82,29 @@ class TimedLib:
         return getattr(self._lib, name)
 
 
-def make_batch(N, E, L, D, seed, dev):
+def rmat_edges(scale, E, gen, dev, a=0.57, b=0.19, c=0.19):
+    """R-MAT edge list (no de-duplication): per bit one quadrant draw with probabilities a, b, c, d."""
+    src = torch.zeros(E, dtype=torch.int64, device=dev)
+    dst = torch.zeros(E, dtype=torch.int64, device=dev)
+    for _ in range(scale):
+        r = torch.rand(E, generator=gen, device=dev)
+        src = src * 2 + (r >= a + b).to(torch.int64)
+        dst = dst * 2 + (((r >= a) & (r < a + b)) | (r >= a + b + c)).to(torch.int64)
+    return torch.stack([src, dst])
+
+
+def make_batch(N, E, L, D, seed, dev, dtype=torch.float32, rmat=False):
     g = torch.Generator(device=dev).manual_seed(seed)
-    x = torch.randn(N, L * D, generator=g, device=dev, dtype=torch.float32)
-    ei = torch.randint(0, N, (2, E), generator=g, device=dev, dtype=torch.int64)
-    dy = torch.randn(N, L * D, generator=g, device=dev, dtype=torch.float32)
+    x = torch.empty(N, L * D, device=dev, dtype=dtype)
+    dy = torch.empty(N, L * D, device=dev, dtype=dtype)
+    rows = max(1, (1 << 28) // (L * D))                      # fill in slabs: no full-size fp32 temporary
+    for t in (x, dy):
+        for r0 in range(0, N, rows):
+            t[r0:r0 + rows] = torch.randn(min(rows, N - r0), L * D, generator=g, device=dev).to(dtype)
+    if rmat:
+        ei = rmat_edges(N.bit_length() - 1, E, g, dev)
+    else:
+        ei = torch.randint(0, N, (2, E), generator=g, device=dev, dtype=torch.int64)
     return x, ei, dy
 
 
@@ -138,6 +159,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--workload', default=os.environ.get('AMPCONV_BENCH_WORKLOAD', 'cfg4'))
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--dtype', default=None, choices=['f32', 'bf16'],
+                    help='storage dtype (default: f32; bf16 for cfg5)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -156,18 +179,21 @@ def main():
     from ampnet_amd.distributed import GradientAllReducer, broadcast_parameters
 
     N, E, L, D, H, desc = WORKLOADS[args.workload]
-    R = L * D * 4
+    dt_name = args.dtype or ('bf16' if args.workload == 'cfg5' else 'f32')
+    tdt = torch.bfloat16 if dt_name == 'bf16' else torch.float32
+    R = L * D * (2 if dt_name == 'bf16' else 4)
     torch.manual_seed(1)
     layer = AMPConv(D, H).to(dev)
     layer.retain_attention = False                            # no [E, L, L] side output kept alive
     with torch.no_grad():
         layer.multi_head_attention.in_proj_bias.normal_(0, 0.1)
         layer.multi_head_attention.out_proj.bias.normal_(0, 0.1)
+    layer = layer.to(tdt)
     if world > 1:
         broadcast_parameters(layer, src=0)
     reducer = GradientAllReducer(layer.parameters())
 
-    x, ei, dy = make_batch(N, E, L, D, 1234 + rank, dev)      # each rank: its own graph
+    x, ei, dy = make_batch(N, E, L, D, 1234 + rank, dev, tdt, rmat=args.workload == 'cfg5')   # own graph per rank
     x.requires_grad_(True)
 
     timer = KernelTimer()
@@ -219,7 +245,7 @@ def main():
         traffic = None                                         # PMC-measured HBM bytes per launch
         try:                                                   # (profiles/pmc_traffic.json, same workload)
             pmc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
-            if pmc.get('workload') == args.workload:
+            if pmc.get('workload') == args.workload and dt_name == 'f32':
                 traffic = pmc['kernels'][dom]['traffic_bytes']
         except (OSError, KeyError, ValueError):
             pass
@@ -227,7 +253,7 @@ def main():
             'metric': 'AMPConv edges/sec (fwd+bwd)', 'value': value, 'unit': 'edges/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': dt_name, 'data': 'synthetic',
             'config': {'workload': f'{args.workload}: {desc}, one AMPConv layer fwd+bwd incl. CSR build, '
                                    f'one graph per GPU' + (' + RCCL grad all-reduce' if world > 1 else ''),
                        'N': N, 'E': E, 'L': L, 'D': D, 'H': H, 'parallelism': f'dp{world}'},

@@ -40,7 +40,9 @@ enum {
   AMPCONV_E_WORKSPACE = -3 /* workspace too small */
 };
 
-/* dtype codes.  All AMPCONV_F32* codes take and return fp32 tensors; they differ in how the
+/* dtype codes.  AMPCONV_BF16: every view is bf16 in HBM (Q/K/V/O and gradients), products on the
+ * bf16 MFMA with fp32 accumulation, fp32 softmax (L <= 20, dh = 32 only; BASELINE config 5).
+ * All AMPCONV_F32* codes take and return fp32 tensors; they differ in how the
  * per-edge products are evaluated on the matrix cores:
  *   AMPCONV_F32_EXACT   v_mfma_f32_16x16x4_f32 (native fp32 MFMA, 1/16 of the bf16 rate)
  *   AMPCONV_F32_BF16X9  every fp32 operand split EXACTLY into 3 bf16 terms, all 9 partial
@@ -148,14 +150,15 @@ int ampconv_attn_weights(ampconv_view_t Q, ampconv_view_t K,
  * mask_rows: zero, in place, the rows of Y[N, F] whose CSR segment is empty
  * (out-projection bias must not leak into nodes nobody sends to).
  * masked_colsum: out[f] = sum over rows with a non-empty segment of dY[n, f],
- * folded over the L tokens: out has D entries (out_proj.bias gradient).  */
+ * folded over the L tokens: out has D fp32 entries (out_proj.bias gradient).
+ * `dtype` of Y / dY: AMPCONV_F32 or AMPCONV_BF16.  */
 int ampconv_segment_mean(const float *msg, const int32_t *rowptr,
                          const int32_t *eperm, int64_t N, int64_t F, float *out,
                          void *stream);
-int ampconv_mask_rows(float *Y, const int32_t *rowptr, int64_t N, int64_t F,
-                      void *stream);
-int ampconv_masked_colsum(const float *dY, const int32_t *rowptr, int64_t N,
-                          int L, int D, float *out, void *stream);
+int ampconv_mask_rows(void *Y, const int32_t *rowptr, int64_t N, int64_t F,
+                      int dtype, void *stream);
+int ampconv_masked_colsum(const void *dY, const int32_t *rowptr, int64_t N,
+                          int L, int D, float *out, int dtype, void *stream);
 
 #ifdef __cplusplus
 }

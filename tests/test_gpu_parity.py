@@ -375,3 +375,44 @@ def test_data_parallel_step_two_ranks(dev, tmp_path):
     for l0, l1, a0, a1 in zip(r[0]['local'], r[1]['local'], r[0]['avg'], r[1]['avg']):
         torch.testing.assert_close(a0, (l0 + l1) / 2, rtol=1e-5, atol=1e-7)
         assert torch.equal(a0, a1)
+
+
+@pytest.mark.parametrize('shape', [(1200, 12000, 20, 256, 8), (700, 5000, 13, 64, 2)], ids=['L20_D256', 'L13_D64'])
+def test_bf16_storage(shape, dev):
+    """bf16-storage mode (BASELINE config 5: Q/K/V/O and gradients in bf16, fp32 accumulate)
+    against the fp64 oracle evaluated on the same bf16-rounded inputs and parameters.
+    Tolerance: rtol 2e-2, atol 2e-2 of the tensor's scale."""
+    from ampnet_amd import AMPConv
+    from oracle.ampconv_numpy import AMPConvOracle
+    N, E, L, D, H = shape
+    torch.manual_seed(41)
+    layer = AMPConv(D, H)
+    with torch.no_grad():
+        layer.multi_head_attention.in_proj_bias.normal_(0, 0.1)
+        layer.multi_head_attention.out_proj.bias.normal_(0, 0.1)
+    layer = layer.to(dev).to(torch.bfloat16)
+    g = torch.Generator().manual_seed(42)
+    x = torch.randn(N, L * D, generator=g).to(torch.bfloat16)
+    dy = torch.randn(N, L * D, generator=g).to(torch.bfloat16)
+    ei = torch.randint(0, N - 20, (2, E), generator=g)
+    ei[1, : E // 10] = 3                                     # dst hub (long CSR segment)
+    ei[0, E // 10: E // 5] = 7                               # src hub (long CSC segment)
+    xg = x.to(dev).requires_grad_(True)
+    y = layer(xg, ei.to(dev))
+    assert y.dtype == torch.bfloat16
+    y.backward(dy.to(dev))
+    m = layer.multi_head_attention
+    f64 = lambda t: t.detach().float().cpu().numpy().astype(np.float64)
+    o = AMPConvOracle(f64(m.in_proj_weight), f64(m.in_proj_bias), f64(m.out_proj.weight), f64(m.out_proj.bias),
+                      H, dtype=np.float64, edge_chunk=2048)
+    y_ref, w_ref = o.forward(f64(x), ei.numpy(), need_weights=True)
+    dx_ref, dWin, dbin, dWo, dbo = o.backward(f64(dy))
+    assert_close_scaled(f64(y), y_ref, 'y', atol=2e-2, rtol=2e-2)
+    assert (f64(y)[N - 20:] == 0).all()
+    assert_close_scaled(f64(xg.grad), dx_ref, 'dx', atol=2e-2, rtol=2e-2)
+    assert_close_scaled(f64(m.in_proj_weight.grad), dWin, 'g_in_proj_weight', atol=2e-2, rtol=2e-2)
+    assert_close_scaled(f64(m.in_proj_bias.grad), dbin, 'g_in_proj_bias', atol=2e-2, rtol=2e-2)
+    assert_close_scaled(f64(m.out_proj.weight.grad), dWo, 'g_out_proj_weight', atol=2e-2, rtol=2e-2)
+    assert_close_scaled(f64(m.out_proj.bias.grad), dbo, 'g_out_proj_bias', atol=2e-2, rtol=2e-2)
+    w = layer.attn_output_weights.cpu().numpy()
+    assert_close_scaled(w, w_ref, 'attn_output_weights', atol=2e-2, rtol=2e-2)

@@ -41,8 +41,11 @@ def main():
     lib = _lib.load()
     dh = D // H
     torch.manual_seed(0)
-    qkv = torch.randn(N * L, 3 * D, device=dev)
-    dobar = torch.randn(N * L, D, device=dev)
+    tdt = torch.bfloat16 if '--bf16' in sys.argv else torch.float32
+    if tdt == torch.bfloat16:
+        dt = _lib.AMPCONV_BF16
+    qkv = torch.randn(N * L, 3 * D, device=dev).to(tdt)
+    dobar = torch.randn(N * L, D, device=dev).to(tdt)
     ei = torch.randint(0, N, (2, E), device=dev)
     if '--hub' in sys.argv:                       # 5 % of the edges end at node 3, 5 % start at node 5
         ei[1, : E // 20] = 3
@@ -53,12 +56,12 @@ def main():
     print(f'mode={dt} N={N} E={E} L={L} D={D} H={H}  csr build (cold) {1e3 * (time.time() - t0):.1f} ms')
     print(f'csr build {timeit(lambda: EdgeCSR(ei, N, validate=False)):.3f} ms')
     Qv, Kv, Vv = (F_._view(qkv, i * D, L, dh) for i in range(3))
-    obar = torch.empty(N * L, D, device=dev)
-    dqkv = torch.empty(N * L, 3 * D, device=dev)
+    obar = torch.empty(N * L, D, device=dev, dtype=tdt)
+    dqkv = torch.empty(N * L, 3 * D, device=dev, dtype=tdt)
     dQv, dKv, dVv = (F_._view(dqkv, i * D, L, dh) for i in range(3))
     dOv = F_._view(dobar, 0, L, dh)
     st = torch.cuda.current_stream().cuda_stream
-    R = L * D * 4
+    R = L * D * qkv.element_size()
 
     keep = {}
 
