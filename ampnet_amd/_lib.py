@@ -16,7 +16,7 @@ AMPCONV_F32_BF16X9 = 3     # fp32 operands split exactly into 3 bf16, 9 partial 
 AMPCONV_F32_BF16X6 = 4     # ... 6 partial products
 PRECISIONS = {'default': AMPCONV_F32, 'exact': AMPCONV_F32_EXACT, 'bf16x9': AMPCONV_F32_BF16X9,
               'bf16x6': AMPCONV_F32_BF16X6}
-HUB_CHUNK = 256            # edges per chunk of a long CSR/CSC segment (include/ampconv.h, long segments)
+HUB_CHUNK = int(os.environ.get('AMPCONV_HUB_CHUNK', 64))   # edges per chunk of a long CSR/CSC segment (include/ampconv.h, long segments)
 COLSUM_BLOCKS = 1024      # scratch blocks of ampconv_masked_colsum (csrc/node_ops.hip)
 
 
