@@ -416,3 +416,47 @@ def test_bf16_storage(shape, dev):
     assert_close_scaled(f64(m.out_proj.bias.grad), dbo, 'g_out_proj_bias', atol=2e-2, rtol=2e-2)
     w = layer.attn_output_weights.cpu().numpy()
     assert_close_scaled(w, w_ref, 'attn_output_weights', atol=2e-2, rtol=2e-2)
+
+
+def test_training_steps_match_cpu_reference(dev):
+    """Three SGD steps of a 2-layer conv -> ReLU -> conv -> ReLU -> token-mean -> Linear model
+    (the AMPGCN call pattern, src/ampnet/module/amp_gcn.py:248-274) on the GPU path and on the
+    reference-shaped CPU restatement, same initial parameters and batches: losses and final
+    parameters must track each other."""
+    from ampnet_amd import AMPConv
+    from oracle.ampconv_torch import RefShapedAMPConv
+    N, E, L, D, H, C = 300, 2400, 20, 128, 4, 7
+
+    class Net(torch.nn.Module):
+        def __init__(self, conv_cls):
+            super().__init__()
+            self.conv1, self.conv2 = conv_cls(D, H), conv_cls(D, H)
+            self.out = torch.nn.Linear(D, C)
+
+        def forward(self, x, ei):
+            x = torch.relu(self.conv1(x, ei))
+            x = torch.relu(self.conv2(x, ei))
+            return torch.log_softmax(self.out(x.reshape(x.shape[0], L, D).mean(dim=1)), dim=1)
+
+    torch.manual_seed(3)
+    ref = Net(RefShapedAMPConv)
+    gpu = Net(AMPConv)
+    gpu.load_state_dict(ref.state_dict())            # identical state-dict keys
+    gpu = gpu.to(dev)
+    # plain SGD: parameter differences stay proportional to gradient differences (Adam turns
+    # round-off-level gradients into +-lr steps, which is not a property of the layer)
+    opt_r = torch.optim.SGD(ref.parameters(), lr=0.5)
+    opt_g = torch.optim.SGD(gpu.parameters(), lr=0.5)
+    g = torch.Generator().manual_seed(4)
+    for step in range(3):
+        x = torch.randn(N, L * D, generator=g)
+        ei = torch.randint(0, N, (2, E), generator=g)
+        yl = torch.randint(0, C, (N,), generator=g)
+        opt_r.zero_grad(); opt_g.zero_grad()
+        loss_r = torch.nn.functional.nll_loss(ref(x, ei), yl)
+        loss_g = torch.nn.functional.nll_loss(gpu(x.to(dev), ei.to(dev)), yl.to(dev))
+        loss_r.backward(); loss_g.backward()
+        opt_r.step(); opt_g.step()
+        assert abs(loss_r.item() - loss_g.item()) < 1e-4 * max(1.0, abs(loss_r.item())), (step, loss_r.item(), loss_g.item())
+    for (n, a), b in zip(ref.named_parameters(), gpu.parameters()):
+        torch.testing.assert_close(b.detach().cpu(), a.detach(), rtol=1e-3, atol=2e-5, msg=lambda m: f'{n}: {m}')
