@@ -74,7 +74,8 @@ template <int DH, bool FULL, int PF>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void fwd_mfma(FwdArgs a) {
   using C = TileCfg<DH>;
   __shared__ __attribute__((aligned(16))) float lds_all[kWavesPerBlock][2][C::TILE_FLOATS];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: unit, row, head and tile bases live in SGPRs
   const int64_t unit = (int64_t)blockIdx.x * kWavesPerBlock + wave;
   if (unit >= a.n_units) return;
   int64_t r, onode;
@@ -219,7 +220,8 @@ template <int DH, bool FULL, int PF>
 __global__ LB_DST void bwd_dst_mfma(BwdArgs a) {
   using C = TileCfg<DH>;
   __shared__ __attribute__((aligned(16))) float lds_all[kWavesPerBlock][2][C::TILE_FLOATS];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: unit, row, head and tile bases live in SGPRs
   const int64_t unit = (int64_t)blockIdx.x * kWavesPerBlock + wave;
   if (unit >= a.n_units) return;
   int64_t r, onode;
@@ -339,7 +341,8 @@ template <int DH, bool FULL, int PF>
 __global__ LB_SRC void bwd_src_mfma(BwdArgs a) {
   using C = TileCfg<DH>;
   __shared__ __attribute__((aligned(16))) float lds_all[kWavesPerBlock][2][C::TILE_FLOATS];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: unit, row, head and tile bases live in SGPRs
   const int64_t unit = (int64_t)blockIdx.x * kWavesPerBlock + wave;
   if (unit >= a.n_units) return;
   int64_t s, onode;

@@ -182,7 +182,8 @@ __device__ __forceinline__ void store_tile(const ampconv_view_t &v, int64_t node
 template <bool FULL>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void fwd_bf16(Args a) {
   __shared__ __attribute__((aligned(16))) char lds_all[kWavesPerBlock][2 * kTileBytes];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: unit, row, head and tile bases live in SGPRs
   const int64_t unit = (int64_t)blockIdx.x * kWavesPerBlock + wave;
   if (unit >= a.n_units) return;
   int64_t r, onode;
@@ -248,7 +249,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void fwd_bf16(Args a) {
 template <bool FULL>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void bwd_dst_bf16(Args a) {
   __shared__ __attribute__((aligned(16))) char lds_all[kWavesPerBlock][2 * kTileBytes];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: unit, row, head and tile bases live in SGPRs
   const int64_t unit = (int64_t)blockIdx.x * kWavesPerBlock + wave;
   if (unit >= a.n_units) return;
   int64_t r, onode;
@@ -330,7 +332,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void bwd_dst_bf16(Args a) {
 template <bool FULL>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void bwd_src_bf16(Args a) {
   __shared__ __attribute__((aligned(16))) char lds_all[kWavesPerBlock][2 * kTileBytes];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: unit, row, head and tile bases live in SGPRs
   const int64_t unit = (int64_t)blockIdx.x * kWavesPerBlock + wave;
   if (unit >= a.n_units) return;
   int64_t s, onode;

@@ -219,7 +219,8 @@ template <int NPROD, bool FULL>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void fwd_split(FwdArgs a) {
   using C = TileCfg<DH>;
   __shared__ __attribute__((aligned(16))) char lds_all[kWavesPerBlock][2 * kTileBytes];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: unit, row, head and tile bases live in SGPRs
   const int64_t unit = (int64_t)blockIdx.x * kWavesPerBlock + wave;
   if (unit >= a.n_units) return;
   const int64_t r = unit / a.H;
@@ -302,7 +303,8 @@ template <int NPROD, bool FULL>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void bwd_dst_split(BwdArgs a) {
   using C = TileCfg<DH>;
   __shared__ __attribute__((aligned(16))) char lds_all[kWavesPerBlock][2 * kTileBytes];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: unit, row, head and tile bases live in SGPRs
   const int64_t unit = (int64_t)blockIdx.x * kWavesPerBlock + wave;
   if (unit >= a.n_units) return;
   const int64_t r = unit / a.H;
@@ -400,7 +402,8 @@ template <int NPROD, bool FULL>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void bwd_src_split(BwdArgs a) {
   using C = TileCfg<DH>;
   __shared__ __attribute__((aligned(16))) char lds_all[kWavesPerBlock][2 * kTileBytes];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform: unit, row, head and tile bases live in SGPRs
   const int64_t unit = (int64_t)blockIdx.x * kWavesPerBlock + wave;
   if (unit >= a.n_units) return;
   const int64_t s = unit / a.H;

@@ -110,9 +110,10 @@ __device__ __forceinline__ void pair_load(PairRegs<DH> &t, const float *baseA, i
     const bool isB = R >= kLmax;
     const int j = isB ? R - kLmax : R;
     const bool valid = (R < 2 * kLmax) && (FULL || j < L);
-    // per-lane part as a 32-bit element offset (loop invariant), tile base uniform per edge
-    const unsigned off = (unsigned)j * (unsigned)(isB ? strideB : strideA) + 4u * (unsigned)q;
-    const float *p = (isB ? baseB : baseA) + off;
+    // per-lane part as a 32-bit BYTE offset (loop invariant) on top of a tile base that is uniform
+    // per edge: lets the compiler keep the base in SGPRs (global_load ... v_off, s[base:base+1])
+    const unsigned boff = ((unsigned)j * (unsigned)(isB ? strideB : strideA) + 4u * (unsigned)q) * 4u;
+    const char *p = reinterpret_cast<const char *>(isB ? baseB : baseA) + boff;
     if (valid) t.v[i] = *reinterpret_cast<const float4 *>(p);
   }
 }
