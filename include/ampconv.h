@@ -160,6 +160,37 @@ int ampconv_mask_rows(void *Y, const int32_t *rowptr, int64_t N, int64_t F,
 int ampconv_masked_colsum(const void *dY, const int32_t *rowptr, int64_t N,
                           int L, int D, float *out, int dtype, void *stream);
 
+/* ---- GraphSAINT random-walk sampler ("next" row: the step before the hot path) -------------
+ * In-tree spec: the reference's vendored PyG sampler, visualization/visualize_graphsaint_subgraphs.py
+ * :195-199 (walks), :107-110 (unique nodes + induced sub-graph), :137-173 (norms).  The graph is
+ * given as the src-sorted CSC of ampconv_csr_build (cscptr, crow = destinations, cperm = original
+ * edge ids).  The caller reads n_sub / e_sub (device int32) back to size the next outputs.
+ *   random_walk : walks[b, 0] = start[b]; each step moves to a uniform random out-neighbour
+ *                 (stays if none); counter-based generator keyed by (seed, walk, step)
+ *   nodes       : walked nodes (with repeats) -> mark[N], relabel[N], node_idx (sorted unique)
+ *   count/fill  : induced sub-graph, edges grouped by source in CSC order: relabelled
+ *                 edge_index [2, e_sub] and the original edge ids
+ *   add_counts  : count[idx[i]] += 1 (occurrence statistics of nodes / edges)
+ *   norms       : edge_norm = clamp(node_count[src] / edge_count, 0, 1e4) (NaN -> 0.1),
+ *                 node_norm = num_samples / max(node_count, 0.1 if 0) / N               */
+int ampconv_saint_random_walk(const int32_t *cscptr, const int32_t *crow, const int64_t *start,
+                              int64_t B, int walk_length, uint64_t seed, int64_t *walks, void *stream);
+size_t ampconv_saint_workspace_bytes(int64_t N);
+int ampconv_saint_nodes(const int64_t *nodes, int64_t n, int64_t N, int32_t *mark, int32_t *relabel,
+                        int64_t *node_idx, int32_t *n_sub, void *workspace, size_t workspace_bytes,
+                        void *stream);
+int ampconv_saint_count_edges(const int64_t *node_idx, int64_t n_sub, const int32_t *cscptr,
+                              const int32_t *crow, const int32_t *mark, int32_t *cnt, int32_t *off,
+                              int32_t *e_sub, void *workspace, size_t workspace_bytes, void *stream);
+int ampconv_saint_fill_edges(const int64_t *node_idx, int64_t n_sub, const int32_t *cscptr,
+                             const int32_t *crow, const int32_t *cperm, const int32_t *mark,
+                             const int32_t *relabel, const int32_t *off, int64_t E_sub,
+                             int64_t *edge_index, int64_t *edge_id, void *stream);
+int ampconv_saint_add_counts(const int64_t *idx, int64_t n, float *count, void *stream);
+int ampconv_saint_norms(const float *node_count, const float *edge_count, const int64_t *edge_src,
+                        int64_t N, int64_t E, float num_samples, float *node_norm, float *edge_norm,
+                        void *stream);
+
 #ifdef __cplusplus
 }
 #endif

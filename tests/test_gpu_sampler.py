@@ -1,0 +1,111 @@
+"""GraphSAINT random-walk sampler on the GPU against the numpy restatement of the reference's
+vendored sampler (oracle/graphsaint_numpy.py).  The random stream is unpinned (torch_sparse is
+absent); its defining properties and everything downstream of it are checked."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import graphsaint_numpy as ref
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def graph():
+    dev = torch.device('cuda:0')
+    rng = np.random.default_rng(5)
+    N, E = 3000, 24000
+    ei = rng.integers(0, N - 30, size=(2, E)).astype(np.int64)       # last 30 nodes isolated
+    ei[0, :40] = N - 1                                                # ... except node N-1: out-edges only
+    data = types.SimpleNamespace(x=torch.randn(N, 12, device=dev), y=torch.randint(0, 7, (N,), device=dev),
+                                 edge_index=torch.from_numpy(ei).to(dev),
+                                 train_mask=(torch.rand(N, device=dev) < 0.5),
+                                 edge_attr=torch.arange(E, device=dev, dtype=torch.float32))
+    return data, ei, N, E
+
+
+def test_walks_and_induced_subgraph(graph):
+    from ampnet_amd.sampler import GraphSAINTRandomWalkSampler
+    data, ei, N, E = graph
+    s = GraphSAINTRandomWalkSampler(data, batch_size=20, walk_length=30, num_steps=3, seed=11, num_nodes=N)
+    seen = []
+    for _ in range(3):
+        node_idx, edge_index, edge_id, walks = s.sample()
+        w = walks.cpu().numpy()
+        assert w.shape == (20, 31)
+        assert ref.walk_is_valid(ei, N, w)
+        n_ref, e_ref, keep = ref.induced_subgraph(ei, N, w)
+        np.testing.assert_array_equal(node_idx.cpu().numpy(), n_ref)          # sorted unique nodes
+        got = edge_index.cpu().numpy()
+        eid = edge_id.cpu().numpy()
+        order = np.argsort(eid)                                               # edge order is free
+        np.testing.assert_array_equal(eid[order], keep)
+        np.testing.assert_array_equal(got[:, order], e_ref)
+        # relabelled edges point at the right original endpoints
+        np.testing.assert_array_equal(n_ref[got[0]], ei[0][eid])
+        np.testing.assert_array_equal(n_ref[got[1]], ei[1][eid])
+        seen.append(w.copy())
+    assert not np.array_equal(seen[0], seen[1])                               # a new draw each call
+    s2 = GraphSAINTRandomWalkSampler(data, batch_size=20, walk_length=30, num_steps=3, seed=11, num_nodes=N)
+    np.testing.assert_array_equal(s2.sample()[3].cpu().numpy(), seen[0])      # same seed -> same batch
+
+
+def test_walk_steps_are_uniform_over_neighbours(graph):
+    from ampnet_amd.sampler import GraphSAINTRandomWalkSampler
+    data, ei, N, E = graph
+    s = GraphSAINTRandomWalkSampler(data, batch_size=4000, walk_length=1, seed=3, num_nodes=N)
+    # all walks start at node N-1 (40 out-edges): first steps must be ~uniform over its neighbours
+    walks = torch.empty(4000, 2, dtype=torch.int64, device=data.x.device)
+    from ampnet_amd import _lib
+    start = torch.full((4000,), N - 1, dtype=torch.int64, device=data.x.device)
+    _lib.check(_lib.load().ampconv_saint_random_walk(s.csr.cscptr.data_ptr(), s.csr.crow.data_ptr(),
+                                                     start.data_ptr(), 4000, 1, 12345, walks.data_ptr(),
+                                                     torch.cuda.current_stream().cuda_stream), 'walk')
+    nxt = walks[:, 1].cpu().numpy()
+    neigh = ei[1][ei[0] == N - 1]
+    assert set(nxt.tolist()) <= set(neigh.tolist())
+    counts = np.array([(nxt == v).sum() for v in np.unique(neigh)])
+    mult = np.array([(neigh == v).sum() for v in np.unique(neigh)])          # duplicate edges count twice
+    expected = 4000 * mult / mult.sum()
+    chi2 = ((counts - expected) ** 2 / expected).sum()
+    assert chi2 < 2.5 * len(counts), chi2                                      # loose goodness of fit
+
+
+def test_norms_and_batches(graph):
+    from ampnet_amd.sampler import GraphSAINTRandomWalkSampler
+    data, ei, N, E = graph
+    s = GraphSAINTRandomWalkSampler(data, batch_size=30, walk_length=20, num_steps=4, sample_coverage=3,
+                                    seed=7, num_nodes=N)
+    nn_ref, en_ref = ref.norms(s.node_count.cpu().numpy(), s.edge_count.cpu().numpy(), ei[0], N, s.num_samples)
+    np.testing.assert_allclose(s.node_norm.cpu().numpy(), nn_ref, rtol=1e-6)
+    np.testing.assert_allclose(s.edge_norm.cpu().numpy(), en_ref, rtol=1e-6)
+    assert s.node_count.sum().item() >= N * 3                                 # coverage reached
+    n_batches = 0
+    for b in s:
+        n_batches += 1
+        idx = b.node_idx
+        assert torch.equal(b.x, data.x[idx]) and torch.equal(b.y, data.y[idx])
+        assert torch.equal(b.train_mask, data.train_mask[idx])
+        assert torch.equal(b.edge_attr, data.edge_attr[b.edge_id])            # per-edge attributes follow
+        assert torch.equal(b.node_norm, s.node_norm[idx]) and torch.equal(b.edge_norm, s.edge_norm[b.edge_id])
+        assert b.edge_index.max().item() < b.num_nodes
+    assert n_batches == len(s) == 4
+
+
+def test_sampler_feeds_the_layer(graph):
+    """The harness pattern of experiments/cora_benchmark_graphsaint.py:96-110 on the GPU path."""
+    from ampnet_amd import AMPConv
+    from ampnet_amd.sampler import GraphSAINTRandomWalkSampler
+    data, ei, N, E = graph
+    dev = data.x.device
+    feats = types.SimpleNamespace(x=torch.randn(N, 4 * 32, device=dev), y=data.y, edge_index=data.edge_index)
+    layer = AMPConv(32, 1).to(dev)
+    s = GraphSAINTRandomWalkSampler(feats, batch_size=8, walk_length=50, num_steps=2, sample_coverage=1,
+                                    seed=1, num_nodes=N)
+    for b in s:
+        out = layer(b.x, b.edge_index)
+        loss = (out.pow(2).mean(dim=1) * b.node_norm).sum()
+        loss.backward()
+    assert torch.isfinite(layer.multi_head_attention.in_proj_weight.grad).all()
