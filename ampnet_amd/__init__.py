@@ -9,5 +9,8 @@ include/ampconv.h.  No CPU fallback.
 from .conv import AMPConv, InvalidConfiguration
 from .graph import EdgeCSR, graph_cache
 from . import distributed
+from .module import AMPGCN, FeatureTokens
+from .sampler import GraphSAINTRandomWalkSampler
 
-__all__ = ['AMPConv', 'InvalidConfiguration', 'EdgeCSR', 'graph_cache', 'distributed']
+__all__ = ['AMPConv', 'InvalidConfiguration', 'EdgeCSR', 'graph_cache', 'distributed', 'AMPGCN', 'FeatureTokens',
+           'GraphSAINTRandomWalkSampler']

@@ -191,6 +191,21 @@ int ampconv_saint_norms(const float *node_count, const float *edge_count, const 
                         int64_t N, int64_t E, float num_samples, float *node_norm, float *edge_norm,
                         void *stream);
 
+/* ---- AMPGCN featuriser ("next" row: the step right before the first AMPConv layer) ----------
+ * Reference src/ampnet/module/amp_gcn.py:120-183: z-score of the node features (:122-125), L present
+ * (non-zero) features sampled per node with replacement (:132-135), token = concat(embedding row,
+ * z-scored value) (:146-147).  x is [N, F] fp32, idx [N, L] int32 (-1 = node without any present
+ * feature; `empty_flag` is raised), table [F, De], out [N, L, De + 1].  table_grad zeroes dtable and
+ * accumulates the token gradients with float atomics.  */
+int ampconv_feat_zscore_stats(const float *x, int64_t N, int64_t F, float *mean, float *inv_std,
+                              void *stream);
+int ampconv_feat_sample_present(const float *x, int64_t N, int F, int L, uint64_t seed, int32_t *idx,
+                                int32_t *empty_flag, void *stream);
+int ampconv_feat_build(const float *x, const float *mean, const float *inv_std, const int32_t *idx,
+                       const float *table, int64_t N, int F, int L, int De, float *out, void *stream);
+int ampconv_feat_table_grad(const float *dout, const int32_t *idx, int64_t N, int L, int De, int F,
+                            float *dtable, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

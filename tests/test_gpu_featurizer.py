@@ -1,0 +1,105 @@
+"""AMPGCN featuriser + model wrapper on the GPU against the numpy/sklearn restatement of
+src/ampnet/module/amp_gcn.py:120-183 (oracle/featurizer_numpy.py)."""
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import featurizer_numpy as ref
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def feats():
+    rng = np.random.default_rng(9)
+    N, Fdim = 500, 1433                                  # Cora's feature width
+    x = (rng.random((N, Fdim)) < 0.013).astype(np.float32)          # sparse bag-of-words rows
+    x[:, 7] = 0.0                                        # a constant (all-zero) feature -> scale 1
+    x[np.arange(N), rng.integers(0, Fdim, N)] = 1.0      # every node has at least one present feature
+    x[:, 7] = 0.0
+    x *= rng.random((N, Fdim)).astype(np.float32) + 0.5  # non-binary values
+    return x
+
+
+def test_zscore_and_tokens_match_sklearn(feats):
+    from ampnet_amd.module import FeatureTokens
+    dev = torch.device('cuda:0')
+    torch.manual_seed(0)
+    ft = FeatureTokens(1433, 99, 40, seed=3).to(dev)
+    x = torch.from_numpy(feats).to(dev)
+    mean, inv_std = ft.zscore_stats(x)
+    xz = (x - mean) * inv_std
+    np.testing.assert_allclose(xz.cpu().numpy(), ref.zscore(feats), rtol=1e-5, atol=1e-5)
+    tokens, idx = ft(x)
+    idx_h = idx.cpu().numpy()
+    assert idx_h.shape == (500, 40) and ref.indices_are_present(feats, idx_h)
+    want = ref.build_tokens(feats, idx_h, ft.feature_embedding_table.weight.detach().cpu().numpy())
+    np.testing.assert_allclose(tokens.detach().cpu().numpy(), want, rtol=1e-5, atol=1e-5)
+    # gradient reaches the embedding table exactly like indexing does
+    g = torch.randn_like(tokens)
+    tokens.backward(g)
+    table_ref = torch.zeros(1433, 99)
+    table_ref.index_add_(0, torch.from_numpy(idx_h.reshape(-1)).long(), g.cpu().view(-1, 100)[:, :99])
+    torch.testing.assert_close(ft.feature_embedding_table.weight.grad.cpu(), table_ref, rtol=1e-5, atol=1e-5)
+    # sampling: reproducible per seed, uniform over the present features of a node
+    i1, _ = ft.sample(x, seed=5)
+    i2, _ = ft.sample(x, seed=5)
+    assert torch.equal(i1, i2)
+    big = FeatureTokens(1433, 99, 4000, seed=1).to(dev)
+    ib, _ = big.sample(x[:1].contiguous(), seed=9)
+    present = np.nonzero(feats[0])[0]
+    counts = np.array([(ib.cpu().numpy() == f).sum() for f in present])
+    assert counts.sum() == 4000
+    exp = 4000 / len(present)
+    assert ((counts - exp) ** 2 / exp).sum() < 3.0 * len(present)
+
+
+def test_node_without_present_feature_raises(feats):
+    from ampnet_amd.module import FeatureTokens
+    dev = torch.device('cuda:0')
+    x = torch.from_numpy(feats.copy()).to(dev)
+    x[3] = 0
+    with pytest.raises(ValueError, match='no present'):
+        FeatureTokens(1433, 99, 40).to(dev)(x)
+
+
+def test_ampgcn_model_matches_reference_structure(feats):
+    """State-dict keys of the reference AMPGCN and a forward/backward on the GPU path; with the
+    sampled indices fixed, the logits equal a CPU restatement built from oracle pieces."""
+    from ampnet_amd.module import AMPGCN
+    from oracle.ampconv_torch import RefShapedAMPConv
+    dev = torch.device('cuda:0')
+    torch.manual_seed(1)
+    model = AMPGCN(device=dev, embedding_dim=32, num_heads=1, num_sampled_vectors=20, feat_emb_dim=31,
+                   dropout_rate=0.0, dropout_adj_rate=0.0).to(dev)
+    keys = list(model.state_dict().keys())
+    assert keys == ['feature_embedding_table.weight',
+                    'conv1.multi_head_attention.in_proj_weight', 'conv1.multi_head_attention.in_proj_bias',
+                    'conv1.multi_head_attention.out_proj.weight', 'conv1.multi_head_attention.out_proj.bias',
+                    'conv2.multi_head_attention.in_proj_weight', 'conv2.multi_head_attention.in_proj_bias',
+                    'conv2.multi_head_attention.out_proj.weight', 'conv2.multi_head_attention.out_proj.bias',
+                    'final_linear_out.weight', 'final_linear_out.bias']
+    N = feats.shape[0]
+    g = torch.Generator().manual_seed(2)
+    ei = torch.randint(0, N, (2, 3000), generator=g)
+    data = types.SimpleNamespace(x=torch.from_numpy(feats).to(dev), edge_index=ei.to(dev))
+    out = model(data)
+    assert out.shape == (N, 7)
+    y = torch.randint(0, 7, (N,), generator=g).to(dev)
+    torch.nn.functional.nll_loss(out, y).backward()
+    assert torch.isfinite(model.feature_embedding_table.weight.grad).all()
+    # CPU restatement with the SAME sampled indices
+    idx = model.sampled_node_feat_indices.cpu().numpy()
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    x0 = torch.from_numpy(ref.build_tokens(feats, idx, sd['feature_embedding_table.weight'].numpy()))
+    c1, c2 = RefShapedAMPConv(32, 1), RefShapedAMPConv(32, 1)
+    c1.load_state_dict({k[len('conv1.'):]: v for k, v in sd.items() if k.startswith('conv1.')})
+    c2.load_state_dict({k[len('conv2.'):]: v for k, v in sd.items() if k.startswith('conv2.')})
+    with torch.no_grad():
+        h = torch.relu(c2(torch.relu(c1(x0, ei)), ei))
+        logits = torch.nn.functional.linear(h.reshape(N, 20, 32).mean(dim=1), sd['final_linear_out.weight'],
+                                            sd['final_linear_out.bias'])
+        want = torch.log_softmax(logits, dim=1)
+    torch.testing.assert_close(out.detach().cpu(), want, rtol=1e-4, atol=1e-5)
