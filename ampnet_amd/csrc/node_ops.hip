@@ -38,13 +38,20 @@ __global__ void masked_colsum_partial(const T *__restrict__ dY,
   const int64_t n0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t n1 = n0 + rows_per_block < N ? n0 + rows_per_block : N;
   for (int c = threadIdx.x; c < D; c += blockDim.x) {
-    float acc = 0.f;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;     // four independent chains: 4 loads in flight
     for (int64_t n = n0; n < n1; ++n) {
       if (rowptr[n + 1] == rowptr[n]) continue;
       const T *row = dY + n * (int64_t)L * D + c;
-      for (int l = 0; l < L; ++l) acc += (float)row[(int64_t)l * D];
+      int l = 0;
+      for (; l + 4 <= L; l += 4) {
+        a0 += (float)row[(int64_t)l * D];
+        a1 += (float)row[(int64_t)(l + 1) * D];
+        a2 += (float)row[(int64_t)(l + 2) * D];
+        a3 += (float)row[(int64_t)(l + 3) * D];
+      }
+      for (; l < L; ++l) a0 += (float)row[(int64_t)l * D];
     }
-    partial[(int64_t)blockIdx.x * D + c] = acc;
+    partial[(int64_t)blockIdx.x * D + c] = (a0 + a1) + (a2 + a3);
   }
 }
 
@@ -87,7 +94,7 @@ extern "C" int ampconv_masked_colsum(const void *dY, const int32_t *rowptr, int6
                                      int D, float *out, int dtype, void *stream) {
   if (N < 0 || L <= 0 || D <= 0) return AMPCONV_E_BADARG;
   if (!out) return AMPCONV_E_BADARG;
-  const int nblocks = 1024;
+  const int nblocks = 1024;        // = COLSUM_BLOCKS of ampnet_amd/_lib.py
   float *partial = out + D;
   if (N == 0) {
     hipError_t e = hipMemsetAsync(out, 0, sizeof(float) * D, (hipStream_t)stream);

@@ -10,7 +10,7 @@ shape (one-subgraph-per-GPU data parallelism, weak scaling) and the parameter
 gradients are averaged with one RCCL all-reduce per step inside the timed
 region (experiments/cora_benchmark_graphsaint_distributed.py:63-94 as intended).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg4|cfg3|cora|tiny]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg4|cfg3|cfg5|cora|tiny] [--dtype f32|bf16]
 
 Prints ONE JSON line on rank 0.  `roofline` prices the dominant kernel against
 the 8 TB/s HBM3E spec peak with durations measured live by HIP events on the

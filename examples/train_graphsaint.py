@@ -67,7 +67,7 @@ def main():
             loss.backward()
             opt.step()
             sched.step()
-            tot += float(loss); cnt += 1
+            tot += loss.item(); cnt += 1
             correct += float((out.argmax(1) == batch.y)[batch.train_mask].float().mean())
         history.append((tot / cnt, correct / cnt))
         print(f'epoch {epoch}: train loss {tot / cnt:.4f}  train acc {correct / cnt:.3f}  '
