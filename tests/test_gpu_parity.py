@@ -460,3 +460,50 @@ def test_training_steps_match_cpu_reference(dev):
         assert abs(loss_r.item() - loss_g.item()) < 1e-4 * max(1.0, abs(loss_r.item())), (step, loss_r.item(), loss_g.item())
     for (n, a), b in zip(ref.named_parameters(), gpu.parameters()):
         torch.testing.assert_close(b.detach().cpu(), a.detach(), rtol=1e-3, atol=2e-5, msg=lambda m: f'{n}: {m}')
+
+
+@pytest.mark.parametrize('seed', range(10))
+def test_random_shapes_mfma_vs_generic(seed, dev, monkeypatch):
+    """Random small problems (L in 1..20, dh in {16, 32}, H in 1..16, degenerate graphs included):
+    the MFMA kernels and the independent shape-generic kernels must agree on y and every gradient."""
+    from ampnet_amd import AMPConv, graph_cache
+    rng = np.random.default_rng(1000 + seed)
+    dh = int(rng.choice([16, 32]))
+    H = int(rng.choice([1, 2, 3, 4, 8, 16]))
+    L = int(rng.integers(1, 21))
+    D = dh * H
+    N = int(rng.integers(1, 400))
+    kind = seed % 5
+    E = int(rng.integers(0, 6 * N + 2))
+    src = rng.integers(0, N, E)
+    dst = rng.integers(0, N, E)
+    if kind == 1:
+        dst[:] = rng.integers(0, N)                       # every edge into one node (one long segment)
+    elif kind == 2:
+        src[:] = rng.integers(0, N)                       # every edge out of one node
+    elif kind == 3:
+        dst = src.copy()                                  # self loops only
+    ei = torch.from_numpy(np.stack([src, dst]).astype(np.int64)).to(dev)
+    torch.manual_seed(seed)
+    layer = AMPConv(D, H).to(dev)
+    with torch.no_grad():
+        layer.multi_head_attention.in_proj_bias.normal_(0, 0.2)
+        layer.multi_head_attention.out_proj.bias.normal_(0, 0.2)
+    x = torch.randn(N, L * D, device=dev)
+    dy = torch.randn(N, L * D, device=dev)
+
+    def run():
+        graph_cache.clear()
+        layer.zero_grad(set_to_none=True)
+        xg = x.clone().requires_grad_(True)
+        y = layer(xg, ei)
+        y.backward(dy)
+        m = layer.multi_head_attention
+        return [t.detach().cpu().numpy() for t in (y, xg.grad, m.in_proj_weight.grad, m.in_proj_bias.grad,
+                                                    m.out_proj.weight.grad, m.out_proj.bias.grad)]
+
+    fast = run()
+    monkeypatch.setenv('AMPCONV_FORCE_GENERIC', '1')
+    slow = run()
+    for name, a, b in zip(['y', 'dx', 'gWin', 'gbin', 'gWo', 'gbo'], fast, slow):
+        assert_close_scaled(a, b, f'{name} (N={N} E={E} L={L} D={D} H={H} kind={kind})')
