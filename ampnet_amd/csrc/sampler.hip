@@ -101,9 +101,8 @@ __global__ void norms_kernel(const float *__restrict__ node_count, const float *
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < E) {
     const float t = node_count[edge_src[i]], c = edge_count[i];
-    float r = t / c;                                   // 0/0 -> NaN -> 0.1; x/0 -> inf -> clamp 1e4
-    r = r != r ? 0.1f : fminf(fmaxf(r, 0.f), 1e4f);
-    edge_norm[i] = r;
+    // the reference divides first: 0/0 -> NaN -> 0.1, x/0 -> inf -> clamp 1e4 (counts are >= 0)
+    edge_norm[i] = c == 0.f ? (t == 0.f ? 0.1f : 1e4f) : fminf(t / c, 1e4f);
   }
   if (i < N) {
     const float c = node_count[i] == 0.f ? 0.1f : node_count[i];
