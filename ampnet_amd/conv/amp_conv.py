@@ -58,6 +58,8 @@ class AMPConv(MessagePassing):
         # how fp32 products run on the matrix cores: 'default' | 'exact' | 'bf16x9' | 'bf16x6'
         # (include/ampconv.h, dtype codes); inputs, outputs and accumulation are fp32 in every mode
         self.precision = 'default'
+        # how the dense fp32 projections run: 'fp32' | 'bf16x3' (functional.gemm_precision)
+        self.gemm_precision = 'fp32'
         self.num_heads = num_heads
         self.embed_dim = embed_dim
         # parameter container only: same init RNG consumption and state-dict keys as the reference
@@ -99,7 +101,7 @@ class AMPConv(MessagePassing):
             raise ValueError(f'edge_index is on {edge_index.device} but x is on {x.device}')
         csr = graph_cache.get(edge_index, x.size(0))
         y, qkv, _ = F_.AMPConvFunction.apply(x, x, *self._params(), csr, self.num_heads, True,
-                                             _lib.PRECISIONS[self.precision])
+                                             _lib.PRECISIONS[self.precision], self.gemm_precision)
         L = x.size(1) // self.embed_dim
         self._set_attn_ctx(qkv, None, edge_index, L, shared=True)
         return y
@@ -114,7 +116,7 @@ class AMPConv(MessagePassing):
         E = x_i.size(0)
         csr = EdgeCSR.identity(E, x_i.device)
         y, q, kv = F_.AMPConvFunction.apply(x_i, x_j, *self._params(), csr, self.num_heads, False,
-                                            _lib.PRECISIONS[self.precision])
+                                            _lib.PRECISIONS[self.precision], self.gemm_precision)
         ar = torch.arange(E, dtype=torch.int64, device=x_i.device)
         L = x_i.size(1) // self.embed_dim
         self._set_attn_ctx(q, kv, torch.stack([ar, ar]), L, shared=False)

@@ -13,7 +13,9 @@ Data layout in HBM (fp32):
   dQKV  [N*L, 3D]   written by the two backward edge passes, consumed by one GEMM each
                     for dX and d(in_proj_weight)
 """
+import contextlib
 import ctypes
+import os
 
 import torch
 
@@ -30,6 +32,40 @@ def _view(buf2d, col_off, L, dh):
 
 def _ptr(t):
     return t.data_ptr() if t is not None else None
+
+
+GEMM_PRECISIONS = ('fp32', 'bf16x3')
+
+
+@contextlib.contextmanager
+def gemm_precision(mode):
+    """How the dense fp32 projections run.  'fp32': plain fp32 MFMA GEMMs (rocBLAS, ~135-150
+    TFLOP/s on MI355X).  'bf16x3': hipBLASLt's fp32 GEMM that splits each operand into two bf16
+    planes and sums three bf16 MFMA products in fp32 (what ROCm serves as "TF32" on gfx950, which
+    has no xf32 matrix instruction): ~2x the rate, element error ~5e-6 of the largest output
+    instead of ~6e-7 (tools/bench_gemm.py).  Inputs, outputs and accumulation stay fp32; the
+    edge kernels are not affected.  torch's switches are process-global, so they are set for the
+    duration of the block and restored."""
+    if mode not in GEMM_PRECISIONS:
+        raise ValueError(f'gemm precision must be one of {GEMM_PRECISIONS}, got {mode!r}')
+    if mode == 'fp32':
+        yield
+        return
+    prev_env = os.environ.get('HIPBLASLT_ALLOW_TF32')
+    prev_tf32 = torch.backends.cuda.matmul.allow_tf32
+    prev_lib = torch.backends.cuda.preferred_blas_library()
+    os.environ['HIPBLASLT_ALLOW_TF32'] = '1'
+    torch.backends.cuda.matmul.allow_tf32 = True
+    torch.backends.cuda.preferred_blas_library('hipblaslt')
+    try:
+        yield
+    finally:
+        torch.backends.cuda.preferred_blas_library(prev_lib)
+        torch.backends.cuda.matmul.allow_tf32 = prev_tf32
+        if prev_env is None:
+            os.environ.pop('HIPBLASLT_ALLOW_TF32', None)
+        else:
+            os.environ['HIPBLASLT_ALLOW_TF32'] = prev_env
 
 
 def _tn_matmul(a, b, chunks=128):
@@ -66,7 +102,8 @@ class AMPConvFunction(torch.autograd.Function):
     the pre-gathered x_i / x_j with an identity graph."""
 
     @staticmethod
-    def forward(ctx, xq, xkv, w_in, b_in, w_out, b_out, csr, num_heads, shared, dtype=_lib.AMPCONV_F32):
+    def forward(ctx, xq, xkv, w_in, b_in, w_out, b_out, csr, num_heads, shared, dtype=_lib.AMPCONV_F32,
+                gemm='fp32'):
         lib = _lib.load()
         D = w_out.size(0)
         H = int(num_heads)
@@ -78,7 +115,7 @@ class AMPConvFunction(torch.autograd.Function):
                 raise ValueError('bf16 inputs need bf16 parameters: call layer.to(torch.bfloat16)')
         Nq, Nk = xq.size(0), xkv.size(0)
         xq2 = xq.contiguous().view(Nq * L, D)
-        with torch.cuda.device(xq.device):
+        with torch.cuda.device(xq.device), gemm_precision(gemm):
             if shared:
                 qkv = torch.addmm(b_in, xq2, w_in.t())                     # [N*L, 3D]
                 Qv, Kv, Vv = (_view(qkv, i * D, L, dh) for i in range(3))
@@ -98,7 +135,7 @@ class AMPConvFunction(torch.autograd.Function):
             _lib.check(rc, 'ampconv_mask_rows')
         ctx.set_materialize_grads(False)     # no zero-filled [N*L, 3D] gradient for the qkv side output
         ctx.save_for_backward(xq2, xkv2, w_in, w_out, qkv, kv, obar)
-        ctx.csr, ctx.dims, ctx.shared, ctx.dtype = csr, (Nq, Nk, L, D, H), shared, dtype
+        ctx.csr, ctx.dims, ctx.shared, ctx.dtype, ctx.gemm = csr, (Nq, Nk, L, D, H), shared, dtype, gemm
         ctx.mark_non_differentiable(qkv)
         if kv is not None:
             ctx.mark_non_differentiable(kv)
@@ -108,14 +145,14 @@ class AMPConvFunction(torch.autograd.Function):
     def backward(ctx, dy, _dqkv=None, _dkv=None):
         lib = _lib.load()
         if dy is None:
-            return (None,) * 10
+            return (None,) * 11
         xq2, xkv2, w_in, w_out, qkv, kv, obar = ctx.saved_tensors
         csr, shared = ctx.csr, ctx.shared
         Nq, Nk, L, D, H = ctx.dims
         dh = D // H
         dev = dy.device
         need_xq, need_xkv = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev), gemm_precision(ctx.gemm):
             dy2 = dy.contiguous().view(Nq * L, D)
             # out-projection: rows with no in-edge contribute nothing (their obar is 0, and
             # the bias gradient masks them explicitly)
@@ -158,7 +195,7 @@ class AMPConvFunction(torch.autograd.Function):
                 db_in = torch.cat([dqkv.sum(dim=0), dkv.sum(dim=0)])
                 dxq = dqkv.mm(w_in[:D]).view(Nq, L * D) if need_xq else None
                 dxkv = dkv.mm(w_in[D:]).view(Nk, L * D) if need_xkv else None
-        return dxq, dxkv, dw_in, db_in, dw_out, db_out, None, None, None, None
+        return dxq, dxkv, dw_in, db_in, dw_out, db_out, None, None, None, None, None
 
 
 def attention_weights(Qv, Kv, edge_index, L, D, H):

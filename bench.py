@@ -10,7 +10,7 @@ shape (one-subgraph-per-GPU data parallelism, weak scaling) and the parameter
 gradients are averaged with one RCCL all-reduce per step inside the timed
 region (experiments/cora_benchmark_graphsaint_distributed.py:63-94 as intended).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg4|cfg3|cfg5|cora|tiny] [--dtype f32|bf16]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg4|cfg3|cfg5|cora|tiny] [--dtype f32|bf16] [--gemm fp32|bf16x3]
 
 Prints ONE JSON line on rank 0.  `roofline` prices the dominant kernel against
 the 8 TB/s HBM3E spec peak with durations measured live by HIP events on the
@@ -161,6 +161,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--dtype', default=None, choices=['f32', 'bf16'],
                     help='storage dtype (default: f32; bf16 for cfg5)')
+    ap.add_argument('--gemm', default='fp32', choices=['fp32', 'bf16x3'],
+                    help='dense fp32 projections: plain fp32 GEMMs (default, the headline number) or '
+                         "hipBLASLt's 3-product bf16 split (ampnet_amd.conv.functional.gemm_precision)")
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -185,6 +188,7 @@ def main():
     torch.manual_seed(1)
     layer = AMPConv(D, H).to(dev)
     layer.retain_attention = False                            # no [E, L, L] side output kept alive
+    layer.gemm_precision = args.gemm
     with torch.no_grad():
         layer.multi_head_attention.in_proj_bias.normal_(0, 0.1)
         layer.multi_head_attention.out_proj.bias.normal_(0, 0.1)
@@ -234,6 +238,21 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
+    alt = None
+    if world == 1 and dt_name == 'f32' and args.gemm == 'fp32':
+        # same step with the projections on hipBLASLt's bf16x3 path -- reported beside, never as `value`
+        layer.gemm_precision = 'bf16x3'
+        step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        dta = time.perf_counter() - t0
+        layer.gemm_precision = 'fp32'
+        alt = {'gemm': 'bf16x3', 'value': E * args.steps / dta, 'unit': 'edges/s',
+               'ms_per_step': 1e3 * dta / args.steps}
+
     if rank == 0:
         ms = timer.summary()
         alg = {'ampconv_fwd_edge': (2 * E + 2 * N) * R, 'ampconv_bwd_edge_dst': (2 * E + 3 * N) * R,
@@ -256,7 +275,8 @@ def main():
             'vs_baseline': None, 'dtype': dt_name, 'data': 'synthetic',
             'config': {'workload': f'{args.workload}: {desc}, one AMPConv layer fwd+bwd incl. CSR build, '
                                    f'one graph per GPU' + (' + RCCL grad all-reduce' if world > 1 else ''),
-                       'N': N, 'E': E, 'L': L, 'D': D, 'H': H, 'parallelism': f'dp{world}'},
+                       'N': N, 'E': E, 'L': L, 'D': D, 'H': H, 'parallelism': f'dp{world}',
+                       'gemm': args.gemm},
             'layer_hbm': {'algorithmic_bytes_per_step': b_alg,
                           'achieved_GBps_per_gpu': b_alg * args.steps / dt / 1e9,
                           'frac_of_8TBps': b_alg * args.steps / dt / 1e9 / HBM_PEAK_GBS},
@@ -265,6 +285,8 @@ def main():
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'algorithmic_bytes_per_launch': alg[dom], 'avg_launch_ms': ms[dom]},
         }
+        if alt is not None:
+            out['alt_gemm'] = alt
         if world == 1 and not args.no_cpu_baseline:
             del x, dy
             torch.cuda.empty_cache()

@@ -26,10 +26,11 @@ def dev():
     return torch.device('cuda:0')
 
 
-def _layer(g, dev, prefix='', mode='default'):
+def _layer(g, dev, prefix='', mode='default', gemm='fp32'):
     from ampnet_amd import AMPConv
     layer = AMPConv(int(g['D']), int(g['H'])).to(dev)
     layer.precision = mode
+    layer.gemm_precision = gemm
     sd = {'multi_head_attention.in_proj_weight': torch.from_numpy(g[prefix + 'in_proj_weight']),
           'multi_head_attention.in_proj_bias': torch.from_numpy(g[prefix + 'in_proj_bias']),
           'multi_head_attention.out_proj.weight': torch.from_numpy(g[prefix + 'out_proj_weight']),
@@ -44,8 +45,8 @@ def _grads(layer):
             m.out_proj.weight.grad.cpu().numpy(), m.out_proj.bias.grad.cpu().numpy())
 
 
-def _check_single(g, dev, mode='default'):
-    layer = _layer(g, dev, mode=mode)
+def _check_single(g, dev, mode='default', gemm='fp32'):
+    layer = _layer(g, dev, mode=mode, gemm=gemm)
     x = torch.from_numpy(g['x']).to(dev).requires_grad_(True)
     ei = torch.from_numpy(g['edge_index']).to(dev)
     y = layer(x, ei)
@@ -76,6 +77,25 @@ def test_golden_single_layer(path, mode, dev):
     # every way of running the fp32 products on the matrix cores (include/ampconv.h dtype codes)
     # must reproduce the reference's outputs at the same fp32 tolerance
     _check_single(load_golden(path), dev, mode)
+
+
+@pytest.mark.parametrize('path', SINGLE, ids=[os.path.basename(p)[:-4] for p in SINGLE])
+def test_golden_gemm_bf16x3(path, dev):
+    # projections on hipBLASLt's 3-product bf16 split (functional.gemm_precision): same fp32
+    # tolerance against the reference's outputs, and torch's global switches come back as they were
+    before = (torch.backends.cuda.matmul.allow_tf32, torch.backends.cuda.preferred_blas_library(),
+              os.environ.get('HIPBLASLT_ALLOW_TF32'))
+    _check_single(load_golden(path), dev, gemm='bf16x3')
+    after = (torch.backends.cuda.matmul.allow_tf32, torch.backends.cuda.preferred_blas_library(),
+             os.environ.get('HIPBLASLT_ALLOW_TF32'))
+    assert before == after
+
+
+def test_gemm_precision_rejects_unknown_mode(dev):
+    from ampnet_amd.conv.functional import gemm_precision
+    with pytest.raises(ValueError):
+        with gemm_precision('fp16'):
+            pass
 
 
 @pytest.mark.parametrize('path', SINGLE[:4], ids=[os.path.basename(p)[:-4] for p in SINGLE[:4]])
