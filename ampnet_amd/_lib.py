@@ -38,10 +38,12 @@ SIGNATURES = {
     'ampconv_hub_plan': (_i32, [_vp, _i64, _i64, _i32, _vp, _vp]),
     'ampconv_hub_workspace_bytes': (_sz, [_i64, _i32, _i32, _i32]),
     'ampconv_fwd_edge': (_i32, [View, View, View, _vp, _vp, _vp, _i64, _i32, _i32, _i32, View, _vp, _i64, _vp, _i32, _vp]),
+    'ampconv_csc_positions': (_i32, [_vp, _vp, _i64, _vp, _vp, _vp]),
+    'ampconv_softmax_stats_bytes': (_sz, [_i64, _i32, _i32, _i32, _i32]),
     'ampconv_bwd_edge_dst': (_i32, [View, View, View, View, _vp, _vp, _i64, _i32, _i32, _i32, View, _vp, _i64, _vp,
-                                    _i32, _vp]),
+                                    _vp, _vp, _i32, _vp]),
     'ampconv_bwd_edge_src': (_i32, [View, View, View, View, _vp, _vp, _vp, _i64, _i32, _i32, _i32,
-                                    View, View, _vp, _i64, _vp, _i32, _vp]),
+                                    View, View, _vp, _i64, _vp, _vp, _i32, _vp]),
     'ampconv_attn_weights': (_i32, [View, View, _vp, _i64, _i32, _i32, _i32, _vp, _i32, _vp]),
     'ampconv_saint_random_walk': (_i32, [_vp, _vp, _vp, _i64, _i32, ctypes.c_uint64, _vp, _vp]),
     'ampconv_saint_workspace_bytes': (_sz, [_i64]),

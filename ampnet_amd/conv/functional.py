@@ -35,6 +35,9 @@ def _ptr(t):
 
 
 GEMM_PRECISIONS = ('fp32', 'bf16x3')
+# hand the softmax statistics of the destination pass to the source pass (AMPCONV_SOFTMAX_STATS=0:
+# both passes reduce their own; used by the tests to cross-check the two ways)
+SOFTMAX_STATS = os.environ.get('AMPCONV_SOFTMAX_STATS', '1') != '0'
 
 
 @contextlib.contextmanager
@@ -175,16 +178,24 @@ class AMPConvFunction(torch.autograd.Function):
                 dkv = torch.empty(Nk * L, 2 * D, dtype=dy2.dtype, device=dev)
                 Qv, Kv, Vv = _view(qkv, 0, L, dh), _view(kv, 0, L, dh), _view(kv, D, L, dh)
                 dQv, dKv, dVv = _view(dqkv, 0, L, dh), _view(dkv, 0, L, dh), _view(dkv, D, L, dh)
+            # softmax statistics (normaliser, delta) per edge: a by-product of the destination
+            # pass that saves the source pass its cross-lane reductions (include/ampconv.h)
+            stats = spos = None
+            nstat = lib.ampconv_softmax_stats_bytes(csr.num_edges, L, D, H, ctx.dtype) if SOFTMAX_STATS else 0
+            if nstat:
+                stats = torch.empty(nstat // 4, dtype=torch.float32, device=dev)
+                spos = csr.csc_positions()
             plan, nch, ws = csr.hub_args('dst', L, D, 1)
             rc = lib.ampconv_bwd_edge_dst(Qv, Kv, Vv, dOv, csr.rowptr.data_ptr(), csr.col.data_ptr(),
-                                          Nq, L, D, H, dQv, plan, nch, _ptr(ws), ctx.dtype, _stream())
+                                          Nq, L, D, H, dQv, plan, nch, _ptr(ws), _ptr(spos), _ptr(stats),
+                                          ctx.dtype, _stream())
             _lib.check(rc, 'ampconv_bwd_edge_dst')
             plan, nch, ws = csr.hub_args('src', L, D, 2)
             rc = lib.ampconv_bwd_edge_src(Qv, Kv, Vv, dOv, csr.cscptr.data_ptr(), csr.crow.data_ptr(),
                                           csr.cinv.data_ptr(), Nk, L, D, H, dKv, dVv, plan, nch, _ptr(ws),
-                                          ctx.dtype, _stream())
+                                          _ptr(stats), ctx.dtype, _stream())
             _lib.check(rc, 'ampconv_bwd_edge_src')
-            del dobar
+            del dobar, stats
             if shared:
                 dw_in = _tn_matmul(dqkv, xq2)
                 db_in = dqkv.sum(dim=0)

@@ -37,6 +37,14 @@ struct HubDesc {
   int32_t row, beg, end;   // row of the segment, CSR/CSC positions [beg, end) of this chunk
   int32_t nfirst;          // number of chunks of the row if this is its first chunk, else 0
 };
+// softmax statistics handed from the destination pass to the source pass: per (CSC position, head)
+// 20 log2-sum-exp values then 20 delta values (one per destination token; include/ampconv.h)
+constexpr int kStatsPerUnit = 40;
+struct StatsArgs {
+  const int32_t *spos;     // CSR position -> CSC position (dst pass only)
+  float *stats;            // nullptr: the source pass reduces its own softmax
+};
+
 struct HubArgs {
   const int32_t *header;   // plan header {n_chunks, chunk, 0, 0}; descriptors follow at header + 4
   int mode;                // 0: no plan, 1: main pass (rows longer than header[1] are skipped),
@@ -89,11 +97,12 @@ int ampconv_fwd_edge_mfma(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
 int ampconv_bwd_edge_dst_mfma(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
                               ampconv_view_t dO, const int32_t *rowptr, const int32_t *col,
                               int64_t n_rows, int L, int D, int H, ampconv_view_t dQ, HubArgs hub,
-                              hipStream_t stream);
+                              StatsArgs st, hipStream_t stream);
 int ampconv_bwd_edge_src_mfma(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
                               ampconv_view_t dO, const int32_t *cscptr, const int32_t *crow,
                               const float *cinv, int64_t n_src, int L, int D, int H,
-                              ampconv_view_t dK, ampconv_view_t dV, HubArgs hub, hipStream_t stream);
+                              ampconv_view_t dK, ampconv_view_t dV, HubArgs hub, StatsArgs st,
+                              hipStream_t stream);
 
 // ---- split-operand bf16 MFMA path (edge_mfma_split.hip): L <= 20, dh == 32; nprod = 9 or 6
 bool ampconv_split_supported(int L, int D, int H);

@@ -98,12 +98,21 @@ extern "C" int ampconv_fwd_edge(ampconv_view_t Q, ampconv_view_t K, ampconv_view
                                   (hipStream_t)stream);
 }
 
+extern "C" size_t ampconv_softmax_stats_bytes(int64_t E, int L, int D, int H, int dtype) {
+  if (E <= 0 || check_common(L, D, H, dtype) != AMPCONV_OK || dtype == AMPCONV_BF16) return 0;
+  if (force_generic() || !ampconv_mfma_supported(L, D, H) || split_products(dtype, L, D, H)) return 0;
+  return (size_t)E * H * kStatsPerUnit * sizeof(float);
+}
+
 extern "C" int ampconv_bwd_edge_dst(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
                                     ampconv_view_t dObar, const int32_t *rowptr,
                                     const int32_t *col, int64_t n_rows, int L, int D, int H,
                                     ampconv_view_t dQ, const void *hub_plan, int64_t hub_chunks,
-                                    void *hub_ws, int dtype, void *stream) {
+                                    void *hub_ws, const int32_t *spos, float *stats, int dtype,
+                                    void *stream) {
   if (int rc = check_common(L, D, H, dtype)) return rc;
+  if (stats && (!spos || (uintptr_t)stats % 16 != 0)) return AMPCONV_E_BADARG;
+  const StatsArgs sa{spos, stats};
   if (n_rows < 0) return AMPCONV_E_BADARG;
   if (n_rows == 0) return AMPCONV_OK;
   if (!view_ok(Q) || !view_ok(K) || !view_ok(V) || !view_ok(dObar) || !view_ok(dQ) || !rowptr)
@@ -111,6 +120,7 @@ extern "C" int ampconv_bwd_edge_dst(ampconv_view_t Q, ampconv_view_t K, ampconv_
   const ampconv_view_t views[] = {Q, K, V, dObar, dQ};
   if (dtype == AMPCONV_BF16) {
     if (!ampconv_bf16_supported(L, D, H, views, 5)) return AMPCONV_E_DTYPE;
+    if (stats) return AMPCONV_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     if (hub_plan && hub_chunks > 0 && hub_ws) {
       if (int rc = ampconv_bwd_edge_dst_bf16(Q, K, V, dObar, rowptr, col, n_rows, L, D, H, dQ,
@@ -127,23 +137,24 @@ extern "C" int ampconv_bwd_edge_dst(ampconv_view_t Q, ampconv_view_t K, ampconv_
   }
   if (!force_generic() && ampconv_mfma_supported(L, D, H) && ampconv_mfma_views_ok(views, 5)) {
     if (const int np = split_products(dtype, L, D, H))
-      return ampconv_bwd_edge_dst_split(np, Q, K, V, dObar, rowptr, col, n_rows, L, D, H, dQ,
+      return stats ? AMPCONV_E_BADARG : ampconv_bwd_edge_dst_split(np, Q, K, V, dObar, rowptr, col, n_rows, L, D, H, dQ,
                                         (hipStream_t)stream);
     if (hub_plan && hub_chunks > 0 && hub_ws) {
       HubArgs hm = hub_args(hub_plan, 1), hh = hub_args(hub_plan, 2);
-      if (int rc = ampconv_bwd_edge_dst_mfma(Q, K, V, dObar, rowptr, col, n_rows, L, D, H, dQ, hm,
+      if (int rc = ampconv_bwd_edge_dst_mfma(Q, K, V, dObar, rowptr, col, n_rows, L, D, H, dQ, hm, sa,
                                              (hipStream_t)stream))
         return rc;
       ampconv_view_t P = partial_view(hub_ws, 0, hub_chunks, L, D, H);
-      if (int rc = ampconv_bwd_edge_dst_mfma(Q, K, V, dObar, rowptr, col, hub_chunks, L, D, H, P, hh,
+      if (int rc = ampconv_bwd_edge_dst_mfma(Q, K, V, dObar, rowptr, col, hub_chunks, L, D, H, P, hh, sa,
                                              (hipStream_t)stream))
         return rc;
       return ampconv_hub_combine(hub_plan, hub_chunks, (const float *)P.ptr, dQ, nullptr, L, D, H,
                                  1.f / sqrtf((float)(D / H)), 0, (hipStream_t)stream);
     }
     return ampconv_bwd_edge_dst_mfma(Q, K, V, dObar, rowptr, col, n_rows, L, D, H, dQ,
-                                     HubArgs{nullptr, 0}, (hipStream_t)stream);
+                                     HubArgs{nullptr, 0}, sa, (hipStream_t)stream);
   }
+  if (stats) return AMPCONV_E_BADARG;     // this shape's kernels keep no statistics (ampconv_softmax_stats_bytes = 0)
   return ampconv_bwd_edge_dst_generic(Q, K, V, dObar, rowptr, col, n_rows, L, D, H, dQ,
                                       (hipStream_t)stream);
 }
@@ -153,8 +164,10 @@ extern "C" int ampconv_bwd_edge_src(ampconv_view_t Q, ampconv_view_t K, ampconv_
                                     const int32_t *crow, const float *cinv, int64_t n_src,
                                     int L, int D, int H, ampconv_view_t dK, ampconv_view_t dV,
                                     const void *hub_plan, int64_t hub_chunks, void *hub_ws,
-                                    int dtype, void *stream) {
+                                    const float *stats, int dtype, void *stream) {
   if (int rc = check_common(L, D, H, dtype)) return rc;
+  if (stats && (uintptr_t)stats % 16 != 0) return AMPCONV_E_BADARG;
+  const StatsArgs sa{nullptr, const_cast<float *>(stats)};
   if (n_src < 0) return AMPCONV_E_BADARG;
   if (n_src == 0) return AMPCONV_OK;
   if (!view_ok(Q) || !view_ok(K) || !view_ok(V) || !view_ok(dObar) || !view_ok(dK) ||
@@ -163,6 +176,7 @@ extern "C" int ampconv_bwd_edge_src(ampconv_view_t Q, ampconv_view_t K, ampconv_
   const ampconv_view_t views[] = {Q, K, V, dObar, dK, dV};
   if (dtype == AMPCONV_BF16) {
     if (!ampconv_bf16_supported(L, D, H, views, 6)) return AMPCONV_E_DTYPE;
+    if (stats) return AMPCONV_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     if (hub_plan && hub_chunks > 0 && hub_ws) {
       if (int rc = ampconv_bwd_edge_src_bf16(Q, K, V, dObar, cscptr, crow, cinv, n_src, L, D, H, dK, dV,
@@ -183,17 +197,17 @@ extern "C" int ampconv_bwd_edge_src(ampconv_view_t Q, ampconv_view_t K, ampconv_
   }
   if (!force_generic() && ampconv_mfma_supported(L, D, H) && ampconv_mfma_views_ok(views, 6)) {
     if (const int np = split_products(dtype, L, D, H))
-      return ampconv_bwd_edge_src_split(np, Q, K, V, dObar, cscptr, crow, cinv, n_src, L, D, H,
+      return stats ? AMPCONV_E_BADARG : ampconv_bwd_edge_src_split(np, Q, K, V, dObar, cscptr, crow, cinv, n_src, L, D, H,
                                         dK, dV, (hipStream_t)stream);
     if (hub_plan && hub_chunks > 0 && hub_ws) {
       HubArgs hm = hub_args(hub_plan, 1), hh = hub_args(hub_plan, 2);
       if (int rc = ampconv_bwd_edge_src_mfma(Q, K, V, dObar, cscptr, crow, cinv, n_src, L, D, H, dK, dV,
-                                             hm, (hipStream_t)stream))
+                                             hm, sa, (hipStream_t)stream))
         return rc;
       ampconv_view_t PK = partial_view(hub_ws, 0, hub_chunks, L, D, H);
       ampconv_view_t PV = partial_view(hub_ws, 1, hub_chunks, L, D, H);
       if (int rc = ampconv_bwd_edge_src_mfma(Q, K, V, dObar, cscptr, crow, cinv, hub_chunks, L, D, H, PK,
-                                             PV, hh, (hipStream_t)stream))
+                                             PV, hh, sa, (hipStream_t)stream))
         return rc;
       if (int rc = ampconv_hub_combine(hub_plan, hub_chunks, (const float *)PK.ptr, dK, nullptr, L, D, H,
                                        0.6931471805599453f, 0, (hipStream_t)stream))
@@ -202,8 +216,9 @@ extern "C" int ampconv_bwd_edge_src(ampconv_view_t Q, ampconv_view_t K, ampconv_
                                  (hipStream_t)stream);
     }
     return ampconv_bwd_edge_src_mfma(Q, K, V, dObar, cscptr, crow, cinv, n_src, L, D, H, dK, dV,
-                                     HubArgs{nullptr, 0}, (hipStream_t)stream);
+                                     HubArgs{nullptr, 0}, sa, (hipStream_t)stream);
   }
+  if (stats) return AMPCONV_E_BADARG;
   return ampconv_bwd_edge_src_generic(Q, K, V, dObar, cscptr, crow, cinv, n_src, L, D, H, dK,
                                       dV, (hipStream_t)stream);
 }

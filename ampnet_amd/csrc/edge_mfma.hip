@@ -49,8 +49,10 @@ struct FwdArgs {
 
 // softmax over the 20 source tokens of one destination-token column held as
 // (t0[0..3] = tokens 4g..4g+3, t1[0] = token 16+g) across the 4 lane groups g.
+// Returns m + log2(sum): P = exp2(S' - lse), what the source pass needs to rebuild P without
+// reducing again (kStatsPerUnit below).
 template <bool FULL>
-__device__ __forceinline__ void column_softmax(f32x4 &t0, f32x4 &t1, int L, int g) {
+__device__ __forceinline__ float column_softmax(f32x4 &t0, f32x4 &t1, int L, int g) {
   if (!FULL) {
 #pragma unroll
     for (int q = 0; q < 4; ++q)
@@ -68,6 +70,7 @@ __device__ __forceinline__ void column_softmax(f32x4 &t0, f32x4 &t1, int L, int 
 #pragma unroll
   for (int q = 0; q < 4; ++q) t0[q] *= inv;
   t1[0] *= inv;
+  return m + __builtin_amdgcn_logf(l);
 }
 
 template <int DH, bool FULL, int PF>
@@ -200,6 +203,8 @@ struct BwdArgs {
   const int32_t *ptr;      // rowptr (dst pass) / cscptr (src pass)
   const int32_t *idx;      // col (dst pass) / crow (src pass)
   const float *cinv;       // src pass: 1/in-degree of the destination of each CSC edge
+  const int32_t *spos;     // dst pass, STATS: CSC position of each CSR edge
+  float *stats;            // STATS: [CSC position][head][lse(20) | delta(20)], written by the dst pass
   int64_t n_units;
   int L, H;
   float qscale;            // log2(e) / sqrt(dh)
@@ -216,7 +221,7 @@ struct BwdArgs {
 #define LB_DST __launch_bounds__(64 * kWavesPerBlock)
 #define LB_SRC __launch_bounds__(64 * kWavesPerBlock)
 #endif
-template <int DH, bool FULL, int PF>
+template <int DH, bool FULL, int PF, bool STATS>
 __global__ LB_DST void bwd_dst_mfma(BwdArgs a) {
   using C = TileCfg<DH>;
   __shared__ __attribute__((aligned(16))) float lds_all[kWavesPerBlock][2][C::TILE_FLOATS];
@@ -251,19 +256,23 @@ __global__ LB_DST void bwd_dst_mfma(BwdArgs a) {
   for (int mc = 0; mc < C::MC; ++mc) dQT[mc][0] = dQT[mc][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   PairRegs<DH> ring[PF];
+  float ring_pos[PF];      // STATS: CSC position of the edge (int bits; rides in the window's weight slot)
   IdxWindow win;
-  if (beg < end) idxwin_load<false>(win, a.idx, nullptr, beg, end, lane);
-  auto fetch = [&](PairRegs<DH> &buf, int p) {
-    const int64_t s = idxwin_get<false>(win, a.idx, nullptr, p, end, lane, nullptr);
+  const float *wts = reinterpret_cast<const float *>(a.spos);
+  if (beg < end) idxwin_load<STATS>(win, a.idx, wts, beg, end, lane);
+  auto fetch = [&](PairRegs<DH> &buf, float &pos, int p) {
+    const int64_t s = idxwin_get<STATS>(win, a.idx, wts, p, end, lane, &pos);
     pair_load<DH, FULL>(buf, tile_ptr<const float>(a.K, s, h), a.K.row_stride,
                         tile_ptr<const float>(a.V, s, h), a.V.row_stride, L, lane);
   };
 #pragma unroll
   for (int k = 0; k < PF; ++k)
-    if (beg + k < end) fetch(ring[k], beg + k);
-  auto step = [&](PairRegs<DH> &kv, int p) {
+    if (beg + k < end) fetch(ring[k], ring_pos[k], beg + k);
+  auto step = [&](PairRegs<DH> &kv, float &pos, int p) {
     pair_to_lds<DH, FULL>(Kt, kv, 1.f, 1.f, L, lane);
-    if (p + PF < end) fetch(kv, p + PF);
+    float *sb = nullptr;
+    if (STATS) sb = a.stats + ((int64_t)__builtin_bit_cast(int, pos) * a.H + h) * kStatsPerUnit;
+    if (p + PF < end) fetch(kv, pos, p + PF);
     __builtin_amdgcn_wave_barrier();
 
     // the destination-token columns of the two column tiles are independent (the softmax runs
@@ -291,11 +300,18 @@ __global__ LB_DST void bwd_dst_mfma(BwdArgs a) {
         }
       }
       PRIO(0);
-      column_softmax<FULL>(S0, S1, L, g);
+      const float lse = column_softmax<FULL>(S0, S1, L, g);
       float part = S1[0] * dP1[0];
 #pragma unroll
       for (int q = 0; q < 4; ++q) part = fmaf(S0[q], dP0[q], part);
       const float delta = groups_sum(part);
+      if (STATS) {        // every lane group holds the column's values; group 0 stores them
+        const int i = (lane & 15) + 16 * nt;
+        if (g == 0 && i < kLmax) {
+          sb[i] = lse;
+          sb[kLmax + i] = delta;
+        }
+      }
 #pragma unroll
       for (int q = 0; q < 4; ++q) S0[q] *= dP0[q] - delta;     // S now holds dS^T
       S1[0] *= dP1[0] - delta;
@@ -315,7 +331,7 @@ __global__ LB_DST void bwd_dst_mfma(BwdArgs a) {
   for (int p0 = beg; p0 < end; p0 += PF) {
 #pragma unroll
     for (int k = 0; k < PF; ++k)
-      if (p0 + k < end) step(ring[k], p0 + k);
+      if (p0 + k < end) step(ring[k], ring_pos[k], p0 + k);
   }
 
   float *ob = tile_ptr<float>(a.dQ, onode, h);
@@ -337,7 +353,12 @@ __global__ LB_DST void bwd_dst_mfma(BwdArgs a) {
 //   S = Q K^T (destination tokens on MFMA rows, source tokens on columns), P = row softmax
 //   (16-lane DPP reductions), dP = dO V^T, dS = P o (dP - delta);
 //   dV^T += dO^T P,  dK^T += Q^T dS      (P / dS C/D registers = B operands)
-template <int DH, bool FULL, int PF>
+struct StatRegs {      // lse / delta of the destination tokens this lane's C/D rows hold
+  f32x4 l4, d4;        // tokens 4g .. 4g+3
+  float l1, d1;        // token 16 + g
+};
+
+template <int DH, bool FULL, int PF, bool STATS>
 __global__ LB_SRC void bwd_src_mfma(BwdArgs a) {
   using C = TileCfg<DH>;
   __shared__ __attribute__((aligned(16))) float lds_all[kWavesPerBlock][2][C::TILE_FLOATS];
@@ -374,21 +395,31 @@ __global__ LB_SRC void bwd_src_mfma(BwdArgs a) {
   STAMP_DECL
   PairRegs<DH> ring[PF];
   float ring_inv[PF];
+  StatRegs ring_st[PF];
   IdxWindow win;
   if (beg < end) idxwin_load<true>(win, a.idx, a.cinv, beg, end, lane);
-  auto fetch = [&](PairRegs<DH> &buf, float &inv, int p) {
+  auto fetch = [&](PairRegs<DH> &buf, float &inv, StatRegs &st, int p) {
     const int64_t d = idxwin_get<true>(win, a.idx, a.cinv, p, end, lane, &inv);
     pair_load<DH, FULL>(buf, tile_ptr<const float>(a.Q, d, h), a.Q.row_stride,
                         tile_ptr<const float>(a.dO, d, h), a.dO.row_stride, L, lane);
+    if (STATS) {
+      const float *sb = a.stats + ((int64_t)p * a.H + h) * kStatsPerUnit;
+      const int g = lane >> 4;
+      st.l4 = *reinterpret_cast<const f32x4 *>(sb + 4 * g);
+      st.d4 = *reinterpret_cast<const f32x4 *>(sb + kLmax + 4 * g);
+      st.l1 = sb[16 + g];
+      st.d1 = sb[kLmax + 16 + g];
+    }
   };
 #pragma unroll
   for (int k = 0; k < PF; ++k)
-    if (beg + k < end) fetch(ring[k], ring_inv[k], beg + k);
-  auto step = [&](PairRegs<DH> &qg, float &inv, int p) {
+    if (beg + k < end) fetch(ring[k], ring_inv[k], ring_st[k], beg + k);
+  auto step = [&](PairRegs<DH> &qg, float &inv, StatRegs &rs, int p) {
     STAMP(0);
     pair_to_lds<DH, FULL>(Qt, qg, a.qscale, inv, L, lane);
     STAMP(1);
-    if (p + PF < end) fetch(qg, inv, p + PF);
+    const StatRegs st = rs;
+    if (p + PF < end) fetch(qg, inv, rs, p + PF);
     STAMP(2);
     __builtin_amdgcn_wave_barrier();
 
@@ -418,6 +449,15 @@ __global__ LB_SRC void bwd_src_mfma(BwdArgs a) {
       // row softmax over the source tokens: columns n (+16 for tile 1) across the 16 lanes
 #pragma unroll
       for (int q = 0; q < (mt == 0 ? 4 : 1); ++q) {
+        if (STATS) {      // P and delta of this edge were reduced by the destination pass
+          const float lse = mt == 0 ? st.l4[q] : st.l1, delta = mt == 0 ? st.d4[q] : st.d1;
+          const float p0 = v0 ? fast_exp2(S0[q] - lse) : 0.f, p1 = v1 ? fast_exp2(S1[q] - lse) : 0.f;
+          S0[q] = p0;
+          S1[q] = p1;
+          dP0[q] = p0 * (dP0[q] - delta);
+          dP1[q] = p1 * (dP1[q] - delta);
+          continue;
+        }
         const float s0 = v0 ? S0[q] : kNegBig, s1 = v1 ? S1[q] : kNegBig;
         const float m = row16_max(fmaxf(s0, s1));
         float p0 = fast_exp2(s0 - m), p1 = fast_exp2(s1 - m);
@@ -454,7 +494,7 @@ __global__ LB_SRC void bwd_src_mfma(BwdArgs a) {
   for (int p0 = beg; p0 < end; p0 += PF) {
 #pragma unroll
     for (int k = 0; k < PF; ++k)
-      if (p0 + k < end) step(ring[k], ring_inv[k], p0 + k);
+      if (p0 + k < end) step(ring[k], ring_inv[k], ring_st[k], p0 + k);
   }
 
   STAMP_FLUSH(unit);
@@ -513,10 +553,11 @@ int ampconv_fwd_edge_mfma(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
 int ampconv_bwd_edge_dst_mfma(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
                               ampconv_view_t dO, const int32_t *rowptr, const int32_t *col,
                               int64_t n_rows, int L, int D, int H, ampconv_view_t dQ, HubArgs hub,
-                              hipStream_t stream) {
+                              StatsArgs st, hipStream_t stream) {
   const int dh = D / H;
   BwdArgs a{};
   a.hub = hub;
+  a.spos = st.spos; a.stats = st.stats;
   a.Q = Q; a.K = K; a.V = V; a.dO = dO; a.dQ = dQ;
   a.ptr = rowptr; a.idx = col; a.cinv = nullptr;
   a.n_units = n_rows * H; a.L = L; a.H = H;
@@ -525,20 +566,29 @@ int ampconv_bwd_edge_dst_mfma(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t
   const int64_t blocks = (a.n_units + kWavesPerBlock - 1) / kWavesPerBlock;
   if (blocks > INT32_MAX) return AMPCONV_E_BADARG;
   const dim3 grid((unsigned)blocks), block(64 * kWavesPerBlock);
-  if (dh == 32 && L == kLmax) bwd_dst_mfma<32, true, AMPCONV_PF_DST><<<grid, block, 0, stream>>>(a);
-  else if (dh == 32) bwd_dst_mfma<32, false, 1><<<grid, block, 0, stream>>>(a);
-  else if (L == kLmax) bwd_dst_mfma<16, true, AMPCONV_PF_DST><<<grid, block, 0, stream>>>(a);
-  else bwd_dst_mfma<16, false, 1><<<grid, block, 0, stream>>>(a);
+  if (st.stats) {
+    if (dh == 32 && L == kLmax) bwd_dst_mfma<32, true, AMPCONV_PF_DST, true><<<grid, block, 0, stream>>>(a);
+    else if (dh == 32) bwd_dst_mfma<32, false, 1, true><<<grid, block, 0, stream>>>(a);
+    else if (L == kLmax) bwd_dst_mfma<16, true, AMPCONV_PF_DST, true><<<grid, block, 0, stream>>>(a);
+    else bwd_dst_mfma<16, false, 1, true><<<grid, block, 0, stream>>>(a);
+  } else {
+    if (dh == 32 && L == kLmax) bwd_dst_mfma<32, true, AMPCONV_PF_DST, false><<<grid, block, 0, stream>>>(a);
+    else if (dh == 32) bwd_dst_mfma<32, false, 1, false><<<grid, block, 0, stream>>>(a);
+    else if (L == kLmax) bwd_dst_mfma<16, true, AMPCONV_PF_DST, false><<<grid, block, 0, stream>>>(a);
+    else bwd_dst_mfma<16, false, 1, false><<<grid, block, 0, stream>>>(a);
+  }
   return ampconv_launch_status();
 }
 
 int ampconv_bwd_edge_src_mfma(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
                               ampconv_view_t dO, const int32_t *cscptr, const int32_t *crow,
                               const float *cinv, int64_t n_src, int L, int D, int H,
-                              ampconv_view_t dK, ampconv_view_t dV, HubArgs hub, hipStream_t stream) {
+                              ampconv_view_t dK, ampconv_view_t dV, HubArgs hub, StatsArgs st,
+                              hipStream_t stream) {
   const int dh = D / H;
   BwdArgs a{};
   a.hub = hub;
+  a.stats = st.stats;
   a.Q = Q; a.K = K; a.V = V; a.dO = dO; a.dK = dK; a.dV = dV;
   a.ptr = cscptr; a.idx = crow; a.cinv = cinv;
   a.n_units = n_src * H; a.L = L; a.H = H;
@@ -547,10 +597,17 @@ int ampconv_bwd_edge_src_mfma(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t
   const int64_t blocks = (a.n_units + kWavesPerBlock - 1) / kWavesPerBlock;
   if (blocks > INT32_MAX) return AMPCONV_E_BADARG;
   const dim3 grid((unsigned)blocks), block(64 * kWavesPerBlock);
-  if (dh == 32 && L == kLmax) bwd_src_mfma<32, true, AMPCONV_PF_SRC><<<grid, block, 0, stream>>>(a);
-  else if (dh == 32) bwd_src_mfma<32, false, 1><<<grid, block, 0, stream>>>(a);
-  else if (L == kLmax) bwd_src_mfma<16, true, AMPCONV_PF_SRC><<<grid, block, 0, stream>>>(a);
-  else bwd_src_mfma<16, false, 1><<<grid, block, 0, stream>>>(a);
+  if (st.stats) {
+    if (dh == 32 && L == kLmax) bwd_src_mfma<32, true, AMPCONV_PF_SRC, true><<<grid, block, 0, stream>>>(a);
+    else if (dh == 32) bwd_src_mfma<32, false, 1, true><<<grid, block, 0, stream>>>(a);
+    else if (L == kLmax) bwd_src_mfma<16, true, AMPCONV_PF_SRC, true><<<grid, block, 0, stream>>>(a);
+    else bwd_src_mfma<16, false, 1, true><<<grid, block, 0, stream>>>(a);
+  } else {
+    if (dh == 32 && L == kLmax) bwd_src_mfma<32, true, AMPCONV_PF_SRC, false><<<grid, block, 0, stream>>>(a);
+    else if (dh == 32) bwd_src_mfma<32, false, 1, false><<<grid, block, 0, stream>>>(a);
+    else if (L == kLmax) bwd_src_mfma<16, true, AMPCONV_PF_SRC, false><<<grid, block, 0, stream>>>(a);
+    else bwd_src_mfma<16, false, 1, false><<<grid, block, 0, stream>>>(a);
+  }
   return ampconv_launch_status();
 }
 

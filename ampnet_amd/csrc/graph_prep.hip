@@ -73,6 +73,17 @@ size_t cub_temp_bytes(int64_t E, int64_t N) {
   return t;
 }
 
+// CSR position -> CSC position of the same edge (two passes through the original edge ids)
+__global__ void scatter_positions(const int32_t *__restrict__ cperm, int64_t E, int32_t *__restrict__ by_edge) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < E) by_edge[cperm[q]] = (int32_t)q;
+}
+__global__ void gather_positions(const int32_t *__restrict__ eperm, const int32_t *__restrict__ by_edge,
+                                 int64_t E, int32_t *__restrict__ spos) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < E) spos[p] = by_edge[eperm[p]];
+}
+
 }  // namespace
 
 extern "C" size_t ampconv_csr_workspace_bytes(int64_t N, int64_t E) {
@@ -133,5 +144,17 @@ extern "C" int ampconv_csr_build(const int64_t *edge_index, int64_t E, int64_t N
   gather_other<<<grid, T, 0, stream>>>(cperm, dst, E, N, crow);
   fill_ptr<<<gridn, T, 0, stream>>>(keys_out, E, N, cscptr);
   if (cinv) edge_inv_degree<<<grid, T, 0, stream>>>(crow, rowptr, E, cinv);
+  return ampconv_launch_status();
+}
+
+extern "C" int ampconv_csc_positions(const int32_t *eperm, const int32_t *cperm, int64_t E, int32_t *scratch,
+                                     int32_t *spos, void *stream) {
+  if (E < 0 || E > INT32_MAX) return AMPCONV_E_BADARG;
+  if (E == 0) return AMPCONV_OK;
+  if (!eperm || !cperm || !scratch || !spos) return AMPCONV_E_BADARG;
+  const int T = 256;
+  const int grid = (int)((E + T - 1) / T);
+  scatter_positions<<<grid, T, 0, (hipStream_t)stream>>>(cperm, E, scratch);
+  gather_positions<<<grid, T, 0, (hipStream_t)stream>>>(eperm, scratch, E, spos);
   return ampconv_launch_status();
 }

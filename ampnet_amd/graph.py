@@ -84,6 +84,23 @@ class EdgeCSR:
         self.hub_dst_chunks = self.hub_src_chunks = 0
         return self
 
+    def csc_positions(self):
+        """spos[p] = CSC position of the edge at CSR position p (lazily, once per graph): where the
+        destination pass files the softmax statistics the source pass reads back in order."""
+        if getattr(self, '_spos', None) is None:
+            lib = _lib.load()
+            E = self.num_edges
+            if self.eperm.data_ptr() == self.cperm.data_ptr():        # identity graph
+                self._spos = self.eperm
+            else:
+                self._spos = torch.empty(max(E, 1), dtype=torch.int32, device=self.device)
+                scratch = torch.empty(max(E, 1), dtype=torch.int32, device=self.device)
+                with torch.cuda.device(self.device):
+                    rc = lib.ampconv_csc_positions(self.eperm.data_ptr(), self.cperm.data_ptr(), E,
+                                                   scratch.data_ptr(), self._spos.data_ptr(), _stream())
+                _lib.check(rc, 'ampconv_csc_positions')
+        return self._spos
+
     def hub_args(self, side, L, D, n_tiles):
         """(plan pointer, n_chunks, workspace tensor) of the 'dst' or 'src' long-segment plan."""
         plan = self.hub_dst if side == 'dst' else self.hub_src

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define AMPCONV_VERSION 100
+#define AMPCONV_VERSION 101
 
 enum {
   AMPCONV_OK = 0,
@@ -91,6 +91,12 @@ int ampconv_csr_build(const int64_t *edge_index, int64_t E, int64_t N,
                       int32_t *oob, void *workspace, size_t workspace_bytes,
                       void *stream);
 
+/* spos[p] = position in the src-sorted CSC of the edge at position p of the dst-sorted CSR
+ * (eperm, cperm of ampconv_csr_build; `scratch` = E int32).  Needed only to hand softmax
+ * statistics from the destination pass to the source pass (below).  */
+int ampconv_csc_positions(const int32_t *eperm, const int32_t *cperm, int64_t E,
+                          int32_t *scratch, int32_t *spos, void *stream);
+
 /* ---- long segments ("hubs": power-law graphs, BASELINE config 5) ---------------------------
  * One wavefront per (row, head) runs as long as its longest segment.  A plan cuts every CSR
  * (or CSC) segment longer than `chunk` edges into chunks; the edge kernels then reduce each
@@ -122,18 +128,27 @@ int ampconv_fwd_edge(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
  * _dst: one pass over the dst-sorted CSR, writes dQ[r] for every row.
  * _src: one pass over the src-sorted CSC, writes dK[s], dV[s] for every source;
  *       `cinv[p]` = 1/in-degree of the destination of CSC edge p (ampconv_csr_build).
- * No atomics: every output row is owned by one wavefront.  */
+ * No atomics: every output row is owned by one wavefront.
+ * Softmax statistics (optional): both passes need, per edge, head and destination token i, the
+ * softmax normaliser and delta_i = sum_j P_ij dP_ij.  The destination pass has them as a by-product
+ * (its softmax runs inside a lane); the source pass otherwise re-reduces them across lanes.  With
+ * `stats` (ampconv_softmax_stats_bytes(E, ...) bytes, 16-byte aligned; 0 = this dtype/shape keeps
+ * none and `stats` must be NULL) the destination pass stores them at the edge's CSC position
+ * (`spos`, ampconv_csc_positions) as 20 log2-sum-exp + 20 delta floats per (edge, head), and the
+ * source pass -- which must then run AFTER the destination pass -- reads them back sequentially.  */
+size_t ampconv_softmax_stats_bytes(int64_t E, int L, int D, int H, int dtype);
 int ampconv_bwd_edge_dst(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
                          ampconv_view_t dObar, const int32_t *rowptr,
                          const int32_t *col, int64_t n_rows, int L, int D, int H,
                          ampconv_view_t dQ, const void *hub_plan, int64_t hub_chunks,
-                         void *hub_ws, int dtype, void *stream);
+                         void *hub_ws, const int32_t *spos, float *stats, int dtype,
+                         void *stream);
 int ampconv_bwd_edge_src(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
                          ampconv_view_t dObar, const int32_t *cscptr,
                          const int32_t *crow, const float *cinv,
                          int64_t n_src, int L, int D, int H, ampconv_view_t dK,
                          ampconv_view_t dV, const void *hub_plan, int64_t hub_chunks,
-                         void *hub_ws, int dtype, void *stream);
+                         void *hub_ws, const float *stats, int dtype, void *stream);
 
 /* ---- per-edge side outputs, ORIGINAL edge order ------------------------------
  * attn_weights: W[e] = mean_h softmax_rows(Q[dst e,:,h] K[src e,:,h]^T/sqrt(dh)),

@@ -527,3 +527,44 @@ def test_random_shapes_mfma_vs_generic(seed, dev, monkeypatch):
     slow = run()
     for name, a, b in zip(['y', 'dx', 'gWin', 'gbin', 'gWo', 'gbo'], fast, slow):
         assert_close_scaled(a, b, f'{name} (N={N} E={E} L={L} D={D} H={H} kind={kind})')
+
+
+@pytest.mark.parametrize('shape', [(900, 9000, 20, 256, 8), (500, 6000, 13, 64, 4), (400, 5000, 20, 64, 4)],
+                         ids=['L20_dh32', 'L13_dh16', 'L20_dh16_hub'])
+def test_softmax_stats_handoff_matches_own_reduction(shape, dev, monkeypatch):
+    # the source pass either re-reduces softmax / delta across lanes or reads what the destination
+    # pass stored (include/ampconv.h "Softmax statistics"): same gradients to fp32 rounding, on
+    # ragged graphs with hubs (long segments are cut into chunks) and isolated nodes
+    from ampnet_amd import AMPConv, graph_cache, _lib
+    from ampnet_amd.conv import functional as F_
+    N, E, L, D, H = shape
+    g = torch.Generator().manual_seed(E)
+    ei = torch.randint(0, N, (2, E), generator=g)
+    ei[1, : E // 10] = 3                            # hub destination (in-degree >> chunk)
+    ei[0, E // 10: E // 5] = 5                      # hub source
+    ei[1, ei[1] == 7] = 8                           # node 7 receives nothing
+    x = torch.randn(N, L * D, generator=g)
+    dy = torch.randn(N, L * D, generator=g)
+    torch.manual_seed(3)
+    layer = AMPConv(D, H).to(dev)
+    assert _lib.load().ampconv_softmax_stats_bytes(E, L, D, H, _lib.AMPCONV_F32) == E * H * 40 * 4
+    res = []
+    for on in (True, False):
+        monkeypatch.setattr(F_, 'SOFTMAX_STATS', on)
+        graph_cache.clear()
+        layer.zero_grad(set_to_none=True)
+        xg = x.to(dev).requires_grad_(True)
+        layer(xg, ei.to(dev)).backward(dy.to(dev))
+        res.append([xg.grad.cpu().numpy()] + list(_grads(layer)))
+    for a, b, name in zip(res[0], res[1], ('dx', 'gW_in', 'gb_in', 'gW_out', 'gb_out')):
+        scale = max(1.0, float(np.abs(b).max()))
+        np.testing.assert_allclose(a, b, rtol=2e-5, atol=2e-6 * scale, err_msg=name)
+
+
+def test_softmax_stats_rejected_where_unsupported(dev):
+    # shapes on the generic kernels keep no statistics: size query says 0, passing a buffer is an error
+    from ampnet_amd import _lib
+    lib = _lib.load()
+    assert lib.ampconv_softmax_stats_bytes(1000, 40, 100, 2, _lib.AMPCONV_F32) == 0
+    assert lib.ampconv_softmax_stats_bytes(1000, 20, 256, 8, _lib.AMPCONV_BF16) == 0
+    assert lib.ampconv_softmax_stats_bytes(1000, 20, 256, 8, _lib.AMPCONV_F32_BF16X6) == 0

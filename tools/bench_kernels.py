@@ -74,13 +74,21 @@ def main():
         _lib.check(lib.ampconv_fwd_edge(Qv, Kv, Vv, csr.rowptr.data_ptr(), csr.col.data_ptr(), None,
                                         N, L, D, H, F_._view(obar, 0, L, dh), *hub('dst', 1), dt, st), 'fwd')
 
+    # softmax statistics handed from the destination pass to the source pass (--no-stats: off)
+    nstat = 0 if '--no-stats' in sys.argv else lib.ampconv_softmax_stats_bytes(E, L, D, H, dt)
+    stats = torch.empty(nstat // 4, device=dev) if nstat else None
+    spos = csr.csc_positions() if nstat else None
+    sp = (spos.data_ptr(), stats.data_ptr()) if nstat else (None, None)
+    print('softmax stats:', f'{nstat / 1e9:.2f} GB' if nstat else 'off')
+
     def bwd_dst():
         _lib.check(lib.ampconv_bwd_edge_dst(Qv, Kv, Vv, dOv, csr.rowptr.data_ptr(), csr.col.data_ptr(),
-                                            N, L, D, H, dQv, *hub('dst', 1), dt, st), 'bwd_dst')
+                                            N, L, D, H, dQv, *hub('dst', 1), *sp, dt, st), 'bwd_dst')
 
     def bwd_src():
         _lib.check(lib.ampconv_bwd_edge_src(Qv, Kv, Vv, dOv, csr.cscptr.data_ptr(), csr.crow.data_ptr(),
-                                            csr.cinv.data_ptr(), N, L, D, H, dKv, dVv, *hub('src', 2), dt, st), 'bwd_src')
+                                            csr.cinv.data_ptr(), N, L, D, H, dKv, dVv, *hub('src', 2), sp[1],
+                                            dt, st), 'bwd_src')
 
     for name, fn, nbytes, flops in (
             ('fwd_edge', fwd, (2 * E + 2 * N) * R, 4 * L * L * D * E),

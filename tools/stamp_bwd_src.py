@@ -16,7 +16,7 @@ dqkv = torch.empty(N * L, 3 * D, device=dev); dQv, dKv, dVv = (F_._view(dqkv, i 
 dOv = F_._view(dobar, 0, L, dh); st = torch.cuda.current_stream().cuda_stream
 for _ in range(2):
     lib.ampconv_bwd_edge_src(Qv, Kv, Vv, dOv, csr.cscptr.data_ptr(), csr.crow.data_ptr(), csr.cinv.data_ptr(),
-                             N, L, D, H, dKv, dVv, None, 0, None, 2, st)
+                             N, L, D, H, dKv, dVv, None, 0, None, None, 2, st)
 torch.cuda.synchronize()
 raw = ctypes.CDLL(os.environ['AMPCONV_LIB_PATH'])
 buf = (ctypes.c_ulonglong * (8 * 4096))()
