@@ -13,6 +13,7 @@
 //                                       in the same MFMA accumulators = PyG's mean numerator)
 // Reference arithmetic replaced: torch functional.py:6578 (scale), :6589 (QK^T), :6590
 // (softmax), :6594 (PV) per edge, and the mean aggregation of amp_conv.py:11.
+#include <cstdlib>
 #include "mfma_tile.h"
 
 namespace {
@@ -516,6 +517,228 @@ __global__ LB_SRC void bwd_src_mfma(BwdArgs a) {
   }
 }
 
+// ---- backward, source pass with the statistics of the destination pass, tail tokens batched.
+// Tokens 16..19 of a destination fill only a quarter of a 16-row MFMA tile.  The source-side
+// operands (K, V of this source) are the same for every edge and dK / dV are sums over the edges,
+// so the quarter tiles of FOUR consecutive edges share one tile: MFMA row m <-> (edge m >> 2,
+// token 16 + (m & 3)).  In C/D layout lane group g then holds edge g's four tail tokens in regs
+// 0..3, and the products dV^T += dO^T P, dK^T += Q^T dS contract over (edge, token) jointly:
+// k-slot g of step q takes its A operand from edge g's row 16 + q.  This needs no reduction
+// along a row (P = exp2(S - lse), dS = P (dP - delta) are element-wise with the statistics), which
+// is what makes it possible here and not in the passes that compute their own softmax.
+// Per edge and head: 80 MFMAs instead of 104.
+//
+// LDS per wave: the two 16-row main images (rows 16..19 of the 20-row images stay unused) and a
+// stash [4 edges][Q | dO][4 tokens][DH]; stash row rho = 8 e + 4 isG + t, chunk swizzle swz_tail.
+template <int DH>
+__device__ __forceinline__ int swz_tail(int rho) {
+  return DH == 32 ? ((((rho >> 3) & 3) << 1) | ((rho >> 1) & 1)) : ((rho >> 3) & 3);
+}
+template <int DH>
+__device__ __forceinline__ int tail_idx(int rho, int c) {
+  return rho * DH + ((((c >> 2) ^ swz_tail<DH>(rho)) << 2) | (c & 3));
+}
+
+// registers -> main images (token rows < 16) and the stash slot of edge e (rows 16..19), scaled
+template <int DH, bool FULL>
+__device__ __forceinline__ void pair_to_lds_tail(float *ldsA, float *stash, int e, const PairRegs<DH> &t,
+                                                 float mulA, float mulB, int L, int lane) {
+  using C = TileCfg<DH>;
+  const int r = lane / C::CH, q = lane % C::CH;
+#pragma unroll
+  for (int i = 0; i < PairRegs<DH>::NP; ++i) {
+    const int R = r + C::RPI * i;
+    const bool isB = R >= kLmax;
+    const int j = isB ? R - kLmax : R;
+    const bool valid = (R < 2 * kLmax) && (FULL || j < L);
+    if (valid) {
+      const float mul = isB ? mulB : mulA;
+      float4 x = t.v[i];
+      x.x *= mul; x.y *= mul; x.z *= mul; x.w *= mul;
+      if (j < 16) {
+        *reinterpret_cast<float4 *>(ldsA + (isB ? C::TILE_FLOATS : 0) + j * DH + ((q ^ swz<DH>(j)) << 2)) = x;
+      } else {
+        const int rho = 8 * e + (isB ? 4 : 0) + (j - 16);
+        *reinterpret_cast<float4 *>(stash + rho * DH + ((q ^ swz_tail<DH>(rho)) << 2)) = x;
+      }
+    }
+  }
+}
+
+template <int DH, bool FULL>
+__global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? 3 : 4) void bwd_src_mfma_t4(BwdArgs a) {
+  using C = TileCfg<DH>;
+  constexpr int kStash = 4 * 2 * 4 * DH;
+  __shared__ __attribute__((aligned(16))) float lds_all[kWavesPerBlock][2 * C::TILE_FLOATS + kStash];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t unit = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  if (unit >= a.n_units) return;
+  int64_t s, onode;
+  int h, beg, end, deg;
+  if (!map_unit(a.hub, a.ptr, unit, a.H, s, onode, h, beg, end, deg)) return;
+  const int L = a.L, n = lane & 15, g = lane >> 4;
+  float *Qt = lds_all[wave], *Gt = Qt + C::TILE_FLOATS, *stash = Qt + 2 * C::TILE_FLOATS;
+  const float oscale = a.hub.mode == 2 ? 1.f : a.oscale;
+
+  float kB[2][C::KK], vB[2][C::KK];
+  {
+    const float *kb = tile_ptr<const float>(a.K, s, h);
+    const float *vb = tile_ptr<const float>(a.V, s, h);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      rowop_from_global<DH>(kB[nt], kb, a.K.row_stride, nt, true, 1.f, L, lane);
+      rowop_from_global<DH>(vB[nt], vb, a.V.row_stride, nt, true, 1.f, L, lane);
+    }
+  }
+  if (!FULL) {
+    tile_zero<DH>(Qt, lane);
+    tile_zero<DH>(Gt, lane);
+  }
+  // slots of a last, partial batch and token rows >= L are read by the MFMAs: keep them finite
+  for (int i = lane; i < kStash; i += AMPCONV_WAVE) stash[i] = 0.f;
+  f32x4 dKT[C::MC][2], dVT[C::MC][2];
+#pragma unroll
+  for (int mc = 0; mc < C::MC; ++mc)
+    dKT[mc][0] = dKT[mc][1] = dVT[mc][0] = dVT[mc][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  PairRegs<DH> qg;
+  float inv_next = 0.f;
+  IdxWindow win;
+  auto fetch = [&](int p) {
+    const int64_t d = idxwin_get<true>(win, a.idx, a.cinv, p, end, lane, &inv_next);
+    pair_load<DH, FULL>(qg, tile_ptr<const float>(a.Q, d, h), a.Q.row_stride,
+                        tile_ptr<const float>(a.dO, d, h), a.dO.row_stride, L, lane);
+  };
+  if (beg < end) {
+    idxwin_load<true>(win, a.idx, a.cinv, beg, end, lane);
+    fetch(beg);
+  }
+  const bool v0 = n < L, v1 = 16 + n < L;
+
+  for (int p0 = beg; p0 < end; p0 += 4) {
+#pragma unroll 1
+    for (int e = 0; e < 4; ++e) {
+      const int p = p0 + e;
+      if (p >= end) break;
+      pair_to_lds_tail<DH, FULL>(Qt, stash, e, qg, a.qscale, inv_next, L, lane);
+      // statistics of this edge's tokens 4g .. 4g+3: issued ahead of the tile loads of the next
+      // edge, needed only after the first 32 MFMAs
+      const float *sbm = a.stats + ((int64_t)p * a.H + h) * kStatsPerUnit;
+      const f32x4 l4 = *reinterpret_cast<const f32x4 *>(sbm + 4 * g);
+      const f32x4 d4 = *reinterpret_cast<const f32x4 *>(sbm + kLmax + 4 * g);
+      if (p + 1 < end) fetch(p + 1);
+      __builtin_amdgcn_wave_barrier();
+
+      // main tile: destination tokens 0..15 of this edge
+      f32x4 S0, S1, dP0, dP1;
+      S0 = S1 = dP0 = dP1 = f32x4{0.f, 0.f, 0.f, 0.f};
+      {
+        float qA[C::KK], gA[C::KK];
+        rowop_from_lds<DH>(qA, Qt, 0, lane);
+        rowop_from_lds<DH>(gA, Gt, 0, lane);
+#pragma unroll
+        for (int kk = 0; kk < C::KK; ++kk) {
+          S0 = MFMA16(qA[kk], kB[0][kk], S0);
+          S1 = MFMA16(qA[kk], kB[1][kk], S1);
+          dP0 = MFMA16(gA[kk], vB[0][kk], dP0);
+          dP1 = MFMA16(gA[kk], vB[1][kk], dP1);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float pa = v0 ? fast_exp2(S0[q] - l4[q]) : 0.f, pb = v1 ? fast_exp2(S1[q] - l4[q]) : 0.f;
+        S0[q] = pa;
+        S1[q] = pb;
+        dP0[q] = pa * (dP0[q] - d4[q]);          // dP now holds dS
+        dP1[q] = pb * (dP1[q] - d4[q]);
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int mc = 0; mc < C::MC; ++mc) {
+          const int idx = lds_idx<DH>(col_token(t, g), n + 16 * mc);
+          const float gC = Gt[idx], qC = Qt[idx];
+          dVT[mc][0] = MFMA16(gC, S0[t], dVT[mc][0]);
+          dVT[mc][1] = MFMA16(gC, S1[t], dVT[mc][1]);
+          dKT[mc][0] = MFMA16(qC, dP0[t], dKT[mc][0]);
+          dKT[mc][1] = MFMA16(qC, dP1[t], dKT[mc][1]);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+
+    // tail tile of the (up to) four edges p0 .. p0+3: lane group g <-> edge p0 + g
+    {
+      const bool live = p0 + g < end;
+      const int pe = live ? p0 + g : end - 1;
+      const float *sb = a.stats + ((int64_t)pe * a.H + h) * kStatsPerUnit;
+      const f32x4 l4 = *reinterpret_cast<const f32x4 *>(sb + 16);
+      const f32x4 d4 = *reinterpret_cast<const f32x4 *>(sb + kLmax + 16);
+      f32x4 S0, S1, dP0, dP1;
+      S0 = S1 = dP0 = dP1 = f32x4{0.f, 0.f, 0.f, 0.f};
+      {
+        // ROW operand: MFMA row m = lane & 15 <-> stash row of (edge m >> 2, token 16 + (m & 3))
+        const int rq = 8 * (n >> 2) + (n & 3), rg = rq + 4;
+        float qA[C::KK], gA[C::KK];
+#pragma unroll
+        for (int b = 0; b < C::KK / 4; ++b) {
+          const int chunk = (C::KK / 4) * g + b;
+          const float4 x = *reinterpret_cast<const float4 *>(stash + rq * DH + ((chunk ^ swz_tail<DH>(rq)) << 2));
+          const float4 y = *reinterpret_cast<const float4 *>(stash + rg * DH + ((chunk ^ swz_tail<DH>(rg)) << 2));
+          qA[4 * b + 0] = x.x; qA[4 * b + 1] = x.y; qA[4 * b + 2] = x.z; qA[4 * b + 3] = x.w;
+          gA[4 * b + 0] = y.x; gA[4 * b + 1] = y.y; gA[4 * b + 2] = y.z; gA[4 * b + 3] = y.w;
+        }
+#pragma unroll
+        for (int kk = 0; kk < C::KK; ++kk) {
+          S0 = MFMA16(qA[kk], kB[0][kk], S0);
+          S1 = MFMA16(qA[kk], kB[1][kk], S1);
+          dP0 = MFMA16(gA[kk], vB[0][kk], dP0);
+          dP1 = MFMA16(gA[kk], vB[1][kk], dP1);
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {       // C/D reg q of lane group g = token 16 + q of edge p0 + g
+        const float pa = (v0 && live) ? fast_exp2(S0[q] - l4[q]) : 0.f;
+        const float pb = (v1 && live) ? fast_exp2(S1[q] - l4[q]) : 0.f;
+        S0[q] = pa;
+        S1[q] = pb;
+        dP0[q] = pa * (dP0[q] - d4[q]);
+        dP1[q] = pb * (dP1[q] - d4[q]);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {       // k-slot g of step q: row 16 + q of edge g's tiles
+#pragma unroll
+        for (int mc = 0; mc < C::MC; ++mc) {
+          const float qC = stash[tail_idx<DH>(8 * g + q, n + 16 * mc)];
+          const float gC = stash[tail_idx<DH>(8 * g + 4 + q, n + 16 * mc)];
+          dVT[mc][0] = MFMA16(gC, S0[q], dVT[mc][0]);
+          dVT[mc][1] = MFMA16(gC, S1[q], dVT[mc][1]);
+          dKT[mc][0] = MFMA16(qC, dP0[q], dKT[mc][0]);
+          dKT[mc][1] = MFMA16(qC, dP1[q], dKT[mc][1]);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+
+  float *kb = tile_ptr<float>(a.dK, onode, h), *vb = tile_ptr<float>(a.dV, onode, h);
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int j = n + 16 * nt;
+    if (j < L) {
+#pragma unroll
+      for (int mc = 0; mc < C::MC; ++mc) {
+        float4 k4 = make_float4(dKT[mc][nt][0] * oscale, dKT[mc][nt][1] * oscale,
+                                dKT[mc][nt][2] * oscale, dKT[mc][nt][3] * oscale);
+        float4 v4 = make_float4(dVT[mc][nt][0], dVT[mc][nt][1], dVT[mc][nt][2], dVT[mc][nt][3]);
+        *reinterpret_cast<float4 *>(kb + (int64_t)j * a.dK.row_stride + 4 * g + 16 * mc) = k4;
+        *reinterpret_cast<float4 *>(vb + (int64_t)j * a.dV.row_stride + 4 * g + 16 * mc) = v4;
+      }
+    }
+  }
+}
+
 inline bool aligned16(const ampconv_view_t &v) {
   return ((uintptr_t)v.ptr % 16 == 0) && (v.node_stride % 4 == 0) && (v.row_stride % 4 == 0) &&
          (v.head_stride % 4 == 0);
@@ -597,7 +820,13 @@ int ampconv_bwd_edge_src_mfma(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t
   const int64_t blocks = (a.n_units + kWavesPerBlock - 1) / kWavesPerBlock;
   if (blocks > INT32_MAX) return AMPCONV_E_BADARG;
   const dim3 grid((unsigned)blocks), block(64 * kWavesPerBlock);
-  if (st.stats) {
+  static const bool t4 = !(std::getenv("AMPCONV_SRC_T4") && std::getenv("AMPCONV_SRC_T4")[0] == '0');
+  if (st.stats && t4) {
+    if (dh == 32 && L == kLmax) bwd_src_mfma_t4<32, true><<<grid, block, 0, stream>>>(a);
+    else if (dh == 32) bwd_src_mfma_t4<32, false><<<grid, block, 0, stream>>>(a);
+    else if (L == kLmax) bwd_src_mfma_t4<16, true><<<grid, block, 0, stream>>>(a);
+    else bwd_src_mfma_t4<16, false><<<grid, block, 0, stream>>>(a);
+  } else if (st.stats) {
     if (dh == 32 && L == kLmax) bwd_src_mfma<32, true, AMPCONV_PF_SRC, true><<<grid, block, 0, stream>>>(a);
     else if (dh == 32) bwd_src_mfma<32, false, 1, true><<<grid, block, 0, stream>>>(a);
     else if (L == kLmax) bwd_src_mfma<16, true, AMPCONV_PF_SRC, true><<<grid, block, 0, stream>>>(a);
