@@ -94,6 +94,8 @@ extern "C" int ampconv_fwd_edge(ampconv_view_t Q, ampconv_view_t K, ampconv_view
     return ampconv_fwd_edge_mfma(Q, K, V, rowptr, col, qidx, n_rows, L, D, H, O, HubArgs{nullptr, 0},
                                  (hipStream_t)stream);
   }
+  if (!force_generic() && ampconv_block_supported(L, D, H, views, 4))
+    return ampconv_fwd_edge_block(Q, K, V, rowptr, col, qidx, n_rows, L, D, H, O, (hipStream_t)stream);
   return ampconv_fwd_edge_generic(Q, K, V, rowptr, col, qidx, n_rows, L, D, H, O,
                                   (hipStream_t)stream);
 }
@@ -101,9 +103,12 @@ extern "C" int ampconv_fwd_edge(ampconv_view_t Q, ampconv_view_t K, ampconv_view
 extern "C" size_t ampconv_softmax_stats_bytes(int64_t E, int L, int D, int H, int dtype) {
   // bf16 storage keeps none: there the passes are HBM-bound and the extra 2 x 160 B per edge and
   // head cost the destination pass what they save the source pass (measured: +0.54 / -0.53 ms)
-  if (E <= 0 || check_common(L, D, H, dtype) != AMPCONV_OK || dtype == AMPCONV_BF16) return 0;
-  if (force_generic() || !ampconv_mfma_supported(L, D, H) || split_products(dtype, L, D, H)) return 0;
-  return (size_t)E * H * kStatsPerUnit * sizeof(float);
+  if (E <= 0 || check_common(L, D, H, dtype) != AMPCONV_OK || dtype == AMPCONV_BF16 || force_generic()) return 0;
+  if (ampconv_mfma_supported(L, D, H))
+    return split_products(dtype, L, D, H) ? 0 : (size_t)E * H * kStatsPerUnit * sizeof(float);
+  if (ampconv_block_supported(L, D, H, nullptr, 0))     // shapes of the workgroup-per-unit kernels
+    return (size_t)E * H * ampconv_block_stats_floats(L) * sizeof(float);
+  return 0;
 }
 
 extern "C" int ampconv_bwd_edge_dst(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
@@ -156,6 +161,9 @@ extern "C" int ampconv_bwd_edge_dst(ampconv_view_t Q, ampconv_view_t K, ampconv_
     return ampconv_bwd_edge_dst_mfma(Q, K, V, dObar, rowptr, col, n_rows, L, D, H, dQ,
                                      HubArgs{nullptr, 0}, sa, (hipStream_t)stream);
   }
+  // (a statistics buffer sized for the edge_mfma layout must not reach these kernels)
+  if (!force_generic() && ampconv_block_supported(L, D, H, views, 5) && !(stats && ampconv_mfma_supported(L, D, H)))
+    return ampconv_bwd_edge_dst_block(Q, K, V, dObar, rowptr, col, n_rows, L, D, H, dQ, sa, (hipStream_t)stream);
   if (stats) return AMPCONV_E_BADARG;     // this shape's kernels keep no statistics (ampconv_softmax_stats_bytes = 0)
   return ampconv_bwd_edge_dst_generic(Q, K, V, dObar, rowptr, col, n_rows, L, D, H, dQ,
                                       (hipStream_t)stream);
@@ -220,6 +228,10 @@ extern "C" int ampconv_bwd_edge_src(ampconv_view_t Q, ampconv_view_t K, ampconv_
     return ampconv_bwd_edge_src_mfma(Q, K, V, dObar, cscptr, crow, cinv, n_src, L, D, H, dK, dV,
                                      HubArgs{nullptr, 0}, sa, (hipStream_t)stream);
   }
+  // the workgroup-per-unit source pass exists only with the statistics; without them: generic kernels
+  if (stats && !force_generic() && ampconv_block_supported(L, D, H, views, 6) && !ampconv_mfma_supported(L, D, H))
+    return ampconv_bwd_edge_src_block(Q, K, V, dObar, cscptr, crow, cinv, n_src, L, D, H, dK, dV, stats,
+                                      (hipStream_t)stream);
   if (stats) return AMPCONV_E_BADARG;
   return ampconv_bwd_edge_src_generic(Q, K, V, dObar, cscptr, crow, cinv, n_src, L, D, H, dK,
                                       dV, (hipStream_t)stream);

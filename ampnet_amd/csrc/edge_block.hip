@@ -1,0 +1,494 @@
+// MFMA edge-phase kernels for the shapes edge_mfma.hip does not take: L <= 64 tokens, even
+// dh <= 64 (the reference's AMPGCN class defaults are L = 40, dh = 50: amp_gcn.py:23-26), fp32.
+//
+// One WORKGROUP owns one (row, head) unit; its ntok = ceil(L / 16) wavefronts share the LDS
+// images of the per-edge tiles and each owns one 16-token tile of the unit's own ("fixed") side:
+//   forward / dst pass: wave w <-> destination tokens 16w .. 16w+15 (columns of S^T = K Q^T); the
+//                       softmax runs along the source tokens = MFMA rows, inside the wave
+//   src pass          : wave w <-> source tokens 16w .. 16w+15 (columns of S = Q K^T); the softmax
+//                       would run across waves, so this pass takes P and delta from the statistics
+//                       the destination pass stored (include/ampconv.h): no cross-wave reduction
+// so no wave ever needs another wave's registers and every output tile has one owner (no atomics).
+// Tiles are zero-padded in LDS to 16 ntok rows x DHP in {32, 64} channels; products run on
+// v_mfma_f32_16x16x4_f32 (exact fp32) with the operand conventions of mfma_tile.h.
+// Reference arithmetic replaced: the same lines as edge_mfma.hip (torch functional.py:6578-6594,
+// amp_conv.py:11); backward per SURVEY.md A.2.
+#include "mfma_tile.h"
+
+namespace {
+
+constexpr float kLog2eB = 1.4426950408889634f;
+constexpr int kMaxTok = 4;       // 16-token tiles per node: L <= 64
+
+template <int DHP>
+__device__ __forceinline__ int bswz(int j) {
+  return DHP == 64 ? (j & 15) : swz<32>(j);
+}
+template <int DHP>
+__device__ __forceinline__ int bidx(int j, int c) {
+  return j * DHP + ((((c >> 2) ^ bswz<DHP>(j)) << 2) | (c & 3));
+}
+
+// ROW operand of token tile t from an LDS image: op[kk] = tile[16 t + m][KK ks + kk]
+template <int DHP>
+__device__ __forceinline__ void b_rowop_lds(float (&op)[DHP / 4], const float *lds, int t, int lane) {
+  constexpr int KK = DHP / 4;
+  const int m = lane & 15, ks = lane >> 4, j = 16 * t + m;
+#pragma unroll
+  for (int b = 0; b < KK / 4; ++b) {
+    const int chunk = (KK / 4) * ks + b;
+    const float4 x = *reinterpret_cast<const float4 *>(lds + j * DHP + ((chunk ^ bswz<DHP>(j)) << 2));
+    op[4 * b + 0] = x.x; op[4 * b + 1] = x.y; op[4 * b + 2] = x.z; op[4 * b + 3] = x.w;
+  }
+}
+// ROW operand of token tile t straight from global memory (the unit's fixed side), scaled;
+// token rows >= L and channels >= dh read as zero
+template <int DHP>
+__device__ __forceinline__ void b_rowop_global(float (&op)[DHP / 4], const float *base, int64_t row_stride,
+                                               int t, float mul, int L, int dh, int lane) {
+  constexpr int KK = DHP / 4;
+  const int m = lane & 15, ks = lane >> 4, j = 16 * t + m;
+#pragma unroll
+  for (int kk = 0; kk < KK; ++kk) {
+    const int c = KK * ks + kk;
+    op[kk] = (j < L && c < dh) ? base[(int64_t)j * row_stride + c] * mul : 0.f;
+  }
+}
+
+// ---- cooperative staging of two [L x dh] tiles (A then B) global -> registers -> LDS images.
+// Thread (r0 = tid / DVP, cv = tid % DVP) owns vector column cv (VEC floats) of rows r0 + i RS.
+template <int DHP, int VEC>
+struct Stage {
+  static constexpr int DVP = DHP / VEC;       // vector slots per padded row
+  static constexpr int NP = DVP / 4;          // passes per tensor: 16 ntok / (64 ntok / DVP)
+  float v[2][NP][VEC];
+};
+
+template <int DHP, int VEC>
+__device__ __forceinline__ void stage_load(Stage<DHP, VEC> &s, const float *baseA, int64_t strideA,
+                                           const float *baseB, int64_t strideB, int L, int dh, int tid,
+                                           int nthreads) {
+  using S = Stage<DHP, VEC>;
+  const int cv = tid % S::DVP, r0 = tid / S::DVP, RS = nthreads / S::DVP, c = cv * VEC;
+#pragma unroll
+  for (int i = 0; i < S::NP; ++i) {
+    const int j = r0 + i * RS;
+    if (j < L && c < dh) {
+      const float *pa = baseA + (int64_t)j * strideA + c, *pb = baseB + (int64_t)j * strideB + c;
+      if constexpr (VEC == 4) {
+        const float4 x = *reinterpret_cast<const float4 *>(pa), y = *reinterpret_cast<const float4 *>(pb);
+        s.v[0][i][0] = x.x; s.v[0][i][1] = x.y; s.v[0][i][2] = x.z; s.v[0][i][3] = x.w;
+        s.v[1][i][0] = y.x; s.v[1][i][1] = y.y; s.v[1][i][2] = y.z; s.v[1][i][3] = y.w;
+      } else {
+        const float2 x = *reinterpret_cast<const float2 *>(pa), y = *reinterpret_cast<const float2 *>(pb);
+        s.v[0][i][0] = x.x; s.v[0][i][1] = x.y;
+        s.v[1][i][0] = y.x; s.v[1][i][1] = y.y;
+      }
+    }
+  }
+}
+
+template <int DHP, int VEC>
+__device__ __forceinline__ void stage_store(float *ldsA, float *ldsB, const Stage<DHP, VEC> &s, float mulA,
+                                            float mulB, int L, int dh, int tid, int nthreads) {
+  using S = Stage<DHP, VEC>;
+  const int cv = tid % S::DVP, r0 = tid / S::DVP, RS = nthreads / S::DVP, c = cv * VEC;
+#pragma unroll
+  for (int i = 0; i < S::NP; ++i) {
+    const int j = r0 + i * RS;
+    if (j < L && c < dh) {
+      const int o = bidx<DHP>(j, c);
+      if constexpr (VEC == 4) {
+        *reinterpret_cast<float4 *>(ldsA + o) = make_float4(s.v[0][i][0] * mulA, s.v[0][i][1] * mulA,
+                                                             s.v[0][i][2] * mulA, s.v[0][i][3] * mulA);
+        *reinterpret_cast<float4 *>(ldsB + o) = make_float4(s.v[1][i][0] * mulB, s.v[1][i][1] * mulB,
+                                                             s.v[1][i][2] * mulB, s.v[1][i][3] * mulB);
+      } else {
+        *reinterpret_cast<float2 *>(ldsA + o) = make_float2(s.v[0][i][0] * mulA, s.v[0][i][1] * mulA);
+        *reinterpret_cast<float2 *>(ldsB + o) = make_float2(s.v[1][i][0] * mulB, s.v[1][i][1] * mulB);
+      }
+    }
+  }
+}
+
+// C/D tile [channel tile mc][this wave's token tile] -> global rows of `v` (channels < dh, tokens < L)
+template <int DHP, int VEC>
+__device__ __forceinline__ void store_ct(const ampconv_view_t &v, int64_t node, int h, const f32x4 (&T)[DHP / 16],
+                                         float scale, int tile, int L, int dh, int lane) {
+  const int i = (lane & 15) + 16 * tile, g = lane >> 4;
+  if (i >= L) return;
+  float *ob = tile_ptr<float>(v, node, h) + (int64_t)i * v.row_stride;
+#pragma unroll
+  for (int mc = 0; mc < DHP / 16; ++mc) {
+    const int c = 4 * g + 16 * mc;
+    if constexpr (VEC == 4) {
+      if (c < dh)
+        *reinterpret_cast<float4 *>(ob + c) = make_float4(T[mc][0] * scale, T[mc][1] * scale, T[mc][2] * scale,
+                                                          T[mc][3] * scale);
+    } else {
+      if (c < dh) *reinterpret_cast<float2 *>(ob + c) = make_float2(T[mc][0] * scale, T[mc][1] * scale);
+      if (c + 2 < dh) *reinterpret_cast<float2 *>(ob + c + 2) = make_float2(T[mc][2] * scale, T[mc][3] * scale);
+    }
+  }
+}
+
+struct BArgs {
+  ampconv_view_t Q, K, V, dO, O, dK, dV;     // O = forward output / dQ
+  const int32_t *ptr, *idx, *qidx;
+  const float *cinv;
+  const int32_t *spos;
+  float *stats;
+  int64_t n_units;
+  int L, dh, H, ntok;
+  float qscale, oscale;
+};
+
+// softmax over the source tokens (MFMA rows of every token tile t < ntok) of one destination-token
+// column; returns m + log2(sum).  S[t][q] = source token 16 t + 4 g + q.
+__device__ __forceinline__ float block_column_softmax(f32x4 (&S)[kMaxTok], int ntok, int L, int g) {
+  float m = kNegBig;
+#pragma unroll
+  for (int t = 0; t < kMaxTok; ++t)
+    if (t < ntok) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (16 * t + 4 * g + q >= L) S[t][q] = kNegBig;
+        m = fmaxf(m, S[t][q]);
+      }
+    }
+  m = groups_max(m);
+  float l = 0.f;
+#pragma unroll
+  for (int t = 0; t < kMaxTok; ++t)
+    if (t < ntok) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        S[t][q] = fast_exp2(S[t][q] - m);
+        l += S[t][q];
+      }
+    }
+  l = groups_sum(l);
+  const float inv = fast_rcp(l);
+#pragma unroll
+  for (int t = 0; t < kMaxTok; ++t)
+    if (t < ntok) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) S[t][q] *= inv;
+    }
+  return m + __builtin_amdgcn_logf(l);
+}
+
+// ---------------------------------------------------------------- forward
+template <int DHP, int VEC>
+__global__ __launch_bounds__(256) void fwd_block(BArgs a) {
+  constexpr int KK = DHP / 4, MC = DHP / 16;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t r = blockIdx.x / a.H;
+  const int h = blockIdx.x % a.H;
+  const int L = a.L, dh = a.dh, ntok = a.ntok, g = lane >> 4;
+  const int beg = a.ptr[r], end = a.ptr[r + 1], deg = end - beg;
+  float *Kt = lds, *Vt = lds + 16 * ntok * DHP;
+  const int64_t d = a.qidx ? a.qidx[r] : r;
+
+  float qB[KK];
+  b_rowop_global<DHP>(qB, tile_ptr<const float>(a.Q, d, h), a.Q.row_stride, wave, a.qscale, L, dh, lane);
+  for (int i = tid; i < 2 * 16 * ntok * DHP; i += nthreads) lds[i] = 0.f;     // padding stays zero
+  f32x4 OT[MC];
+#pragma unroll
+  for (int mc = 0; mc < MC; ++mc) OT[mc] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  Stage<DHP, VEC> st;
+  IdxWindow win;
+  auto fetch = [&](int p) {
+    const int64_t s = idxwin_get<false>(win, a.idx, nullptr, p, end, lane, nullptr);
+    stage_load<DHP, VEC>(st, tile_ptr<const float>(a.K, s, h), a.K.row_stride,
+                         tile_ptr<const float>(a.V, s, h), a.V.row_stride, L, dh, tid, nthreads);
+  };
+  if (beg < end) {
+    idxwin_load<false>(win, a.idx, nullptr, beg, end, lane);
+    fetch(beg);
+  }
+  __syncthreads();
+  for (int p = beg; p < end; ++p) {
+    stage_store<DHP, VEC>(Kt, Vt, st, 1.f, 1.f, L, dh, tid, nthreads);
+    if (p + 1 < end) fetch(p + 1);
+    __syncthreads();
+
+    f32x4 S[kMaxTok];
+#pragma unroll
+    for (int t = 0; t < kMaxTok; ++t)
+      if (t < ntok) {
+        float kA[KK];
+        b_rowop_lds<DHP>(kA, Kt, t, lane);
+        S[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) S[t] = MFMA16(kA[kk], qB[kk], S[t]);
+      }
+    block_column_softmax(S, ntok, L, g);
+#pragma unroll
+    for (int t = 0; t < kMaxTok; ++t)
+      if (t < ntok) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+          for (int mc = 0; mc < MC; ++mc) {
+            const float vA = Vt[bidx<DHP>(16 * t + 4 * g + q, (lane & 15) + 16 * mc)];
+            OT[mc] = MFMA16(vA, S[t][q], OT[mc]);
+          }
+        }
+      }
+    __syncthreads();
+  }
+  store_ct<DHP, VEC>(a.O, r, h, OT, deg > 0 ? 1.f / (float)deg : 0.f, wave, L, dh, lane);
+}
+
+// ---------------------------------------------------------------- backward, destination pass
+template <int DHP, int VEC, bool STATS>
+__global__ __launch_bounds__(256) void bwd_dst_block(BArgs a) {
+  constexpr int KK = DHP / 4, MC = DHP / 16;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t r = blockIdx.x / a.H;
+  const int h = blockIdx.x % a.H;
+  const int L = a.L, dh = a.dh, ntok = a.ntok, g = lane >> 4;
+  const int beg = a.ptr[r], end = a.ptr[r + 1], deg = end - beg;
+  float *Kt = lds, *Vt = lds + 16 * ntok * DHP;
+  const float inv = deg > 0 ? 1.f / (float)deg : 0.f;       // dO is the gradient of the MEAN
+
+  float qB[KK], gB[KK];
+  b_rowop_global<DHP>(qB, tile_ptr<const float>(a.Q, r, h), a.Q.row_stride, wave, a.qscale, L, dh, lane);
+  b_rowop_global<DHP>(gB, tile_ptr<const float>(a.dO, r, h), a.dO.row_stride, wave, inv, L, dh, lane);
+  for (int i = tid; i < 2 * 16 * ntok * DHP; i += nthreads) lds[i] = 0.f;
+  f32x4 dQT[MC];
+#pragma unroll
+  for (int mc = 0; mc < MC; ++mc) dQT[mc] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  Stage<DHP, VEC> st;
+  IdxWindow win;
+  float pos_next = 0.f;                      // STATS: CSC position (int bits) in the window's weight slot
+  const float *wts = reinterpret_cast<const float *>(a.spos);
+  auto fetch = [&](int p) {
+    const int64_t s = idxwin_get<STATS>(win, a.idx, wts, p, end, lane, &pos_next);
+    stage_load<DHP, VEC>(st, tile_ptr<const float>(a.K, s, h), a.K.row_stride,
+                         tile_ptr<const float>(a.V, s, h), a.V.row_stride, L, dh, tid, nthreads);
+  };
+  if (beg < end) {
+    idxwin_load<STATS>(win, a.idx, wts, beg, end, lane);
+    fetch(beg);
+  }
+  __syncthreads();
+  const int LS = 16 * ntok;
+  for (int p = beg; p < end; ++p) {
+    stage_store<DHP, VEC>(Kt, Vt, st, 1.f, 1.f, L, dh, tid, nthreads);
+    float *sb = nullptr;
+    if (STATS) sb = a.stats + ((int64_t)__builtin_bit_cast(int, pos_next) * a.H + h) * (2 * LS);
+    if (p + 1 < end) fetch(p + 1);
+    __syncthreads();
+
+    f32x4 S[kMaxTok], dP[kMaxTok];
+#pragma unroll
+    for (int t = 0; t < kMaxTok; ++t)
+      if (t < ntok) {
+        float kA[KK], vA[KK];
+        b_rowop_lds<DHP>(kA, Kt, t, lane);
+        b_rowop_lds<DHP>(vA, Vt, t, lane);
+        S[t] = dP[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) {
+          S[t] = MFMA16(kA[kk], qB[kk], S[t]);
+          dP[t] = MFMA16(vA[kk], gB[kk], dP[t]);
+        }
+      }
+    const float lse = block_column_softmax(S, ntok, L, g);
+    float part = 0.f;
+#pragma unroll
+    for (int t = 0; t < kMaxTok; ++t)
+      if (t < ntok) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) part = fmaf(S[t][q], dP[t][q], part);
+      }
+    const float delta = groups_sum(part);
+    if (STATS && g == 0) {                   // all LS columns: the source pass reads every one
+      sb[(lane & 15) + 16 * wave] = lse;
+      sb[LS + (lane & 15) + 16 * wave] = delta;
+    }
+#pragma unroll
+    for (int t = 0; t < kMaxTok; ++t)
+      if (t < ntok) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float dS = S[t][q] * (dP[t][q] - delta);
+#pragma unroll
+          for (int mc = 0; mc < MC; ++mc) {
+            const float kC = Kt[bidx<DHP>(16 * t + 4 * g + q, (lane & 15) + 16 * mc)];
+            dQT[mc] = MFMA16(kC, dS, dQT[mc]);
+          }
+        }
+      }
+    __syncthreads();
+  }
+  store_ct<DHP, VEC>(a.O, r, h, dQT, a.oscale, wave, L, dh, lane);
+}
+
+// ---------------------------------------------------------------- backward, source pass (needs the statistics)
+template <int DHP, int VEC>
+__global__ __launch_bounds__(256) void bwd_src_block(BArgs a) {
+  constexpr int KK = DHP / 4, MC = DHP / 16;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t s = blockIdx.x / a.H;
+  const int h = blockIdx.x % a.H;
+  const int L = a.L, dh = a.dh, ntok = a.ntok, g = lane >> 4, n = lane & 15;
+  const int beg = a.ptr[s], end = a.ptr[s + 1];
+  float *Qt = lds, *Gt = lds + 16 * ntok * DHP;
+
+  float kB[KK], vB[KK];
+  b_rowop_global<DHP>(kB, tile_ptr<const float>(a.K, s, h), a.K.row_stride, wave, 1.f, L, dh, lane);
+  b_rowop_global<DHP>(vB, tile_ptr<const float>(a.V, s, h), a.V.row_stride, wave, 1.f, L, dh, lane);
+  for (int i = tid; i < 2 * 16 * ntok * DHP; i += nthreads) lds[i] = 0.f;
+  f32x4 dKT[MC], dVT[MC];
+#pragma unroll
+  for (int mc = 0; mc < MC; ++mc) dKT[mc] = dVT[mc] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  Stage<DHP, VEC> st;
+  IdxWindow win;
+  float inv_next = 0.f;
+  auto fetch = [&](int p) {
+    const int64_t d = idxwin_get<true>(win, a.idx, a.cinv, p, end, lane, &inv_next);
+    stage_load<DHP, VEC>(st, tile_ptr<const float>(a.Q, d, h), a.Q.row_stride,
+                         tile_ptr<const float>(a.dO, d, h), a.dO.row_stride, L, dh, tid, nthreads);
+  };
+  if (beg < end) {
+    idxwin_load<true>(win, a.idx, a.cinv, beg, end, lane);
+    fetch(beg);
+  }
+  __syncthreads();
+  const int LS = 16 * ntok;
+  const bool colok = n + 16 * wave < L;      // this lane's source token exists
+  for (int p = beg; p < end; ++p) {
+    stage_store<DHP, VEC>(Qt, Gt, st, a.qscale, inv_next, L, dh, tid, nthreads);
+    const float *sb = a.stats + ((int64_t)p * a.H + h) * (2 * LS);
+    if (p + 1 < end) fetch(p + 1);
+    __syncthreads();
+
+#pragma unroll
+    for (int t = 0; t < kMaxTok; ++t)
+      if (t < ntok) {                        // destination tokens 16 t + 4 g + q
+        const f32x4 l4 = *reinterpret_cast<const f32x4 *>(sb + 16 * t + 4 * g);
+        const f32x4 d4 = *reinterpret_cast<const f32x4 *>(sb + LS + 16 * t + 4 * g);
+        f32x4 S = f32x4{0.f, 0.f, 0.f, 0.f}, dP = f32x4{0.f, 0.f, 0.f, 0.f};
+        {
+          float qA[KK], gA[KK];
+          b_rowop_lds<DHP>(qA, Qt, t, lane);
+          b_rowop_lds<DHP>(gA, Gt, t, lane);
+#pragma unroll
+          for (int kk = 0; kk < KK; ++kk) {
+            S = MFMA16(qA[kk], kB[kk], S);
+            dP = MFMA16(gA[kk], vB[kk], dP);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float pr = colok ? fast_exp2(S[q] - l4[q]) : 0.f;
+          const float dS = pr * (dP[q] - d4[q]);
+#pragma unroll
+          for (int mc = 0; mc < MC; ++mc) {
+            const int idx = bidx<DHP>(16 * t + 4 * g + q, n + 16 * mc);
+            dVT[mc] = MFMA16(Gt[idx], pr, dVT[mc]);
+            dKT[mc] = MFMA16(Qt[idx], dS, dKT[mc]);
+          }
+        }
+      }
+    __syncthreads();
+  }
+  store_ct<DHP, VEC>(a.dK, s, h, dKT, a.oscale, wave, L, dh, lane);
+  store_ct<DHP, VEC>(a.dV, s, h, dVT, 1.f, wave, L, dh, lane);
+}
+
+inline int vec_of(const ampconv_view_t *views, int n, int dh) {
+  int vec = dh % 4 == 0 ? 4 : 2;
+  for (int i = 0; i < n; ++i) {
+    const ampconv_view_t &v = views[i];
+    while (vec > 1 && (((uintptr_t)v.ptr % (4 * vec)) || v.node_stride % vec || v.row_stride % vec ||
+                       v.head_stride % vec))
+      vec >>= 1;
+  }
+  return vec;
+}
+
+template <typename K4, typename K2>
+int launch_block(const BArgs &a, int dhp, int vec, K4 k64v4, K2 k64v2, K4 k32v4, K2 k32v2, hipStream_t stream) {
+  if (a.n_units > INT32_MAX) return AMPCONV_E_BADARG;
+  const dim3 grid((unsigned)a.n_units), block(64 * a.ntok);
+  const size_t shmem = (size_t)2 * 16 * a.ntok * dhp * sizeof(float);
+  if (dhp == 64) {
+    if (vec == 4) k64v4<<<grid, block, shmem, stream>>>(a); else k64v2<<<grid, block, shmem, stream>>>(a);
+  } else {
+    if (vec == 4) k32v4<<<grid, block, shmem, stream>>>(a); else k32v2<<<grid, block, shmem, stream>>>(a);
+  }
+  return ampconv_launch_status();
+}
+
+BArgs base_args(int64_t n_rows, int L, int D, int H) {
+  BArgs a{};
+  a.L = L; a.dh = D / H; a.H = H; a.ntok = (L + 15) / 16;
+  a.n_units = n_rows * H;
+  a.qscale = kLog2eB / sqrtf((float)a.dh);
+  return a;
+}
+
+}  // namespace
+
+bool ampconv_block_supported(int L, int D, int H, const ampconv_view_t *views, int n) {
+  const int dh = D / H;
+  if (!(L >= 1 && L <= 16 * kMaxTok && dh >= 2 && dh <= 64 && dh % 2 == 0)) return false;
+  return vec_of(views, n, dh) >= 2;
+}
+
+int ampconv_block_stats_floats(int L) { return 2 * 16 * ((L + 15) / 16); }
+
+int ampconv_fwd_edge_block(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V, const int32_t *rowptr,
+                           const int32_t *col, const int32_t *qidx, int64_t n_rows, int L, int D, int H,
+                           ampconv_view_t O, hipStream_t stream) {
+  BArgs a = base_args(n_rows, L, D, H);
+  a.Q = Q; a.K = K; a.V = V; a.O = O;
+  a.ptr = rowptr; a.idx = col; a.qidx = qidx;
+  const ampconv_view_t views[] = {Q, K, V, O};
+  const int vec = vec_of(views, 4, a.dh), dhp = a.dh > 32 ? 64 : 32;
+  return launch_block(a, dhp, vec, fwd_block<64, 4>, fwd_block<64, 2>, fwd_block<32, 4>, fwd_block<32, 2>, stream);
+}
+
+int ampconv_bwd_edge_dst_block(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V, ampconv_view_t dO,
+                               const int32_t *rowptr, const int32_t *col, int64_t n_rows, int L, int D, int H,
+                               ampconv_view_t dQ, StatsArgs sa, hipStream_t stream) {
+  BArgs a = base_args(n_rows, L, D, H);
+  a.Q = Q; a.K = K; a.V = V; a.dO = dO; a.O = dQ;
+  a.ptr = rowptr; a.idx = col; a.spos = sa.spos; a.stats = sa.stats;
+  a.oscale = 1.f / sqrtf((float)a.dh);
+  const ampconv_view_t views[] = {Q, K, V, dO, dQ};
+  const int vec = vec_of(views, 5, a.dh), dhp = a.dh > 32 ? 64 : 32;
+  if (sa.stats)
+    return launch_block(a, dhp, vec, bwd_dst_block<64, 4, true>, bwd_dst_block<64, 2, true>,
+                        bwd_dst_block<32, 4, true>, bwd_dst_block<32, 2, true>, stream);
+  return launch_block(a, dhp, vec, bwd_dst_block<64, 4, false>, bwd_dst_block<64, 2, false>,
+                      bwd_dst_block<32, 4, false>, bwd_dst_block<32, 2, false>, stream);
+}
+
+int ampconv_bwd_edge_src_block(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V, ampconv_view_t dO,
+                               const int32_t *cscptr, const int32_t *crow, const float *cinv, int64_t n_src,
+                               int L, int D, int H, ampconv_view_t dK, ampconv_view_t dV, const float *stats,
+                               hipStream_t stream) {
+  if (!stats) return AMPCONV_E_BADARG;
+  BArgs a = base_args(n_src, L, D, H);
+  a.Q = Q; a.K = K; a.V = V; a.dO = dO; a.dK = dK; a.dV = dV;
+  a.ptr = cscptr; a.idx = crow; a.cinv = cinv; a.stats = const_cast<float *>(stats);
+  a.oscale = 0.6931471805599453f;       // dK = ln2 * sum dS^T (Q * log2e / sqrt(dh))
+  const ampconv_view_t views[] = {Q, K, V, dO, dK, dV};
+  const int vec = vec_of(views, 6, a.dh), dhp = a.dh > 32 ? 64 : 32;
+  return launch_block(a, dhp, vec, bwd_src_block<64, 4>, bwd_src_block<64, 2>, bwd_src_block<32, 4>,
+                      bwd_src_block<32, 2>, stream);
+}

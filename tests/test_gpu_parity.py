@@ -482,15 +482,23 @@ def test_training_steps_match_cpu_reference(dev):
         torch.testing.assert_close(b.detach().cpu(), a.detach(), rtol=1e-3, atol=2e-5, msg=lambda m: f'{n}: {m}')
 
 
+@pytest.mark.parametrize('family', ['wave', 'block'])
 @pytest.mark.parametrize('seed', range(10))
-def test_random_shapes_mfma_vs_generic(seed, dev, monkeypatch):
-    """Random small problems (L in 1..20, dh in {16, 32}, H in 1..16, degenerate graphs included):
-    the MFMA kernels and the independent shape-generic kernels must agree on y and every gradient."""
+def test_random_shapes_mfma_vs_generic(seed, family, dev, monkeypatch):
+    """Random small problems, degenerate graphs included: the MFMA kernels and the independent
+    shape-generic kernels must agree on y and every gradient.  'wave' = edge_mfma.hip shapes
+    (L in 1..20, dh in {16, 32}), 'block' = edge_block.hip shapes (L in 1..64, even dh <= 64,
+    e.g. the reference's class defaults L = 40, dh = 50)."""
     from ampnet_amd import AMPConv, graph_cache
-    rng = np.random.default_rng(1000 + seed)
-    dh = int(rng.choice([16, 32]))
-    H = int(rng.choice([1, 2, 3, 4, 8, 16]))
-    L = int(rng.integers(1, 21))
+    rng = np.random.default_rng(1000 + seed + (500 if family == 'block' else 0))
+    if family == 'wave':
+        dh = int(rng.choice([16, 32]))
+        H = int(rng.choice([1, 2, 3, 4, 8, 16]))
+        L = int(rng.integers(1, 21))
+    else:
+        dh = int(rng.choice([2, 6, 10, 20, 34, 48, 50, 64]))
+        H = int(rng.choice([1, 2, 3, 4]))
+        L = int(rng.integers(1, 65)) if seed % 2 else int(rng.integers(21, 65))
     D = dh * H
     N = int(rng.integers(1, 400))
     kind = seed % 5
@@ -569,6 +577,8 @@ def test_softmax_stats_rejected_where_unsupported(dev):
     # shapes on the generic kernels keep no statistics: size query says 0, passing a buffer is an error
     from ampnet_amd import _lib
     lib = _lib.load()
-    assert lib.ampconv_softmax_stats_bytes(1000, 40, 100, 2, _lib.AMPCONV_F32) == 0
+    assert lib.ampconv_softmax_stats_bytes(1000, 70, 100, 2, _lib.AMPCONV_F32) == 0       # L > 64
+    assert lib.ampconv_softmax_stats_bytes(1000, 2, 3, 1, _lib.AMPCONV_F32) == 0          # odd dh
+    assert lib.ampconv_softmax_stats_bytes(1000, 40, 100, 2, _lib.AMPCONV_F32) == 1000 * 2 * 2 * 48 * 4   # edge_block.hip
     assert lib.ampconv_softmax_stats_bytes(1000, 20, 256, 8, _lib.AMPCONV_BF16) == 0      # HBM-bound: no gain
     assert lib.ampconv_softmax_stats_bytes(1000, 20, 256, 8, _lib.AMPCONV_F32_BF16X6) == 0
