@@ -159,6 +159,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--workload', default=os.environ.get('AMPCONV_BENCH_WORKLOAD', 'cfg4'))
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-alt-gemm', action='store_true', help='skip the extra bf16x3-GEMM pass (profiling runs)')
     ap.add_argument('--dtype', default=None, choices=['f32', 'bf16'],
                     help='storage dtype (default: f32; bf16 for cfg5)')
     ap.add_argument('--gemm', default='fp32', choices=['fp32', 'bf16x3'],
@@ -239,7 +240,7 @@ def main():
     dt = float(tmax.item())
 
     alt = None
-    if world == 1 and dt_name == 'f32' and args.gemm == 'fp32':
+    if world == 1 and dt_name == 'f32' and args.gemm == 'fp32' and not args.no_alt_gemm:
         # same step with the projections on hipBLASLt's bf16x3 path -- reported beside, never as `value`
         layer.gemm_precision = 'bf16x3'
         step()
