@@ -21,6 +21,7 @@ import torch.nn as nn
 from .. import _lib
 from ..graph import EdgeCSR, graph_cache
 from . import functional as F_
+from . import linear as FL_
 
 try:                                            # PyG is optional (absent in the build image)
     from torch_geometric.nn import MessagePassing as _PyGMessagePassing
@@ -49,8 +50,11 @@ MessagePassing = _PyGMessagePassing if _PyGMessagePassing is not None else _Mess
 
 
 class AMPConv(MessagePassing):
-    def __init__(self, embed_dim, num_heads):
+    def __init__(self, embed_dim, num_heads, softmax=True):
+        """softmax=False: the reference's softmax-free attention (its custom_multihead_attn.py copy,
+        amp_conv.py:6,17; conv/linear.py here) -- same parameters and state-dict keys."""
         super().__init__(aggr='mean')
+        self.softmax = bool(softmax)
         self._attn_ctx = None
         self._attn_output = None
         self._attn_output_weights = None
@@ -83,6 +87,10 @@ class AMPConv(MessagePassing):
         if p.device != x.device:
             raise ValueError(f'parameters are on {p.device} but {name} is on {x.device}')
 
+    def _check_linear(self, x):
+        if x.dtype != torch.float32:
+            raise ValueError('the softmax-free variant runs in float32 only')
+
     def _params(self):
         m = self.multi_head_attention
         return m.in_proj_weight, m.in_proj_bias, m.out_proj.weight, m.out_proj.bias
@@ -100,8 +108,13 @@ class AMPConv(MessagePassing):
         if edge_index.device != x.device:
             raise ValueError(f'edge_index is on {edge_index.device} but x is on {x.device}')
         csr = graph_cache.get(edge_index, x.size(0))
-        y, qkv, _ = F_.AMPConvFunction.apply(x, x, *self._params(), csr, self.num_heads, True,
-                                             _lib.PRECISIONS[self.precision], self.gemm_precision)
+        if self.softmax:
+            y, qkv, _ = F_.AMPConvFunction.apply(x, x, *self._params(), csr, self.num_heads, True,
+                                                 _lib.PRECISIONS[self.precision], self.gemm_precision)
+        else:
+            self._check_linear(x)
+            y, qkv, _ = FL_.LinearAMPConvFunction.apply(x, x, *self._params(), csr, self.num_heads, True,
+                                                        self.gemm_precision)
         L = x.size(1) // self.embed_dim
         self._set_attn_ctx(qkv, None, edge_index, L, shared=True)
         return y
@@ -115,8 +128,13 @@ class AMPConv(MessagePassing):
             raise ValueError(f'x_i {tuple(x_i.shape)} and x_j {tuple(x_j.shape)} differ')
         E = x_i.size(0)
         csr = EdgeCSR.identity(E, x_i.device)
-        y, q, kv = F_.AMPConvFunction.apply(x_i, x_j, *self._params(), csr, self.num_heads, False,
-                                            _lib.PRECISIONS[self.precision], self.gemm_precision)
+        if self.softmax:
+            y, q, kv = F_.AMPConvFunction.apply(x_i, x_j, *self._params(), csr, self.num_heads, False,
+                                                _lib.PRECISIONS[self.precision], self.gemm_precision)
+        else:
+            self._check_linear(x_i)
+            y, q, kv = FL_.LinearAMPConvFunction.apply(x_i, x_j, *self._params(), csr, self.num_heads, False,
+                                                       self.gemm_precision)
         ar = torch.arange(E, dtype=torch.int64, device=x_i.device)
         L = x_i.size(1) // self.embed_dim
         self._set_attn_ctx(q, kv, torch.stack([ar, ar]), L, shared=False)
@@ -162,8 +180,9 @@ class AMPConv(MessagePassing):
         token `col`, mean over heads, original edge order (amp_conv.py:43-47)."""
         if self._attn_output_weights is None and self._attn_ctx is not None:
             Qv, Kv, _, edge_index, L = self._attn_views()
-            self._attn_output_weights = F_.attention_weights(
-                Qv, Kv, edge_index.contiguous(), L, self.embed_dim, self.num_heads)
+            weights = F_.attention_weights if self.softmax else FL_.attention_scores
+            self._attn_output_weights = weights(Qv, Kv, edge_index.contiguous(), L, self.embed_dim,
+                                                self.num_heads)
         return self._attn_output_weights
 
     @attn_output_weights.setter
@@ -177,6 +196,9 @@ class AMPConv(MessagePassing):
             Qv, Kv, Vv, edge_index, L = self._attn_views()
             D, H = self.embed_dim, self.num_heads
             E = edge_index.size(1)
+            if not self.softmax:
+                self._attn_output = self._linear_attn_output(edge_index, L)
+                return self._attn_output
             ident = EdgeCSR.identity(E, edge_index.device)
             ident.col = edge_index[0].to(torch.int32).contiguous()
             qidx = edge_index[1].to(torch.int32).contiguous()
@@ -189,6 +211,28 @@ class AMPConv(MessagePassing):
                 self._attn_output = torch.addmm(m.out_proj.bias.float(), o,
                                                 m.out_proj.weight.float().t()).view(E, L, D)
         return self._attn_output
+
+    def _linear_attn_output(self, edge_index, L):
+        """Per-edge output of the softmax-free variant, [E, L, D]: Q_d (K_s^T V_s) / sqrt(dh), then the
+        out-projection (a diagnostic for small graphs, like the reference's E-sized attribute)."""
+        q_buf, kv_buf, _, _, shared = self._attn_ctx
+        D, H = self.embed_dim, self.num_heads
+        dh = D // H
+        src, dst = edge_index[0], edge_index[1]
+        with torch.no_grad():
+            if shared:
+                N = q_buf.size(0) // L
+                q = q_buf[:, :D].reshape(N, L, H, dh)[dst]
+                k = q_buf[:, D:2 * D].reshape(N, L, H, dh)[src]
+                v = q_buf[:, 2 * D:].reshape(N, L, H, dh)[src]
+            else:
+                E = edge_index.size(1)
+                q = q_buf.reshape(E, L, H, dh)
+                k, v = kv_buf[:, :D].reshape(E, L, H, dh), kv_buf[:, D:].reshape(E, L, H, dh)
+            m = torch.einsum('elhi,elhj->ehij', k, v)
+            o = torch.einsum('elhi,ehij->elhj', q, m).reshape(-1, D) / (dh ** 0.5)
+            mha = self.multi_head_attention
+            return torch.addmm(mha.out_proj.bias, o, mha.out_proj.weight.t()).view(-1, L, D)
 
     @attn_output.setter
     def attn_output(self, value):

@@ -34,6 +34,7 @@ struct WArgs {
   float *W;
   int L, dh, dhp, H;
   float scale;
+  int linear;     // 1: raw scaled scores (the reference's softmax-free variant), 0: softmax
 };
 
 __device__ __forceinline__ void load_tile(float *dst, const float *src, int L, int dh, int dhp,
@@ -213,7 +214,16 @@ __global__ __launch_bounds__(AMPCONV_WAVE) void attn_weights_generic(WArgs a) {
     load_tile(Ks, tile_ptr<const float>(a.K, s, h), L, dh, dhp, a.K.row_stride, 1.f, lane);
     __syncthreads();
     for (int i = 0; i < L; ++i) {
-      softmax_row(Qs + i * dhp, Ks, P, L, dh, dhp, lane);
+      if (a.linear) {
+        for (int j = lane; j < L; j += AMPCONV_WAVE) {
+          float sc = 0.f;
+          for (int c = 0; c < dh; ++c) sc = fmaf(Qs[i * dhp + c], Ks[j * dhp + c], sc);
+          P[j] = sc;
+        }
+        __syncthreads();
+      } else {
+        softmax_row(Qs + i * dhp, Ks, P, L, dh, dhp, lane);
+      }
       for (int j = lane; j < L; j += AMPCONV_WAVE) {
         float w = P[j] * invH;
         if (h > 0) w += W[i * L + j];
@@ -297,15 +307,28 @@ int ampconv_bwd_edge_src_generic(ampconv_view_t Q, ampconv_view_t K, ampconv_vie
   return ampconv_launch_status();
 }
 
+static int attn_weights_impl(ampconv_view_t Q, ampconv_view_t K, const int64_t *edge_index, int64_t E, int L,
+                             int D, int H, float *W, int dtype, int linear, void *stream);
+
 extern "C" int ampconv_attn_weights(ampconv_view_t Q, ampconv_view_t K, const int64_t *edge_index,
                                     int64_t E, int L, int D, int H, float *W, int dtype,
                                     void *stream) {
+  return attn_weights_impl(Q, K, edge_index, E, L, D, H, W, dtype, 0, stream);
+}
+
+extern "C" int ampconv_attn_scores(ampconv_view_t Q, ampconv_view_t K, const int64_t *edge_index,
+                                   int64_t E, int L, int D, int H, float *W, int dtype, void *stream) {
+  return attn_weights_impl(Q, K, edge_index, E, L, D, H, W, dtype, 1, stream);
+}
+
+static int attn_weights_impl(ampconv_view_t Q, ampconv_view_t K, const int64_t *edge_index, int64_t E, int L,
+                             int D, int H, float *W, int dtype, int linear, void *stream) {
   if (dtype != AMPCONV_F32) return AMPCONV_E_DTYPE;
   if (int rc = check_shape(L, D, H)) return rc;
   if (E < 0 || E > INT32_MAX) return AMPCONV_E_BADARG;
   if (E == 0) return AMPCONV_OK;
   if (!view_ok(Q) || !view_ok(K) || !edge_index || !W) return AMPCONV_E_BADARG;
-  WArgs a{Q, K, edge_index, E, W, L, D / H, pad_odd(D / H), H, 1.f / sqrtf((float)(D / H))};
+  WArgs a{Q, K, edge_index, E, W, L, D / H, pad_odd(D / H), H, 1.f / sqrtf((float)(D / H)), linear};
   size_t lds = ((size_t)2 * L * a.dhp + L) * sizeof(float);
   if (int rc = set_lds(attn_weights_generic, lds)) return rc;
   attn_weights_generic<<<(unsigned)E, AMPCONV_WAVE, lds, (hipStream_t)stream>>>(a);

@@ -22,6 +22,36 @@ __global__ void segment_mean_kernel(const float *__restrict__ msg,
   }
 }
 
+// out[r, :] = scale_r * sum_{p in segment r} (w ? w[p] : 1) * rows[idx[p], :], one float4 column
+// per thread, two edges in flight; the per-edge index and weight are wave-uniform (scalar loads)
+__global__ __launch_bounds__(256) void gather_segment_sum_kernel(const float *__restrict__ rows,
+                                                                  const int32_t *__restrict__ ptr,
+                                                                  const int32_t *__restrict__ idx,
+                                                                  const float *__restrict__ w, int mean,
+                                                                  int64_t F, float *__restrict__ out) {
+  const int64_t r = blockIdx.x;
+  const int64_t f = ((int64_t)blockIdx.y * blockDim.x + threadIdx.x) * 4;
+  if (f >= F) return;
+  const int beg = ptr[r], end = ptr[r + 1];
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+  int p = beg;
+  for (; p + 1 < end; p += 2) {
+    const float4 x = *reinterpret_cast<const float4 *>(rows + (int64_t)idx[p] * F + f);
+    const float4 y = *reinterpret_cast<const float4 *>(rows + (int64_t)idx[p + 1] * F + f);
+    const float wx = w ? w[p] : 1.f, wy = w ? w[p + 1] : 1.f;
+    a.x = fmaf(wx, x.x, a.x); a.y = fmaf(wx, x.y, a.y); a.z = fmaf(wx, x.z, a.z); a.w = fmaf(wx, x.w, a.w);
+    b.x = fmaf(wy, y.x, b.x); b.y = fmaf(wy, y.y, b.y); b.z = fmaf(wy, y.z, b.z); b.w = fmaf(wy, y.w, b.w);
+  }
+  if (p < end) {
+    const float4 x = *reinterpret_cast<const float4 *>(rows + (int64_t)idx[p] * F + f);
+    const float wx = w ? w[p] : 1.f;
+    a.x = fmaf(wx, x.x, a.x); a.y = fmaf(wx, x.y, a.y); a.z = fmaf(wx, x.z, a.z); a.w = fmaf(wx, x.w, a.w);
+  }
+  const float sc = mean ? (end > beg ? 1.f / (float)(end - beg) : 0.f) : 1.f;
+  *reinterpret_cast<float4 *>(out + r * F + f) =
+      make_float4((a.x + b.x) * sc, (a.y + b.y) * sc, (a.z + b.z) * sc, (a.w + b.w) * sc);
+}
+
 template <typename T>
 __global__ void mask_rows_kernel(T *__restrict__ Y, const int32_t *__restrict__ rowptr, int64_t N,
                                  int64_t F) {
@@ -72,6 +102,17 @@ extern "C" int ampconv_segment_mean(const float *msg, const int32_t *rowptr, con
   if (N == 0 || F == 0) return AMPCONV_OK;
   if (!rowptr || !out) return AMPCONV_E_BADARG;
   segment_mean_kernel<<<(unsigned)N, 256, 0, (hipStream_t)stream>>>(msg, rowptr, eperm, F, out);
+  return ampconv_launch_status();
+}
+
+extern "C" int ampconv_gather_segment_sum(const float *rows, const int32_t *ptr, const int32_t *idx,
+                                          const float *w, int mean, int64_t N, int64_t F, float *out,
+                                          void *stream) {
+  if (N < 0 || F < 0 || N > INT32_MAX || F % 4 != 0 || F / 4 > (int64_t)65535 * 256) return AMPCONV_E_BADARG;
+  if (N == 0 || F == 0) return AMPCONV_OK;
+  if (!rows || !ptr || !idx || !out || (uintptr_t)rows % 16 || (uintptr_t)out % 16) return AMPCONV_E_BADARG;
+  const dim3 grid((unsigned)N, (unsigned)((F / 4 + 255) / 256));
+  gather_segment_sum_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(rows, ptr, idx, w, mean, F, out);
   return ampconv_launch_status();
 }
 

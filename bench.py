@@ -160,6 +160,8 @@ def main():
     ap.add_argument('--workload', default=os.environ.get('AMPCONV_BENCH_WORKLOAD', 'cfg4'))
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-alt-gemm', action='store_true', help='skip the extra bf16x3-GEMM pass (profiling runs)')
+    ap.add_argument('--softmax-free', action='store_true',
+                    help="the reference's softmax-free attention variant (AMPConv(..., softmax=False)); not the headline")
     ap.add_argument('--dtype', default=None, choices=['f32', 'bf16'],
                     help='storage dtype (default: f32; bf16 for cfg5)')
     ap.add_argument('--gemm', default='fp32', choices=['fp32', 'bf16x3'],
@@ -187,7 +189,7 @@ def main():
     tdt = torch.bfloat16 if dt_name == 'bf16' else torch.float32
     R = L * D * (2 if dt_name == 'bf16' else 4)
     torch.manual_seed(1)
-    layer = AMPConv(D, H).to(dev)
+    layer = AMPConv(D, H, softmax=not args.softmax_free).to(dev)
     layer.retain_attention = False                            # no [E, L, L] side output kept alive
     layer.gemm_precision = args.gemm
     with torch.no_grad():
@@ -240,7 +242,7 @@ def main():
     dt = float(tmax.item())
 
     alt = None
-    if world == 1 and dt_name == 'f32' and args.gemm == 'fp32' and not args.no_alt_gemm:
+    if world == 1 and dt_name == 'f32' and args.gemm == 'fp32' and not args.no_alt_gemm and not args.softmax_free:
         # same step with the projections on hipBLASLt's bf16x3 path -- reported beside, never as `value`
         layer.gemm_precision = 'bf16x3'
         step()
@@ -254,7 +256,15 @@ def main():
         alt = {'gemm': 'bf16x3', 'value': E * args.steps / dta, 'unit': 'edges/s',
                'ms_per_step': 1e3 * dta / args.steps}
 
-    if rank == 0:
+    if rank == 0 and args.softmax_free:
+        # the edge phase of this variant is one segment reduction (conv/linear.py): no edge-kernel roofline
+        print(json.dumps({'metric': 'AMPConv edges/sec (fwd+bwd), softmax-free variant', 'value': world * E * args.steps / dt,
+                          'unit': 'edges/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+                          'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak',
+                          'vs_baseline': None, 'dtype': dt_name, 'data': 'synthetic',
+                          'config': {'workload': f'{args.workload}: {desc}, softmax-free AMPConv layer fwd+bwd',
+                                     'N': N, 'E': E, 'L': L, 'D': D, 'H': H, 'parallelism': f'dp{world}'}}), flush=True)
+    elif rank == 0:
         ms = timer.summary()
         alg = {'ampconv_fwd_edge': (2 * E + 2 * N) * R, 'ampconv_bwd_edge_dst': (2 * E + 3 * N) * R,
                'ampconv_bwd_edge_src': (2 * E + 4 * N) * R}

@@ -158,6 +158,12 @@ int ampconv_attn_weights(ampconv_view_t Q, ampconv_view_t K,
                          const int64_t *edge_index, int64_t E, int L, int D,
                          int H, float *W, int dtype, void *stream);
 
+/* attn_scores: the same without the softmax, W[e] = mean_h Q K^T / sqrt(dh) -- the per-edge weights of
+ * the reference's softmax-free attention (custom_multihead_attn_forward.py:4173-4184, :4441-4442).  */
+int ampconv_attn_scores(ampconv_view_t Q, ampconv_view_t K,
+                        const int64_t *edge_index, int64_t E, int L, int D,
+                        int H, float *W, int dtype, void *stream);
+
 /* ---- node-side helpers --------------------------------------------------------
  * segment_mean: PyG aggr='mean' on an [E, F] message matrix (amp_conv.py:11,
  * testing_message_passing_pyg.py:37-40): out[n] = mean of msg[eperm[p]] over the
@@ -172,6 +178,15 @@ int ampconv_segment_mean(const float *msg, const int32_t *rowptr,
                          void *stream);
 int ampconv_mask_rows(void *Y, const int32_t *rowptr, int64_t N, int64_t F,
                       int dtype, void *stream);
+/* gather_segment_sum: out[r, :] = scale_r * sum_{p in [ptr[r], ptr[r+1])} (w ? w[p] : 1) * rows[idx[p], :]
+ * with F (a multiple of 4) fp32 per row, scale_r = 1/segment length if `mean` else 1, 0 for empty
+ * segments.  The whole edge phase of the softmax-free variant ("next" row 3 of SURVEY.md 8f): without
+ * softmax, sum_e Q_d K_s^T V_s = Q_d sum_e (K_s^T V_s), so the per-edge work collapses to this
+ * segment reduction of the per-source dh x dh matrices K_s^T V_s (forward: CSR, mean; backward:
+ * CSC, weights cinv).  */
+int ampconv_gather_segment_sum(const float *rows, const int32_t *ptr, const int32_t *idx,
+                               const float *w, int mean, int64_t N, int64_t F, float *out,
+                               void *stream);
 int ampconv_masked_colsum(const void *dY, const int32_t *rowptr, int64_t N,
                           int L, int D, float *out, int dtype, void *stream);
 

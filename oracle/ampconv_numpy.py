@@ -14,6 +14,10 @@ What it follows in the reference (paths relative to /root/reference):
   * torch/nn/functional.py:5785-5862    packed in-projection, enc-dec branch
   * torch/nn/functional.py:6576-6612    scale, QK^T, softmax(dim=-1), PV,
         out-projection, head-mean of the weights
+  * softmax=False: the reference's softmax-free attention
+        (src/ampnet/conv/custom_multihead_attn_forward.py:4173-4184: q / sqrt(dh), bmm, softmax
+        line commented out at :4179-4180, bmm with v), the variant amp_conv.py:6,17 refers to.
+        Evaluated per edge here; the GPU path collapses it algebraically (conv/linear.py).
 
 Re-association relative to the reference: Q depends only on the destination
 node and K/V only on the source node, so they are projected once per node;
@@ -38,7 +42,8 @@ class AMPConvOracle:
     """
 
     def __init__(self, in_proj_weight, in_proj_bias, out_proj_weight, out_proj_bias,
-                 num_heads, dtype=np.float64, edge_chunk=4096):
+                 num_heads, dtype=np.float64, edge_chunk=4096, softmax=True):
+        self.softmax = bool(softmax)
         self.dt = np.dtype(dtype)
         self.Win = np.asarray(in_proj_weight, dtype=self.dt)
         self.bin = np.asarray(in_proj_bias, dtype=self.dt)
@@ -77,7 +82,7 @@ class AMPConvOracle:
             k = K[src[a:b]]
             v = V[src[a:b]]
             s = np.einsum('eihc,ejhc->ehij', q * scale, k)   # [e, H, L, L]
-            p = _softmax_rows(s)
+            p = _softmax_rows(s) if self.softmax else s
             o = np.einsum('ehij,ejhc->eihc', p, v)           # [e, L, H, dh]
             np.add.at(Osum, dst[a:b], o)
             if need_weights:
@@ -111,11 +116,14 @@ class AMPConvOracle:
             d_, s_ = dst[a:b], src[a:b]
             q, k, v, do = Q[d_], K[s_], V[s_], dOn[d_]
             s = np.einsum('eihc,ejhc->ehij', q * scale, k)
-            p = _softmax_rows(s)
+            p = _softmax_rows(s) if self.softmax else s
             dv = np.einsum('ehij,eihc->ejhc', p, do)
             dp = np.einsum('eihc,ejhc->ehij', do, v)
-            delta = (dp * p).sum(axis=-1, keepdims=True)
-            ds = p * (dp - delta)
+            if self.softmax:
+                delta = (dp * p).sum(axis=-1, keepdims=True)
+                ds = p * (dp - delta)
+            else:
+                ds = dp
             dq = np.einsum('ehij,ejhc->eihc', ds, k) * scale
             dk = np.einsum('ehij,eihc->ejhc', ds, q) * scale
             np.add.at(dQ, d_, dq)
@@ -135,7 +143,9 @@ class AMPConvOracle:
         q = c['Q'][c['dst']]
         k = c['K'][c['src']]
         v = c['V'][c['src']]
-        p = _softmax_rows(np.einsum('eihc,ejhc->ehij', q * c['scale'], k))
+        p = np.einsum('eihc,ejhc->ehij', q * c['scale'], k)
+        if self.softmax:
+            p = _softmax_rows(p)
         o = np.einsum('ehij,ejhc->eihc', p, v).reshape(c['E'], c['L'], D)
         return o @ self.Wo.T + self.bo
 

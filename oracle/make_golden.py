@@ -9,7 +9,8 @@ Nothing of the reference is copied into the fixtures: they hold inputs
 (x, edge_index, parameters, upstream gradient) and the outputs the reference
 produced for them.
 
-    python oracle/make_golden.py            # rewrites tests/golden/
+    python oracle/make_golden.py                  # rewrites tests/golden/
+    python oracle/make_golden.py --linear-only    # only the softmax-free fixtures (linear_*.npz)
 """
 import importlib.util
 import os
@@ -48,9 +49,34 @@ def load_reference():
     return ref
 
 
-def make_layer(ref, D, H, seed):
+CUSTOM_MHA = '/root/reference/src/ampnet/conv/custom_multihead_attn.py'
+CUSTOM_FWD = '/root/reference/src/ampnet/conv/custom_multihead_attn_forward.py'
+
+
+def load_softmax_free_mha():
+    """The reference's own softmax-free nn.MultiheadAttention copy (custom_multihead_attn.py,
+    custom_multihead_attn_forward.py:4179-4180), loaded unmodified by file path under the module
+    names it imports itself by (its package __init__ pulls in un-installed plotting libraries)."""
+    for pkg in ('src', 'src.ampnet', 'src.ampnet.conv'):
+        sys.modules.setdefault(pkg, types.ModuleType(pkg))
+    mods = {}
+    for name, path in (('src.ampnet.conv.custom_multihead_attn_forward', CUSTOM_FWD),
+                       ('src.ampnet.conv.custom_multihead_attn', CUSTOM_MHA)):
+        spec = importlib.util.spec_from_file_location(name, path)
+        mods[name] = importlib.util.module_from_spec(spec)
+        sys.modules[name] = mods[name]
+        spec.loader.exec_module(mods[name])
+    return mods['src.ampnet.conv.custom_multihead_attn'].MultiheadAttention
+
+
+def make_layer(ref, D, H, seed, mha_cls=None):
     torch.manual_seed(seed)
     layer = ref.AMPConv(embed_dim=D, num_heads=H)
+    if mha_cls is not None:
+        # what un-commenting amp_conv.py:6 and using it at :18 does: the layer's attention module
+        # becomes the reference's softmax-free class (same parameters, same constructor arguments)
+        torch.manual_seed(seed)
+        layer.multi_head_attention = mha_cls(embed_dim=D, num_heads=H, batch_first=True, bias=True)
     with torch.no_grad():                      # exercise the bias paths (default init is 0)
         layer.multi_head_attention.in_proj_bias.normal_(0, 0.1)
         layer.multi_head_attention.out_proj.bias.normal_(0, 0.1)
@@ -95,8 +121,8 @@ def random_graph(rng, N, E, zero_in=0, dups=0, self_loops=0):
     return np.stack([src[perm], dst[perm]]).astype(np.int64)
 
 
-def run_single(ref, name, N, L, D, H, edge_index, seed, weight_edges=None):
-    layer = make_layer(ref, D, H, seed)
+def run_single(ref, name, N, L, D, H, edge_index, seed, weight_edges=None, mha_cls=None):
+    layer = make_layer(ref, D, H, seed, mha_cls)
     g = torch.Generator().manual_seed(seed + 1000)
     x = torch.randn(N, L * D, generator=g, requires_grad=True)
     dy = torch.randn(N, L * D, generator=g)
@@ -139,9 +165,26 @@ def run_two_layer(ref, name, N, L, D, H, edge_index, seed):
     print(f'{name}: two-layer N={N} E={edge_index.shape[1]} L={L} D={D} H={H}')
 
 
+def main_linear(ref):
+    """Fixtures of the softmax-free variant (file names linear_*.npz)."""
+    mha = load_softmax_free_mha()
+    rng = np.random.default_rng(20221005)
+    toy_sl = np.array([[0, 1, 2, 3, 4], [2, 2, 2, 2, 2]], dtype=np.int64)
+    run_single(ref, 'linear_toy5_selfloop_L2_D4_H2', 5, 2, 4, 2, toy_sl, seed=21, mha_cls=mha)
+    run_single(ref, 'linear_cora_L20_D128_H4', 40, 20, 128, 4,
+               random_graph(rng, 40, 260, zero_in=5, dups=16, self_loops=8), seed=22,
+               weight_edges=np.arange(32), mha_cls=mha)
+    run_single(ref, 'linear_wide_L4_D64_H8', 48, 4, 64, 8, random_graph(rng, 48, 350, zero_in=4), seed=23,
+               mha_cls=mha)
+    run_single(ref, 'linear_ampgcn_L40_D100_H2', 12, 40, 100, 2, random_graph(rng, 12, 60, zero_in=2),
+               seed=24, weight_edges=np.arange(8), mha_cls=mha)
+
+
 def main():
     os.makedirs(OUT_DIR, exist_ok=True)
     ref = load_reference()
+    if '--linear-only' in sys.argv:            # add the softmax-free fixtures, leave the others as they are
+        return main_linear(ref)
     rng = np.random.default_rng(20221004)
 
     # toy graph of synthetic_benchmark/testing_message_passing_pyg.py:24-33
@@ -176,6 +219,7 @@ def main():
     run_single(ref, 'hub_L2_D8_H2', Nh, 2, 8, 2, hub, seed=11, weight_edges=np.arange(64))
     # L=1 degenerate (softmax over one element), BASELINE L=1 sweep
     run_single(ref, 'l1_L1_D128_H8', 80, 1, 128, 8, random_graph(rng, 80, 500, zero_in=6), seed=12)
+    main_linear(ref)
 
 
 if __name__ == '__main__':

@@ -21,8 +21,11 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
-def golden_files(two_layer=False):
+def golden_files(two_layer=False, linear=False):
+    """Fixtures written by oracle/make_golden.py.  linear=True: the softmax-free variant
+    (linear_*.npz, from the reference's custom_multihead_attn.py)."""
     fs = sorted(glob.glob(os.path.join(GOLDEN_DIR, '*.npz')))
+    fs = [f for f in fs if os.path.basename(f).startswith('linear_') == linear]
     return [f for f in fs if ('2layer' in os.path.basename(f)) == two_layer]
 
 

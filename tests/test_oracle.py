@@ -14,6 +14,7 @@ from oracle.ampconv_torch import RefShapedAMPConv
 
 SINGLE = golden_files(two_layer=False)
 TWO = golden_files(two_layer=True)
+LINEAR = golden_files(linear=True)
 
 
 def test_golden_present():
@@ -51,6 +52,27 @@ def test_numpy_oracle_vs_reference(path, dtype):
     assert_close_scaled(dbo, g['g_out_proj_bias'], 'g_out_proj_bias')
     ao = o.attn_output()
     assert_close_scaled(ao[g['w_edges'][:4]], g['attn_output'], 'attn_output')
+
+
+@pytest.mark.parametrize('path', LINEAR, ids=[os.path.basename(p)[:-4] for p in LINEAR])
+def test_numpy_oracle_softmax_free_vs_reference(path):
+    # the variant amp_conv.py:6,17 refers to: the reference's nn.MultiheadAttention copy with the
+    # softmax line removed (custom_multihead_attn_forward.py:4179-4180)
+    g = load_golden(path)
+    o = AMPConvOracle(g['in_proj_weight'], g['in_proj_bias'], g['out_proj_weight'],
+                      g['out_proj_bias'], int(g['H']), softmax=False)
+    y, w = o.forward(g['x'], g['edge_index'])
+    assert_close_scaled(y, g['y'], 'y')
+    assert_close_scaled(w[g['w_edges']], g['attn_output_weights'], 'attn_output_weights')
+    deg = np.bincount(g['edge_index'][1], minlength=int(g['N']))
+    assert (y[deg == 0] == 0).all()
+    dx, dWin, dbin, dWo, dbo = o.backward(g['dy'])
+    assert_close_scaled(dx, g['dx'], 'dx')
+    assert_close_scaled(dWin, g['g_in_proj_weight'], 'g_in_proj_weight')
+    assert_close_scaled(dbin, g['g_in_proj_bias'], 'g_in_proj_bias')
+    assert_close_scaled(dWo, g['g_out_proj_weight'], 'g_out_proj_weight')
+    assert_close_scaled(dbo, g['g_out_proj_bias'], 'g_out_proj_bias')
+    assert_close_scaled(o.attn_output()[g['w_edges'][:4]], g['attn_output'], 'attn_output')
 
 
 def _torch_layer(g, prefix=''):
