@@ -47,6 +47,8 @@ SIGNATURES = {
     'ampconv_attn_weights': (_i32, [View, View, _vp, _i64, _i32, _i32, _i32, _vp, _i32, _vp]),
     'ampconv_attn_scores': (_i32, [View, View, _vp, _i64, _i32, _i32, _i32, _vp, _i32, _vp]),
     'ampconv_gather_segment_sum': (_i32, [_vp, _vp, _vp, _vp, _i32, _i64, _i64, _vp, _vp]),
+    'ampconv_linear_outer': (_i32, [View, View, _i64, _i32, _i32, _i32, ctypes.c_float, _vp, _vp]),
+    'ampconv_linear_apply': (_i32, [View, _vp, _i32, _i64, _i32, _i32, _i32, ctypes.c_float, View, _vp]),
     'ampconv_saint_random_walk': (_i32, [_vp, _vp, _vp, _i64, _i32, ctypes.c_uint64, _vp, _vp]),
     'ampconv_saint_workspace_bytes': (_sz, [_i64]),
     'ampconv_saint_nodes': (_i32, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

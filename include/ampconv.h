@@ -187,6 +187,15 @@ int ampconv_mask_rows(void *Y, const int32_t *rowptr, int64_t N, int64_t F,
 int ampconv_gather_segment_sum(const float *rows, const int32_t *ptr, const int32_t *idx,
                                const float *w, int mean, int64_t N, int64_t F, float *out,
                                void *stream);
+/* The per-node products around it (custom_multihead_attn_forward.py:4173-4184 re-associated), one
+ * [L, dh] tile per (node, head) on either side, M = [N, H, dh, dh] fp32 row-major:
+ *   linear_outer: M[n,h] = scale * A[n,:,h]^T B[n,:,h]      (K^T V; Q^T dObar for the backward)
+ *   linear_apply: Out[n,:,h] = scale * A[n,:,h] M[n,h]      (transpose != 0: ... M[n,h]^T)
+ *                 (Q Mbar; dObar Mbar^T, V dM^T, K dM for the backward)  */
+int ampconv_linear_outer(ampconv_view_t A, ampconv_view_t B, int64_t N, int L, int D, int H,
+                         float scale, float *M, void *stream);
+int ampconv_linear_apply(ampconv_view_t A, const float *M, int transpose, int64_t N, int L,
+                         int D, int H, float scale, ampconv_view_t Out, void *stream);
 int ampconv_masked_colsum(const void *dY, const int32_t *rowptr, int64_t N,
                           int L, int D, float *out, int dtype, void *stream);
 

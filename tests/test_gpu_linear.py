@@ -121,6 +121,6 @@ def test_gather_segment_sum_rejects_bad_arguments(dev):
     t = torch.zeros(8, device=dev)
     p = torch.zeros(2, dtype=torch.int32, device=dev)
     assert lib.ampconv_gather_segment_sum(t.data_ptr(), p.data_ptr(), p.data_ptr(), None, 0, 1, 6,
-                                          t.data_ptr(), None) == _lib.AMPCONV_E_BADARG     # F % 4 != 0
+                                          t.data_ptr(), None) == -1     # AMPCONV_E_BADARG: F % 4 != 0
     assert lib.ampconv_gather_segment_sum(None, p.data_ptr(), p.data_ptr(), None, 0, 1, 8,
-                                          t.data_ptr(), None) == _lib.AMPCONV_E_BADARG
+                                          t.data_ptr(), None) == -1
