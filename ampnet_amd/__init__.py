@@ -11,6 +11,7 @@ from .graph import EdgeCSR, graph_cache
 from . import distributed
 from .module import AMPGCN, FeatureTokens
 from .sampler import GraphSAINTRandomWalkSampler
+from .partitioned import NodePartition, PartitionedAMPConv
 
 __all__ = ['AMPConv', 'InvalidConfiguration', 'EdgeCSR', 'graph_cache', 'distributed', 'AMPGCN', 'FeatureTokens',
-           'GraphSAINTRandomWalkSampler']
+           'GraphSAINTRandomWalkSampler', 'NodePartition', 'PartitionedAMPConv']

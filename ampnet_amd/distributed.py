@@ -40,7 +40,9 @@ class GradientAllReducer:
             self._flat = torch.empty(self.numel, dtype=torch.float32, device=like.device)   # fp32 sum
         return self._flat
 
-    def allreduce(self):
+    def allreduce(self, average=True):
+        """average=True: mean over ranks (independent mini-batches per rank); False: sum (ranks hold
+        partitions of ONE graph, ampnet_amd/partitioned.py)."""
         if not self.params:
             return None
         world = dist.get_world_size(self.group)
@@ -55,7 +57,8 @@ class GradientAllReducer:
             off += n
         if world > 1:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-            flat.mul_(1.0 / world)
+            if average:
+                flat.mul_(1.0 / world)
         off = 0
         for p in self.params:                       # unpack
             n = p.numel()

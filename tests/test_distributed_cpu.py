@@ -55,3 +55,39 @@ def test_gradient_allreduce_world2(tmp_path):
         torch.testing.assert_close(a0, (l0 + l1) / 2, rtol=1e-6, atol=1e-7)
         assert torch.equal(a0, a1)
     assert not torch.equal(r[0]['local'][0], r[1]['local'][0])
+
+
+def _partition_worker(rank, world, port, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from ampnet_amd.partitioned import NodePartition
+    from ampnet_amd.distributed import GradientAllReducer
+    part = NodePartition(7)                                   # 7 nodes on 2 ranks: ranges [0,4) and [4,8) padded
+    x = torch.arange(14.).view(7, 2)
+    ei = torch.tensor([[0, 1, 2, 3, 4, 5, 6, 6], [6, 5, 4, 3, 2, 1, 0, 6]])
+    gathered = part.all_gather_rows(part.local_rows(x))       # emulated with all_reduce on gloo
+    partial = torch.full((part.n_padded, 3), float(rank + 1))
+    scattered = part.reduce_scatter_rows(partial)
+    p = torch.nn.Parameter(torch.zeros(3))
+    p.grad = torch.full((3,), float(rank + 1))
+    GradientAllReducer([p]).allreduce(average=False)
+    torch.save({'n_local': part.n_local, 'begin': part.begin, 'edges': part.local_edges(ei),
+                'gathered': gathered, 'scattered': scattered, 'grad': p.grad.clone()},
+               os.path.join(out_dir, f'p{rank}.pt'))
+    dist.destroy_process_group()
+
+
+def test_node_partition_world2(tmp_path):
+    """Bookkeeping and collectives of the destination-partitioned layer (ampnet_amd/partitioned.py) on
+    two gloo ranks: equal padded ranges, edges filed by destination with local ids, gather /
+    reduce-scatter of row blocks, SUMMED parameter gradients."""
+    mp.spawn(_partition_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r = [torch.load(os.path.join(tmp_path, f'p{i}.pt')) for i in range(2)]
+    assert [r[0]['n_local'], r[0]['begin'], r[1]['begin']] == [4, 0, 4]
+    assert torch.equal(r[0]['edges'], torch.tensor([[3, 4, 5, 6], [3, 2, 1, 0]]))          # dst 0..3 stay
+    assert torch.equal(r[1]['edges'], torch.tensor([[0, 1, 2, 6], [2, 1, 0, 2]]))          # dst 4..6 -> 0..2
+    want = torch.cat([torch.arange(14.).view(7, 2), torch.zeros(1, 2)])
+    assert torch.equal(r[0]['gathered'], want) and torch.equal(r[1]['gathered'], want)
+    assert torch.equal(r[0]['scattered'], torch.full((4, 3), 3.0)) and torch.equal(r[1]['scattered'], torch.full((4, 3), 3.0))
+    assert torch.equal(r[0]['grad'], torch.full((3,), 3.0)) and torch.equal(r[1]['grad'], torch.full((3,), 3.0))

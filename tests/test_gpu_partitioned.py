@@ -1,0 +1,90 @@
+"""Destination-partitioned full-graph AMPConv (ampnet_amd/partitioned.py): two
+processes (gloo; both on cuda:0 here, one per GPU over RCCL on the 8-GPU node) each own half of the
+nodes; their outputs, input gradients and summed parameter gradients must equal the single-process
+layer on the whole graph."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_close_scaled
+
+pytestmark = pytest.mark.gpu
+
+N, E, L, D, H = 301, 2600, 20, 128, 4          # odd N: the last range is padded
+
+
+def _problem():
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(N, L * D, generator=g)
+    dy = torch.randn(N, L * D, generator=g)
+    ei = torch.randint(0, N, (2, E), generator=g)
+    ei[1, :300] = 11                             # a hub destination inside rank 0's range
+    ei[0, 300:600] = 250                         # a hub source owned by rank 1, feeding both ranges
+    ei[1, ei[1] == 200] = 201                    # node 200 receives nothing
+    return x, dy, ei
+
+
+def _layer(dev):
+    from ampnet_amd import AMPConv
+    torch.manual_seed(5)
+    layer = AMPConv(D, H).to(dev)
+    with torch.no_grad():
+        layer.multi_head_attention.in_proj_bias.normal_(0, 0.1)
+        layer.multi_head_attention.out_proj.bias.normal_(0, 0.1)
+    return layer
+
+
+def _worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from ampnet_amd import NodePartition, PartitionedAMPConv
+    from ampnet_amd.distributed import GradientAllReducer
+    dev = torch.device('cuda:0')
+    x, dy, ei = _problem()
+    part = NodePartition(N)
+    layer = PartitionedAMPConv(_layer(dev), part)
+    graph = layer.prepare(ei.to(dev))
+    xl = part.local_rows(x.to(dev)).requires_grad_(True)
+    y = layer(xl, graph)
+    y.backward(part.local_rows(dy.to(dev)))
+    GradientAllReducer(layer.parameters()).allreduce(average=False)
+    torch.save({'y': y.detach().cpu(), 'dx': xl.grad.cpu(),
+                'grads': [p.grad.detach().cpu() for p in layer.parameters()]}, os.path.join(out_dir, f'r{rank}.pt'))
+    dist.destroy_process_group()
+
+
+def test_partitioned_layer_matches_single_process(tmp_path):
+    import torch.multiprocessing as mp
+    assert torch.cuda.is_available()
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r = [torch.load(os.path.join(tmp_path, f'r{i}.pt')) for i in range(2)]
+    dev = torch.device('cuda:0')
+    x, dy, ei = _problem()
+    layer = _layer(dev)
+    xg = x.to(dev).requires_grad_(True)
+    y = layer(xg, ei.to(dev))
+    y.backward(dy.to(dev))
+    y_part = torch.cat([r[0]['y'], r[1]['y']])[:N].numpy()
+    dx_part = torch.cat([r[0]['dx'], r[1]['dx']])[:N].numpy()
+    assert_close_scaled(y_part, y.detach().cpu().numpy(), 'y')
+    assert (y_part[200] == 0).all()
+    assert_close_scaled(dx_part, xg.grad.cpu().numpy(), 'dx')
+    for g0, g1, p in zip(r[0]['grads'], r[1]['grads'], layer.parameters()):
+        assert torch.equal(g0, g1)                                     # summed over ranks, identical everywhere
+        assert_close_scaled(g0.numpy(), p.grad.cpu().numpy(), 'parameter gradient')
+
+
+def test_node_partition_bookkeeping():
+    from ampnet_amd import NodePartition
+    part = NodePartition(10)                      # no process group: one rank owns everything
+    assert (part.world, part.rank, part.n_local, part.n_padded, part.begin) == (1, 0, 10, 10, 0)
+    ei = torch.tensor([[0, 3, 9], [9, 0, 3]])
+    assert torch.equal(part.local_edges(ei), ei)
+    x = torch.arange(20.).view(10, 2)
+    assert torch.equal(part.local_rows(x), x)
