@@ -739,6 +739,261 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? 3 : 4) void bwd_src
   }
 }
 
+// ---- forward with the tail tokens of four consecutive edges in one MFMA tile.
+// The column softmax of an edge runs over its 20 source tokens, 16 in the main tile and 4 in the
+// tail, so the tail scores must exist BEFORE the edge's main tile is normalised: per batch of four
+// edges the tail tile S^T[(edge g, token 16+q)][dst token] comes first (its A operand = the four
+// edges' K rows 16..19 as one 16-row LDS image, row rho = 4 edge + token - 16), each edge's main
+// phase then folds "its" lane group of the tail tile into the same cross-group max / sum, and
+// the batch ends with O^T += V_tail^T P_tail^T, contracting over (edge, token) jointly (V rows
+// 16..19 as a second 16-row image).  The tail rows are fetched as whole rows (coalesced), the K
+// rows a batch ahead; gathering them lane-by-lane straight into operand registers measured 46 %
+// SLOWER than no batching (64 sector requests per instruction).  52 -> 40 MFMAs per edge and head.
+template <int DH>
+struct TailRegs {                      // rows 16..19 of one tensor for four edges: 16 rows
+  static constexpr int NP = 16 / TileCfg<DH>::RPI;
+  float4 v[NP];
+};
+template <int DH>
+struct MainRegs {                      // rows 0..15 of two tiles: 32 rows
+  static constexpr int NP = 32 / TileCfg<DH>::RPI;
+  float4 v[NP];
+};
+template <int DH, bool FULL>
+__device__ __forceinline__ void main_load(MainRegs<DH> &t, const float *baseA, int64_t strideA,
+                                          const float *baseB, int64_t strideB, int L, int lane) {
+  using C = TileCfg<DH>;
+  const int r = lane / C::CH, q = lane % C::CH;
+#pragma unroll
+  for (int i = 0; i < MainRegs<DH>::NP; ++i) {
+    const int R = r + C::RPI * i;
+    const bool isB = R >= 16;
+    const int j = R & 15;
+    const unsigned boff = ((unsigned)j * (unsigned)(isB ? strideB : strideA) + 4u * (unsigned)q) * 4u;
+    const char *p = reinterpret_cast<const char *>(isB ? baseB : baseA) + boff;
+    if (FULL || j < L) t.v[i] = *reinterpret_cast<const float4 *>(p);
+  }
+}
+template <int DH, bool FULL>
+__device__ __forceinline__ void main_to_lds(float *ldsA, const MainRegs<DH> &t, int L, int lane) {
+  using C = TileCfg<DH>;
+  const int r = lane / C::CH, q = lane % C::CH;
+#pragma unroll
+  for (int i = 0; i < MainRegs<DH>::NP; ++i) {
+    const int R = r + C::RPI * i;
+    const bool isB = R >= 16;
+    const int j = R & 15;
+    if (FULL || j < L) {
+      const float4 x = t.v[i];     // member-wise: an aggregate copy to LDS keeps the registers' struct in scratch
+      *reinterpret_cast<float4 *>(ldsA + (isB ? 16 * DH : 0) + j * DH + ((q ^ swz<DH>(j)) << 2)) =
+          make_float4(x.x, x.y, x.z, x.w);
+    }
+  }
+}
+
+// rows 16..19 of four edges (nodes id0..id3), whole rows: lane (r, q) owns 16 B of rows rho = r + RPI i
+template <int DH, bool FULL>
+__device__ __forceinline__ void tail_load(TailRegs<DH> &t, const ampconv_view_t &view, int h, int id0, int id1,
+                                          int id2, int id3, int L, int lane) {
+  using C = TileCfg<DH>;
+  const int r0 = lane / C::CH, q = lane % C::CH;
+#pragma unroll
+  for (int i = 0; i < TailRegs<DH>::NP; ++i) {
+    const int rho = r0 + C::RPI * i, tok = 16 + (rho & 3);
+    const int lo = (rho & 4) ? id1 : id0, hi = (rho & 4) ? id3 : id2;     // edge rho >> 2
+    const int node = (rho & 8) ? hi : lo;
+    if (FULL || tok < L)
+      t.v[i] = *reinterpret_cast<const float4 *>(tile_ptr<const float>(view, node, h) +
+                                                  (int64_t)tok * view.row_stride + 4 * q);
+  }
+}
+template <int DH, bool FULL>
+__device__ __forceinline__ void tail_to_lds(float *img, const TailRegs<DH> &t, int L, int lane) {
+  using C = TileCfg<DH>;
+  const int r0 = lane / C::CH, q = lane % C::CH;
+#pragma unroll
+  for (int i = 0; i < TailRegs<DH>::NP; ++i) {
+    const int rho = r0 + C::RPI * i;
+    if (FULL || 16 + (rho & 3) < L) {
+      const float4 x = t.v[i];
+      *reinterpret_cast<float4 *>(img + rho * DH + ((q ^ swz<DH>(rho)) << 2)) = make_float4(x.x, x.y, x.z, x.w);
+    }
+  }
+}
+
+template <int DH, bool FULL>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void fwd_mfma_t4(FwdArgs a) {
+  using C = TileCfg<DH>;
+  __shared__ __attribute__((aligned(16))) float lds_all[kWavesPerBlock][4 * 16 * DH];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t unit = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  if (unit >= a.n_units) return;
+  int64_t r, onode;
+  int h, beg, end, deg;
+  if (!map_unit(a.hub, a.rowptr, unit, a.H, r, onode, h, beg, end, deg)) return;
+  const int L = a.L, g = lane >> 4, n = lane & 15;
+  float *Kt = lds_all[wave], *Vt = Kt + 16 * DH, *Ktail = Kt + 32 * DH, *Vtail = Kt + 48 * DH;
+  const int64_t d = a.qidx ? a.qidx[r] : r;
+
+  float qB[2][C::KK];
+  {
+    const float *qb = tile_ptr<const float>(a.Q, d, h);
+    rowop_from_global<DH>(qB[0], qb, a.Q.row_stride, 0, true, a.qscale, L, lane);
+    rowop_from_global<DH>(qB[1], qb, a.Q.row_stride, 1, true, a.qscale, L, lane);
+  }
+  if (!FULL)
+    for (int i = lane; i < 4 * 16 * DH; i += AMPCONV_WAVE) Kt[i] = 0.f;
+  f32x4 OT[C::MC][2];
+#pragma unroll
+  for (int mc = 0; mc < C::MC; ++mc) OT[mc][0] = OT[mc][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // sources of the edges of the current / next batch (wave-uniform scalars; positions clamped to
+  // the segment, the window is walked strictly forwards)
+  IdxWindow win;
+  int id0 = 0, id1 = 0, id2 = 0, id3 = 0, nid0 = 0, nid1 = 0, nid2 = 0, nid3 = 0;
+#define AMPCONV_IDS(o0, o1, o2, o3, p)                                                               \
+  do {                                                                                               \
+    const int p_ = (p);                                                                              \
+    o0 = idxwin_get<false>(win, a.col, nullptr, p_ < end ? p_ : end - 1, end, lane, nullptr);         \
+    o1 = idxwin_get<false>(win, a.col, nullptr, p_ + 1 < end ? p_ + 1 : end - 1, end, lane, nullptr); \
+    o2 = idxwin_get<false>(win, a.col, nullptr, p_ + 2 < end ? p_ + 2 : end - 1, end, lane, nullptr); \
+    o3 = idxwin_get<false>(win, a.col, nullptr, p_ + 3 < end ? p_ + 3 : end - 1, end, lane, nullptr); \
+  } while (0)
+  TailRegs<DH> ktn, vtn;
+  MainRegs<DH> ring;
+  if (beg < end) {
+    idxwin_load<false>(win, a.col, nullptr, beg, end, lane);
+    AMPCONV_IDS(id0, id1, id2, id3, beg);
+    tail_load<DH, FULL>(ktn, a.K, h, id0, id1, id2, id3, L, lane);
+    main_load<DH, FULL>(ring, tile_ptr<const float>(a.K, id0, h), a.K.row_stride,
+                        tile_ptr<const float>(a.V, id0, h), a.V.row_stride, L, lane);
+  }
+
+  for (int p0 = beg; p0 < end; p0 += 4) {
+    const bool more = p0 + 4 < end;
+    if (more) AMPCONV_IDS(nid0, nid1, nid2, nid3, p0 + 4);
+    const bool live = p0 + g < end;                    // lane group g <-> edge p0 + g of the tail tile
+
+    // tail tile of the batch: S^T rows (edge g, token 16 + q), columns = destination tokens
+    tail_to_lds<DH, FULL>(Ktail, ktn, L, lane);
+    if (more) tail_load<DH, FULL>(ktn, a.K, h, nid0, nid1, nid2, nid3, L, lane);   // a whole batch ahead
+    tail_load<DH, FULL>(vtn, a.V, h, id0, id1, id2, id3, L, lane);                  // this batch's closing operand
+    __builtin_amdgcn_wave_barrier();
+    f32x4 St[2];
+    St[0] = St[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    {
+      float kt[C::KK];
+      rowop_from_lds<DH>(kt, Ktail, 0, lane);
+#pragma unroll
+      for (int kk = 0; kk < C::KK; ++kk) {
+        St[0] = MFMA16(kt[kk], qB[0][kk], St[0]);
+        St[1] = MFMA16(kt[kk], qB[1][kk], St[1]);
+      }
+    }
+    float tm0, tm1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (!live || (!FULL && 16 + q >= L)) St[0][q] = St[1][q] = kNegBig;
+    tm0 = fmaxf(fmaxf(St[0][0], St[0][1]), fmaxf(St[0][2], St[0][3]));
+    tm1 = fmaxf(fmaxf(St[1][0], St[1][1]), fmaxf(St[1][2], St[1][3]));
+
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (p0 + e >= end) break;
+      main_to_lds<DH, FULL>(Kt, ring, L, lane);
+      {
+        const bool has_next = e < 3 ? p0 + e + 1 < end : more;
+        const int next = e == 0 ? id1 : e == 1 ? id2 : e == 2 ? id3 : nid0;
+        if (has_next)
+          main_load<DH, FULL>(ring, tile_ptr<const float>(a.K, next, h), a.K.row_stride,
+                              tile_ptr<const float>(a.V, next, h), a.V.row_stride, L, lane);
+      }
+      __builtin_amdgcn_wave_barrier();
+      f32x4 S[2];
+      {
+        float kA[C::KK];
+        rowop_from_lds<DH>(kA, Kt, 0, lane);
+        S[0] = S[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < C::KK; ++kk) {
+          S[0] = MFMA16(kA[kk], qB[0][kk], S[0]);
+          S[1] = MFMA16(kA[kk], qB[1][kk], S[1]);
+        }
+      }
+      const bool mine = g == e;                          // this lane group holds edge e's tail rows
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        f32x4 &s = S[nt];
+        if (!FULL) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (4 * g + q >= L) s[q] = kNegBig;
+        }
+        float m = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+        m = groups_max(fmaxf(m, mine ? (nt == 0 ? tm0 : tm1) : kNegBig));
+        f32x4 pt;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          s[q] = fast_exp2(s[q] - m);
+          pt[q] = fast_exp2(St[nt][q] - m);              // meaningful in group e only
+        }
+        const float lm = (s[0] + s[1]) + (s[2] + s[3]), lt = (pt[0] + pt[1]) + (pt[2] + pt[3]);
+        const float inv = fast_rcp(groups_sum(lm + (mine ? lt : 0.f)));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          s[q] *= inv;
+          St[nt][q] = mine ? pt[q] * inv : St[nt][q];    // edge e's tail rows become P^T
+        }
+      }
+#pragma unroll
+      for (int mc = 0; mc < C::MC; ++mc) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float vA = Vt[lds_idx<DH>(4 * g + q, n + 16 * mc)];
+          OT[mc][0] = MFMA16(vA, S[0][q], OT[mc][0]);
+          OT[mc][1] = MFMA16(vA, S[1][q], OT[mc][1]);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+
+    // closing product of the batch: contraction over (edge g, token 16 + q)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (!live) St[0][q] = St[1][q] = 0.f;
+    tail_to_lds<DH, FULL>(Vtail, vtn, L, lane);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int mc = 0; mc < C::MC; ++mc) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float vA = Vtail[lds_idx<DH>(4 * g + q, n + 16 * mc)];
+        OT[mc][0] = MFMA16(vA, St[0][q], OT[mc][0]);
+        OT[mc][1] = MFMA16(vA, St[1][q], OT[mc][1]);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    id0 = nid0; id1 = nid1; id2 = nid2; id3 = nid3;
+  }
+#undef AMPCONV_IDS
+
+  const float inv = a.hub.mode == 2 ? 1.f : (deg > 0 ? 1.f / (float)deg : 0.f);
+  float *ob = tile_ptr<float>(a.O, onode, h);
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int i = n + 16 * nt;
+    if (i < L) {
+#pragma unroll
+      for (int mc = 0; mc < C::MC; ++mc) {
+        float4 o = make_float4(OT[mc][nt][0] * inv, OT[mc][nt][1] * inv, OT[mc][nt][2] * inv,
+                               OT[mc][nt][3] * inv);
+        *reinterpret_cast<float4 *>(ob + (int64_t)i * a.O.row_stride + 4 * g + 16 * mc) = o;
+      }
+    }
+  }
+}
+
 inline bool aligned16(const ampconv_view_t &v) {
   return ((uintptr_t)v.ptr % 16 == 0) && (v.node_stride % 4 == 0) && (v.row_stride % 4 == 0) &&
          (v.head_stride % 4 == 0);
@@ -766,6 +1021,14 @@ int ampconv_fwd_edge_mfma(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
   const int64_t blocks = (a.n_units + kWavesPerBlock - 1) / kWavesPerBlock;
   if (blocks > INT32_MAX) return AMPCONV_E_BADARG;
   const dim3 grid((unsigned)blocks), block(64 * kWavesPerBlock);
+  static const bool t4 = !(std::getenv("AMPCONV_FWD_T4") && std::getenv("AMPCONV_FWD_T4")[0] == '0');
+  if (t4 && L > 16) {                    // batched tails pay only if there are tail tokens
+    if (dh == 32 && L == kLmax) fwd_mfma_t4<32, true><<<grid, block, 0, stream>>>(a);
+    else if (dh == 32) fwd_mfma_t4<32, false><<<grid, block, 0, stream>>>(a);
+    else if (L == kLmax) fwd_mfma_t4<16, true><<<grid, block, 0, stream>>>(a);
+    else fwd_mfma_t4<16, false><<<grid, block, 0, stream>>>(a);
+    return ampconv_launch_status();
+  }
   if (dh == 32 && L == kLmax) fwd_mfma<32, true, AMPCONV_PF_FWD><<<grid, block, 0, stream>>>(a);
   else if (dh == 32) fwd_mfma<32, false, 1><<<grid, block, 0, stream>>>(a);
   else if (L == kLmax) fwd_mfma<16, true, AMPCONV_PF_FWD><<<grid, block, 0, stream>>>(a);
