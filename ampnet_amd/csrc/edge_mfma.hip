@@ -994,6 +994,246 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void fwd_mfma_t4(FwdArgs a) {
   }
 }
 
+// ---- backward, destination pass with the tail tokens of four consecutive edges in one MFMA tile
+// (same batching as fwd_mfma_t4: the tail tiles S^T and dP^T of a batch come first, each edge's main
+// phase folds its lane group of them into its column max / sum / delta, the batch closes with
+// dQ^T += K_tail^T dS_tail^T over (edge, token) jointly).  84 -> 60 MFMAs per edge and head.
+// The tail rows (K and V rows 16..19 of four edges) are needed from the first to the last phase of
+// their batch, so the next batch's rows land in a second pair of LDS images, by LDS-DMA
+// (global_load_lds_dwordx4: no staging registers; each lane fetches the 16-byte chunk that belongs
+// at its linear position of the swizzled image).  They are issued right after the first main phase
+// has consumed its staged registers and are complete by the time any younger ordinary load has
+// been waited for, i.e. long before the next batch starts.
+template <int DH, bool FULL>
+__device__ __forceinline__ void tail_dma(float *img, const ampconv_view_t &view, int h, int id0, int id1, int id2,
+                                         int id3, int L, int lane) {
+  using C = TileCfg<DH>;
+  constexpr int ROWS = 64 / C::CH;                 // image rows per wave-instruction (1 KiB)
+#pragma unroll
+  for (int i = 0; i < 16 / ROWS; ++i) {
+    const int rho = ROWS * i + lane / C::CH, pos = lane % C::CH, tok = 16 + (rho & 3);
+    const int lo = (rho & 4) ? id1 : id0, hi = (rho & 4) ? id3 : id2;
+    const int node = (rho & 8) ? hi : lo;
+    const float *src = tile_ptr<const float>(view, node, h) + (int64_t)tok * view.row_stride +
+                       4 * (pos ^ swz<DH>(rho));
+    if (FULL || tok < L)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                       (__attribute__((address_space(3))) void *)(img + ROWS * i * DH), 16, 0, 0);
+  }
+}
+
+template <int DH, bool FULL, bool STATS>
+__global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? 3 : 4) void bwd_dst_mfma_t4(BwdArgs a) {
+  using C = TileCfg<DH>;
+  constexpr int kImg = 16 * DH;
+  __shared__ __attribute__((aligned(16))) float lds_all[kWavesPerBlock][6 * kImg];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t unit = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  if (unit >= a.n_units) return;
+  int64_t r, onode;
+  int h, beg, end, deg;
+  if (!map_unit(a.hub, a.ptr, unit, a.H, r, onode, h, beg, end, deg)) return;
+  const int L = a.L, g = lane >> 4, n = lane & 15;
+  float *Kt = lds_all[wave], *Vt = Kt + kImg;
+  const float inv = deg > 0 ? 1.f / (float)deg : 0.f;       // dO is the gradient of the MEAN
+  const float oscale = a.hub.mode == 2 ? 1.f : a.oscale;
+
+  float qB[2][C::KK], dOB[2][C::KK];
+  {
+    const float *qb = tile_ptr<const float>(a.Q, r, h);
+    const float *gb = tile_ptr<const float>(a.dO, r, h);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      rowop_from_global<DH>(qB[nt], qb, a.Q.row_stride, nt, true, a.qscale, L, lane);
+      rowop_from_global<DH>(dOB[nt], gb, a.dO.row_stride, nt, true, inv, L, lane);
+    }
+  }
+  if (!FULL)
+    for (int i = lane; i < 6 * kImg; i += AMPCONV_WAVE) Kt[i] = 0.f;
+  f32x4 dQT[C::MC][2];
+#pragma unroll
+  for (int mc = 0; mc < C::MC; ++mc) dQT[mc][0] = dQT[mc][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  IdxWindow win;
+  const float *wts = reinterpret_cast<const float *>(a.spos);
+  int id0 = 0, id1 = 0, id2 = 0, id3 = 0, nid0 = 0, nid1 = 0, nid2 = 0, nid3 = 0;
+  float sp0 = 0.f, sp1 = 0.f, sp2 = 0.f, sp3 = 0.f, nsp0 = 0.f, nsp1 = 0.f, nsp2 = 0.f, nsp3 = 0.f;   // CSC positions (int bits)
+#define AMPCONV_IDS(o0, o1, o2, o3, s0, s1, s2, s3, p)                                                 \
+  do {                                                                                                 \
+    const int p_ = (p);                                                                                \
+    o0 = idxwin_get<STATS>(win, a.idx, wts, p_ < end ? p_ : end - 1, end, lane, &s0);                   \
+    o1 = idxwin_get<STATS>(win, a.idx, wts, p_ + 1 < end ? p_ + 1 : end - 1, end, lane, &s1);           \
+    o2 = idxwin_get<STATS>(win, a.idx, wts, p_ + 2 < end ? p_ + 2 : end - 1, end, lane, &s2);           \
+    o3 = idxwin_get<STATS>(win, a.idx, wts, p_ + 3 < end ? p_ + 3 : end - 1, end, lane, &s3);           \
+  } while (0)
+  MainRegs<DH> ring;
+  int cur = 0;
+  if (beg < end) {
+    idxwin_load<STATS>(win, a.idx, wts, beg, end, lane);
+    AMPCONV_IDS(id0, id1, id2, id3, sp0, sp1, sp2, sp3, beg);
+    __builtin_amdgcn_wave_barrier();
+    tail_dma<DH, FULL>(Kt + 2 * kImg, a.K, h, id0, id1, id2, id3, L, lane);
+    tail_dma<DH, FULL>(Kt + 3 * kImg, a.V, h, id0, id1, id2, id3, L, lane);
+    main_load<DH, FULL>(ring, tile_ptr<const float>(a.K, id0, h), a.K.row_stride,
+                        tile_ptr<const float>(a.V, id0, h), a.V.row_stride, L, lane);
+  }
+
+  for (int p0 = beg; p0 < end; p0 += 4) {
+    const bool more = p0 + 4 < end;
+    if (more) AMPCONV_IDS(nid0, nid1, nid2, nid3, nsp0, nsp1, nsp2, nsp3, p0 + 4);
+    const bool live = p0 + g < end;                    // lane group g <-> edge p0 + g of the tail tiles
+    float *Ktail = Kt + (2 + 2 * cur) * kImg, *Vtail = Ktail + kImg;
+
+    // this batch's tail rows were issued a batch ago (or in the prologue), BEFORE the staged loads of
+    // the first main tile: everything but those youngest loads must have landed
+    if (FULL) {
+      if (MainRegs<DH>::NP == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_wave_barrier();
+    f32x4 St[2], dPt[2];
+    St[0] = St[1] = dPt[0] = dPt[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    {
+      float kt[C::KK], vt[C::KK];
+      rowop_from_lds<DH>(kt, Ktail, 0, lane);
+      rowop_from_lds<DH>(vt, Vtail, 0, lane);
+#pragma unroll
+      for (int kk = 0; kk < C::KK; ++kk) {
+        St[0] = MFMA16(kt[kk], qB[0][kk], St[0]);
+        St[1] = MFMA16(kt[kk], qB[1][kk], St[1]);
+        dPt[0] = MFMA16(vt[kk], dOB[0][kk], dPt[0]);
+        dPt[1] = MFMA16(vt[kk], dOB[1][kk], dPt[1]);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (!live || (!FULL && 16 + q >= L)) St[0][q] = St[1][q] = kNegBig;
+    const float tm0 = fmaxf(fmaxf(St[0][0], St[0][1]), fmaxf(St[0][2], St[0][3]));
+    const float tm1 = fmaxf(fmaxf(St[1][0], St[1][1]), fmaxf(St[1][2], St[1][3]));
+
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (p0 + e >= end) break;
+      main_to_lds<DH, FULL>(Kt, ring, L, lane);
+      {
+        const bool has_next = e < 3 ? p0 + e + 1 < end : more;
+        const int next = e == 0 ? id1 : e == 1 ? id2 : e == 2 ? id3 : nid0;
+        if (has_next)
+          main_load<DH, FULL>(ring, tile_ptr<const float>(a.K, next, h), a.K.row_stride,
+                              tile_ptr<const float>(a.V, next, h), a.V.row_stride, L, lane);
+      }
+      if (e == 0 && more) {          // next batch's tail rows -> the other pair of images
+        float *Knext = Kt + (2 + 2 * (cur ^ 1)) * kImg;
+        tail_dma<DH, FULL>(Knext, a.K, h, nid0, nid1, nid2, nid3, L, lane);
+        tail_dma<DH, FULL>(Knext + kImg, a.V, h, nid0, nid1, nid2, nid3, L, lane);
+      }
+      __builtin_amdgcn_wave_barrier();
+      const bool mine = g == e;
+      float *sb = nullptr;
+      if (STATS) {
+        const float pos = e == 0 ? sp0 : e == 1 ? sp1 : e == 2 ? sp2 : sp3;
+        sb = a.stats + ((int64_t)__builtin_bit_cast(int, pos) * a.H + h) * kStatsPerUnit;
+      }
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        f32x4 S0 = f32x4{0.f, 0.f, 0.f, 0.f}, dP0 = S0;
+        {
+          float kA[C::KK], vA[C::KK];
+          rowop_from_lds<DH>(kA, Kt, 0, lane);
+          rowop_from_lds<DH>(vA, Vt, 0, lane);
+#pragma unroll
+          for (int kk = 0; kk < C::KK; ++kk) {
+            S0 = MFMA16(kA[kk], qB[nt][kk], S0);
+            dP0 = MFMA16(vA[kk], dOB[nt][kk], dP0);
+          }
+        }
+        if (!FULL) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (4 * g + q >= L) S0[q] = kNegBig;
+        }
+        float m = fmaxf(fmaxf(S0[0], S0[1]), fmaxf(S0[2], S0[3]));
+        m = groups_max(fmaxf(m, mine ? (nt == 0 ? tm0 : tm1) : kNegBig));
+        f32x4 pt;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          S0[q] = fast_exp2(S0[q] - m);
+          pt[q] = fast_exp2(St[nt][q] - m);              // meaningful in group e only
+        }
+        const float lm = (S0[0] + S0[1]) + (S0[2] + S0[3]), lt = (pt[0] + pt[1]) + (pt[2] + pt[3]);
+        const float l = groups_sum(lm + (mine ? lt : 0.f));
+        const float rinv = fast_rcp(l);
+        float part = 0.f, partt = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          S0[q] *= rinv;
+          pt[q] *= rinv;
+          part = fmaf(S0[q], dP0[q], part);
+          partt = fmaf(pt[q], dPt[nt][q], partt);
+        }
+        const float delta = groups_sum(part + (mine ? partt : 0.f));
+        if (STATS) {
+          const int i = n + 16 * nt;
+          if (g == 0 && i < kLmax) {
+            sb[i] = m + __builtin_amdgcn_logf(l);
+            sb[kLmax + i] = delta;
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          S0[q] *= dP0[q] - delta;                                           // dS^T, main rows
+          dPt[nt][q] = mine ? pt[q] * (dPt[nt][q] - delta) : dPt[nt][q];      // dS^T, edge e's tail rows
+        }
+#pragma unroll
+        for (int mc = 0; mc < C::MC; ++mc) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float kC = Kt[lds_idx<DH>(4 * g + q, n + 16 * mc)];
+            dQT[mc][nt] = MFMA16(kC, S0[q], dQT[mc][nt]);
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+
+    // closing product of the batch: contraction over (edge g, token 16 + q)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      if (!live) dPt[0][q] = dPt[1][q] = 0.f;
+#pragma unroll
+    for (int mc = 0; mc < C::MC; ++mc) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float kC = Ktail[lds_idx<DH>(4 * g + q, n + 16 * mc)];
+        dQT[mc][0] = MFMA16(kC, dPt[0][q], dQT[mc][0]);
+        dQT[mc][1] = MFMA16(kC, dPt[1][q], dQT[mc][1]);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    id0 = nid0; id1 = nid1; id2 = nid2; id3 = nid3;
+    sp0 = nsp0; sp1 = nsp1; sp2 = nsp2; sp3 = nsp3;
+    cur ^= 1;
+  }
+#undef AMPCONV_IDS
+
+  float *ob = tile_ptr<float>(a.dQ, onode, h);
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int i = n + 16 * nt;
+    if (i < L) {
+#pragma unroll
+      for (int mc = 0; mc < C::MC; ++mc) {
+        float4 o = make_float4(dQT[mc][nt][0] * oscale, dQT[mc][nt][1] * oscale,
+                               dQT[mc][nt][2] * oscale, dQT[mc][nt][3] * oscale);
+        *reinterpret_cast<float4 *>(ob + (int64_t)i * a.dQ.row_stride + 4 * g + 16 * mc) = o;
+      }
+    }
+  }
+}
+
 inline bool aligned16(const ampconv_view_t &v) {
   return ((uintptr_t)v.ptr % 16 == 0) && (v.node_stride % 4 == 0) && (v.row_stride % 4 == 0) &&
          (v.head_stride % 4 == 0);
@@ -1052,6 +1292,21 @@ int ampconv_bwd_edge_dst_mfma(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t
   const int64_t blocks = (a.n_units + kWavesPerBlock - 1) / kWavesPerBlock;
   if (blocks > INT32_MAX) return AMPCONV_E_BADARG;
   const dim3 grid((unsigned)blocks), block(64 * kWavesPerBlock);
+  static const bool t4 = !(std::getenv("AMPCONV_DST_T4") && std::getenv("AMPCONV_DST_T4")[0] == '0');
+  if (t4 && L > 16) {                    // batched tails pay only if there are tail tokens
+    if (st.stats) {
+      if (dh == 32 && L == kLmax) bwd_dst_mfma_t4<32, true, true><<<grid, block, 0, stream>>>(a);
+      else if (dh == 32) bwd_dst_mfma_t4<32, false, true><<<grid, block, 0, stream>>>(a);
+      else if (L == kLmax) bwd_dst_mfma_t4<16, true, true><<<grid, block, 0, stream>>>(a);
+      else bwd_dst_mfma_t4<16, false, true><<<grid, block, 0, stream>>>(a);
+    } else {
+      if (dh == 32 && L == kLmax) bwd_dst_mfma_t4<32, true, false><<<grid, block, 0, stream>>>(a);
+      else if (dh == 32) bwd_dst_mfma_t4<32, false, false><<<grid, block, 0, stream>>>(a);
+      else if (L == kLmax) bwd_dst_mfma_t4<16, true, false><<<grid, block, 0, stream>>>(a);
+      else bwd_dst_mfma_t4<16, false, false><<<grid, block, 0, stream>>>(a);
+    }
+    return ampconv_launch_status();
+  }
   if (st.stats) {
     if (dh == 32 && L == kLmax) bwd_dst_mfma<32, true, AMPCONV_PF_DST, true><<<grid, block, 0, stream>>>(a);
     else if (dh == 32) bwd_dst_mfma<32, false, 1, true><<<grid, block, 0, stream>>>(a);

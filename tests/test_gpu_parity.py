@@ -537,8 +537,9 @@ def test_random_shapes_mfma_vs_generic(seed, family, dev, monkeypatch):
         assert_close_scaled(a, b, f'{name} (N={N} E={E} L={L} D={D} H={H} kind={kind})')
 
 
-@pytest.mark.parametrize('shape', [(900, 9000, 20, 256, 8), (500, 6000, 13, 64, 4), (400, 5000, 20, 64, 4)],
-                         ids=['L20_dh32', 'L13_dh16', 'L20_dh16_hub'])
+@pytest.mark.parametrize('shape', [(900, 9000, 20, 256, 8), (500, 6000, 13, 64, 4), (400, 5000, 20, 64, 4),
+                                   (350, 4000, 18, 128, 4), (350, 4000, 17, 32, 2)],
+                         ids=['L20_dh32', 'L13_dh16', 'L20_dh16_hub', 'L18_dh32', 'L17_dh16'])
 def test_softmax_stats_handoff_matches_own_reduction(shape, dev, monkeypatch):
     # the source pass either re-reduces softmax / delta across lanes or reads what the destination
     # pass stored (include/ampconv.h "Softmax statistics"): same gradients to fp32 rounding, on
@@ -582,3 +583,44 @@ def test_softmax_stats_rejected_where_unsupported(dev):
     assert lib.ampconv_softmax_stats_bytes(1000, 40, 100, 2, _lib.AMPCONV_F32) == 1000 * 2 * 2 * 48 * 4   # edge_block.hip
     assert lib.ampconv_softmax_stats_bytes(1000, 20, 256, 8, _lib.AMPCONV_BF16) == 0      # HBM-bound: no gain
     assert lib.ampconv_softmax_stats_bytes(1000, 20, 256, 8, _lib.AMPCONV_F32_BF16X6) == 0
+
+
+@pytest.mark.parametrize('shape', [(260, 2600, 17, 64, 2), (260, 2600, 18, 128, 8), (260, 2600, 19, 96, 3),
+                                   (260, 2600, 20, 32, 2)], ids=['L17_dh32', 'L18_dh16', 'L19_dh32', 'L20_dh16'])
+def test_batched_tail_kernels_vs_generic(shape, dev, monkeypatch):
+    """The batched-tail kernels (fwd / dst / src `_t4`: tail tokens of four edges in one MFMA tile) on
+    partially filled tails (L = 17..19), segment lengths of every residue mod 4, a hub and isolated
+    nodes, against the independent shape-generic kernels; and with the batching switched off."""
+    from ampnet_amd import AMPConv, graph_cache
+    N, E, L, D, H = shape
+    g = torch.Generator().manual_seed(L * 1000 + D)
+    ei = torch.randint(0, N, (2, E), generator=g)
+    ei[1, :150] = 3                                   # hub destination
+    ei[0, 150:300] = 5                                # hub source
+    for k in range(1, 8):                             # nodes with exactly k in-edges and k out-edges
+        ei[1, 300 + 10 * k: 300 + 11 * k] = 100 + k
+        ei[1, ei[1] == 100 + k] = 100 + k
+        ei[0, 600 + 10 * k: 600 + 11 * k] = 200 + k
+    ei[1, ei[1] == 7] = 8                             # node 7 receives nothing
+    torch.manual_seed(L)
+    layer = AMPConv(D, H).to(dev)
+    with torch.no_grad():
+        layer.multi_head_attention.in_proj_bias.normal_(0, 0.2)
+    x = torch.randn(N, L * D, generator=g).to(dev)
+    dy = torch.randn(N, L * D, generator=g).to(dev)
+
+    def run():
+        graph_cache.clear()
+        layer.zero_grad(set_to_none=True)
+        xg = x.clone().requires_grad_(True)
+        y = layer(xg, ei.to(dev))
+        y.backward(dy)
+        m = layer.multi_head_attention
+        return [t.detach().cpu().numpy() for t in (y, xg.grad, m.in_proj_weight.grad, m.in_proj_bias.grad,
+                                                    m.out_proj.weight.grad, m.out_proj.bias.grad)]
+
+    fast = run()
+    monkeypatch.setenv('AMPCONV_FORCE_GENERIC', '1')
+    slow = run()
+    for name, a, b in zip(['y', 'dx', 'gWin', 'gbin', 'gWo', 'gbo'], fast, slow):
+        assert_close_scaled(a, b, name)
