@@ -287,7 +287,7 @@ def main():
             'config': {'workload': f'{args.workload}: {desc}, one AMPConv layer fwd+bwd incl. CSR build, '
                                    f'one graph per GPU' + (' + RCCL grad all-reduce' if world > 1 else ''),
                        'N': N, 'E': E, 'L': L, 'D': D, 'H': H, 'parallelism': f'dp{world}',
-                       'gemm': args.gemm},
+                       'gemm': args.gemm if dt_name == 'f32' else 'bf16'},
             'layer_hbm': {'algorithmic_bytes_per_step': b_alg,
                           'achieved_GBps_per_gpu': b_alg * args.steps / dt / 1e9,
                           'frac_of_8TBps': b_alg * args.steps / dt / 1e9 / HBM_PEAK_GBS},
