@@ -84,10 +84,11 @@ __device__ __forceinline__ void tiles_zero(char *tiles, int lane) {
   for (int i = lane; i < 2 * kTileBytes / 4; i += AMPCONV_WAVE) z[i] = 0;
 }
 
-// channel-product fragment of row tile mt from LDS (tile 1: tokens 16..19 in rows 0..3)
+// channel-product fragment of row tile mt from LDS.  Tile 1 uses the quarter map of mfma_tile.h:
+// MFMA row m <-> token 16 + (m >> 2), so in C/D layout lane group g holds token 16 + g in reg 0
 __device__ __forceinline__ i32x4 rowfrag(const char *tile, int mt, int lane) {
   const int m = lane & 15, kg = lane >> 4;
-  const int j = mt == 0 ? m : 16 + (m & 3);
+  const int j = mt == 0 ? m : 16 + (m >> 2);
   return *reinterpret_cast<const i32x4 *>(tile + plane_off(j, kg));
 }
 // ... of column tile nt straight from global memory (fixed side; token rows >= L read as zero)
@@ -99,31 +100,32 @@ __device__ __forceinline__ i32x4 rowfrag_global(const bf16_t *base, int64_t row_
   if (j < L) x = *reinterpret_cast<const i32x4 *>(base + (int64_t)j * row_stride + 8 * kg);
   return x;
 }
-// token-product fragment of channel tile mc: k-slots 0..3 = tokens 4kg..4kg+3, 4..7 = tokens 16..19
+// token-product fragment of channel tile mc: k-slots 0..3 = tokens 4kg..4kg+3, slot 4 = token 16 + kg
+// (slots 5..7 repeat it; the other operand holds zeros there)
 __device__ __forceinline__ i32x4 colfrag(const char *tile, int mc, int lane) {
   const int q = (lane >> 2) & 3, pp = lane & 3, kg = lane >> 4;
   const int ch = 2 * mc + (pp >> 1), half = (pp & 1) << 3;
   const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
       (__attribute__((address_space(3))) s16x4 *)(tile + plane_off(4 * kg + q, ch) + half));
   const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-      (__attribute__((address_space(3))) s16x4 *)(tile + plane_off(16 + q, ch) + half));
+      (__attribute__((address_space(3))) s16x4 *)(tile + plane_off(16 + kg, ch) + half));
   const i32x2 ai = __builtin_bit_cast(i32x2, a), bi = __builtin_bit_cast(i32x2, b);
   return i32x4{ai[0], ai[1], bi[0], bi[1]};
 }
-// C/D registers -> token-product fragment (t1 must already be zero outside lane group 0)
+// C/D registers -> token-product fragment (t1[1..3] must already be zero: only reg 0 of tile 1 is a token)
 __device__ __forceinline__ i32x4 cd_frag(const f32x4 &t0, const f32x4 &t1) {
   return i32x4{cvt_pk_bf16(t0[0], t0[1]), cvt_pk_bf16(t0[2], t0[3]), cvt_pk_bf16(t1[0], t1[1]),
                cvt_pk_bf16(t1[2], t1[3])};
 }
 
 // softmax over the 20 source tokens of one destination-token column; `sc` = log2e/sqrt(dh) is
-// applied to the raw scores here.  t0[q] = token 4g + q, t1[q] = token 16 + q (lane group 0 only)
+// applied to the raw scores here.  t0[q] = token 4g + q, t1[0] = token 16 + g (regs 1..3 of tile 1 replicate it)
 template <bool FULL>
 __device__ __forceinline__ void column_softmax(f32x4 &t0, f32x4 &t1, float sc, int L, int g) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     if (!FULL && 4 * g + q >= L) t0[q] = kNegBig;
-    if (g != 0 || (!FULL && 16 + q >= L)) t1[q] = kNegBig;
+    if (q != 0 || (!FULL && 16 + g >= L)) t1[q] = kNegBig;
   }
   float m = fmaxf(fmaxf(fmaxf(t0[0], t0[1]), fmaxf(t0[2], t0[3])),
                   fmaxf(fmaxf(t1[0], t1[1]), fmaxf(t1[2], t1[3])));
@@ -304,7 +306,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void bwd_dst_bf16(Args a) {
     i32x4 sB[2];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
-      column_softmax<FULL>(S[0][nt], S[1][nt], a.qscale, L, g);   // P^T; tile-1 weights 0 for g != 0
+      column_softmax<FULL>(S[0][nt], S[1][nt], a.qscale, L, g);   // P^T; tile-1 regs 1..3 get weight 0
       float part = 0.f;
 #pragma unroll
       for (int q = 0; q < 4; ++q) part = fmaf(S[0][nt][q], dP[0][nt][q], fmaf(S[1][nt][q], dP[1][nt][q], part));
@@ -370,7 +372,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void bwd_src_bf16(Args a) {
     idxwin_load<true>(win, a.idx, a.cinv, beg, end, lane);
     fetch(beg, inv_next);
   }
-  const bool v0 = FULL || n < L, v1 = 16 + n < L, g0 = lane < 16;
+  const bool v0 = FULL || n < L, v1 = 16 + n < L;
   for (int p = beg; p < end; ++p) {
     pair_to_lds_h<FULL>(Qt, qg, L, lane);
     inv = inv_next;
@@ -388,17 +390,16 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void bwd_src_bf16(Args a) {
       }
     }
     // row softmax over the source tokens (columns n, 16 + n across the 16 lanes of a DPP row);
-    // rows: tile 0 reg q = destination token 4g + q, tile 1 reg q = token 16 + q in lane group 0.
+    // rows: tile 0 reg q = destination token 4g + q, tile 1 reg 0 = token 16 + g (quarter map).
     // After this block S holds P * (1/deg) (for dV) and dP holds dS (1/deg included).
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < (mt == 0 ? 4 : 1); ++q) {
         const float s0 = v0 ? S[mt][0][q] : kNegBig, s1 = v1 ? S[mt][1][q] : kNegBig;
         const float m = row16_max(fmaxf(s0, s1));
         float p0 = fast_exp2((s0 - m) * a.qscale), p1 = fast_exp2((s1 - m) * a.qscale);
-        float rinv = fast_rcp(row16_sum(p0 + p1));
-        if (mt == 1 && !g0) rinv = 0.f;                    // rows of tile 1 exist in group 0 only
+        const float rinv = fast_rcp(row16_sum(p0 + p1));
         p0 *= rinv;
         p1 *= rinv;
         const float delta = row16_sum(fmaf(p0, dP[mt][0][q], p1 * dP[mt][1][q]));
@@ -408,6 +409,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void bwd_src_bf16(Args a) {
         dP[mt][1][q] = p1 * (dP[mt][1][q] - delta) * inv;
       }
     }
+#pragma unroll
+    for (int q = 1; q < 4; ++q)            // regs 1..3 of tile 1 are replicas, not tokens
+      S[1][0][q] = S[1][1][q] = dP[1][0][q] = dP[1][1][q] = 0.f;
     i32x4 pB[2], sB[2];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
