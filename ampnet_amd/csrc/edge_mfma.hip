@@ -891,12 +891,21 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void fwd_mfma_t4(FwdArgs a) {
         St[1] = MFMA16(kt[kk], qB[1][kk], St[1]);
       }
     }
-    float tm0, tm1;
+    // per lane (edge g, destination column): tail max tm, u = exp2(S - tm) and their sum, once per
+    // batch; an edge's main phase only rescales them by exp2(tm - m) / l.  (The destination pass keeps
+    // the per-edge form: the four extra live registers spill inside its loop and the gain is lost.)
+    float tm[2], tsum[2], csel[2] = {0.f, 0.f};
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (!live || (!FULL && 16 + q >= L)) St[0][q] = St[1][q] = kNegBig;
-    tm0 = fmaxf(fmaxf(St[0][0], St[0][1]), fmaxf(St[0][2], St[0][3]));
-    tm1 = fmaxf(fmaxf(St[1][0], St[1][1]), fmaxf(St[1][2], St[1][3]));
+    for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (!live || (!FULL && 16 + q >= L)) St[nt][q] = kNegBig;
+      tm[nt] = fmaxf(fmaxf(St[nt][0], St[nt][1]), fmaxf(St[nt][2], St[nt][3]));
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        St[nt][q] = (live && (FULL || 16 + q < L)) ? fast_exp2(St[nt][q] - tm[nt]) : 0.f;
+      tsum[nt] = (St[nt][0] + St[nt][1]) + (St[nt][2] + St[nt][3]);
+    }
 
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -931,20 +940,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void fwd_mfma_t4(FwdArgs a) {
             if (4 * g + q >= L) s[q] = kNegBig;
         }
         float m = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
-        m = groups_max(fmaxf(m, mine ? (nt == 0 ? tm0 : tm1) : kNegBig));
-        f32x4 pt;
+        m = groups_max(fmaxf(m, mine ? tm[nt] : kNegBig));
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          s[q] = fast_exp2(s[q] - m);
-          pt[q] = fast_exp2(St[nt][q] - m);              // meaningful in group e only
-        }
-        const float lm = (s[0] + s[1]) + (s[2] + s[3]), lt = (pt[0] + pt[1]) + (pt[2] + pt[3]);
-        const float inv = fast_rcp(groups_sum(lm + (mine ? lt : 0.f)));
+        for (int q = 0; q < 4; ++q) s[q] = fast_exp2(s[q] - m);
+        const float lm = (s[0] + s[1]) + (s[2] + s[3]);
+        const float ct = fast_exp2(tm[nt] - m);            // meaningful in group e only
+        const float inv = fast_rcp(groups_sum(lm + (mine ? ct * tsum[nt] : 0.f)));
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          s[q] *= inv;
-          St[nt][q] = mine ? pt[q] * inv : St[nt][q];    // edge e's tail rows become P^T
-        }
+        for (int q = 0; q < 4; ++q) s[q] *= inv;
+        csel[nt] = mine ? ct * inv : csel[nt];             // edge e's tail rows: P^T = u * csel
       }
 #pragma unroll
       for (int mc = 0; mc < C::MC; ++mc) {
@@ -960,8 +964,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void fwd_mfma_t4(FwdArgs a) {
 
     // closing product of the batch: contraction over (edge g, token 16 + q)
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (!live) St[0][q] = St[1][q] = 0.f;
+    for (int q = 0; q < 4; ++q) {          // u = 0 for edges beyond the segment and tokens beyond L
+      St[0][q] *= csel[0];
+      St[1][q] *= csel[1];
+    }
     tail_to_lds<DH, FULL>(Vtail, vtn, L, lane);
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
