@@ -624,3 +624,37 @@ def test_batched_tail_kernels_vs_generic(shape, dev, monkeypatch):
     slow = run()
     for name, a, b in zip(['y', 'dx', 'gWin', 'gbin', 'gWo', 'gbo'], fast, slow):
         assert_close_scaled(a, b, name)
+
+
+def test_batched_tail_kernels_large_scores(dev, monkeypatch):
+    """Scores spread over hundreds of log2 units between the edges of one destination: in the
+    batched-tail kernels every lane group evaluates exp2(tail score of ITS edge - max of the edge being
+    processed), which overflows to inf in the groups that are then discarded by a select.  No inf or
+    NaN may leak into the results, and they must still agree with the generic kernels."""
+    from ampnet_amd import AMPConv, graph_cache
+    N, E, L, D, H = 200, 2400, 20, 64, 2
+    g = torch.Generator().manual_seed(99)
+    ei = torch.randint(0, N, (2, E), generator=g).to(dev)
+    torch.manual_seed(17)
+    layer = AMPConv(D, H).to(dev)
+    x = torch.randn(N, L * D, generator=g)
+    x[::3] *= 25.0                                  # a third of the nodes produce huge keys / queries
+    x = x.to(dev)
+    dy = torch.randn(N, L * D, generator=g).to(dev)
+
+    def run():
+        graph_cache.clear()
+        layer.zero_grad(set_to_none=True)
+        xg = x.clone().requires_grad_(True)
+        y = layer(xg, ei)
+        y.backward(dy)
+        m = layer.multi_head_attention
+        return [t.detach().cpu().numpy() for t in (y, xg.grad, m.in_proj_weight.grad, m.out_proj.weight.grad)]
+
+    fast = run()
+    for t in fast:
+        assert np.isfinite(t).all()
+    monkeypatch.setenv('AMPCONV_FORCE_GENERIC', '1')
+    slow = run()
+    for name, a, b in zip(['y', 'dx', 'gWin', 'gWo'], fast, slow):
+        assert_close_scaled(a, b, name, atol=3e-5, rtol=3e-4)      # saturated softmaxes amplify rounding
