@@ -195,10 +195,24 @@ class AMPConvFunction(torch.autograd.Function):
                                           csr.cinv.data_ptr(), Nk, L, D, H, dKv, dVv, plan, nch, _ptr(ws),
                                           _ptr(stats), ctx.dtype, _stream())
             _lib.check(rc, 'ampconv_bwd_edge_src')
+            # in_proj_bias gradient without a pass over all of dQKV: softmax rows sum to 1, so the
+            # column sum of dV over every source token equals the column sum of dObar over the rows
+            # that receive messages (the same masked sum as db_out), and the K bias shifts every
+            # score of a row equally, i.e. has gradient exactly 0 (torch's autograd returns ~1e-9 noise)
+            db_v = None
+            if shared and dy2.dtype == torch.float32:
+                scratch_v = torch.empty_like(scratch)          # `scratch` still backs db_out
+                rc = lib.ampconv_masked_colsum(dobar.data_ptr(), csr.rowptr.data_ptr(), Nq, L, D,
+                                               scratch_v.data_ptr(), io, _stream())
+                _lib.check(rc, 'ampconv_masked_colsum')
+                db_v = scratch_v[:D]
             del dobar, stats
             if shared:
                 dw_in = _tn_matmul(dqkv, xq2)
-                db_in = dqkv.sum(dim=0)
+                if db_v is not None:
+                    db_in = torch.cat([dqkv[:, :D].sum(dim=0), torch.zeros_like(db_v), db_v])
+                else:
+                    db_in = dqkv.sum(dim=0)
                 dxq = dqkv.mm(w_in).view(Nq, L * D) if need_xq else None
                 dxkv = None
             else:
