@@ -1022,9 +1022,17 @@ __device__ __forceinline__ void tail_dma(float *img, const ampconv_view_t &view,
     const int node = (rho & 8) ? hi : lo;
     const float *src = tile_ptr<const float>(view, node, h) + (int64_t)tok * view.row_stride +
                        4 * (pos ^ swz<DH>(rho));
+    // Issued as inline assembly on purpose: behind the builtin the compiler orders EVERY later LDS read
+    // after the DMA (`s_waitcnt vmcnt(0)` right after the issue = the whole memory latency, once per
+    // batch, also for reads of other LDS objects).  The caller waits for the images itself.
+    const unsigned dst = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)(img + ROWS * i * DH);
+    unsigned saved_m0;
     if (FULL || tok < L)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                       (__attribute__((address_space(3))) void *)(img + ROWS * i * DH), 16, 0, 0);
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
+                   "s_mov_b32 m0, %0"
+                   : "=&s"(saved_m0)
+                   : "v"(src), "s"(dst)
+                   : "memory");
   }
 }
 
@@ -1032,7 +1040,11 @@ template <int DH, bool FULL, bool STATS>
 __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? 3 : 4) void bwd_dst_mfma_t4(BwdArgs a) {
   using C = TileCfg<DH>;
   constexpr int kImg = 16 * DH;
-  __shared__ __attribute__((aligned(16))) float lds_all[kWavesPerBlock][6 * kImg];
+  // two separate LDS objects: the compiler orders every LDS read behind an LDS-DMA it cannot prove
+  // disjoint from it (a `vmcnt(0)` right after the issue, i.e. the whole memory latency once per
+  // batch); reads of the main images provably never touch the tail images this way
+  __shared__ __attribute__((aligned(16))) float lds_all[kWavesPerBlock][2 * kImg];
+  __shared__ __attribute__((aligned(16))) float lds_tails[kWavesPerBlock][4 * kImg];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t unit = (int64_t)blockIdx.x * kWavesPerBlock + wave;
@@ -1041,7 +1053,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? 3 : 4) void bwd_dst
   int h, beg, end, deg;
   if (!map_unit(a.hub, a.ptr, unit, a.H, r, onode, h, beg, end, deg)) return;
   const int L = a.L, g = lane >> 4, n = lane & 15;
-  float *Kt = lds_all[wave], *Vt = Kt + kImg;
+  float *Kt = lds_all[wave], *Vt = Kt + kImg, *tails = lds_tails[wave];
   const float inv = deg > 0 ? 1.f / (float)deg : 0.f;       // dO is the gradient of the MEAN
   const float oscale = a.hub.mode == 2 ? 1.f : a.oscale;
 
@@ -1055,8 +1067,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? 3 : 4) void bwd_dst
       rowop_from_global<DH>(dOB[nt], gb, a.dO.row_stride, nt, true, inv, L, lane);
     }
   }
-  if (!FULL)
-    for (int i = lane; i < 6 * kImg; i += AMPCONV_WAVE) Kt[i] = 0.f;
+  if (!FULL) {
+    for (int i = lane; i < 2 * kImg; i += AMPCONV_WAVE) Kt[i] = 0.f;
+    for (int i = lane; i < 4 * kImg; i += AMPCONV_WAVE) tails[i] = 0.f;
+  }
   f32x4 dQT[C::MC][2];
 #pragma unroll
   for (int mc = 0; mc < C::MC; ++mc) dQT[mc][0] = dQT[mc][1] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -1079,8 +1093,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? 3 : 4) void bwd_dst
     idxwin_load<STATS>(win, a.idx, wts, beg, end, lane);
     AMPCONV_IDS(id0, id1, id2, id3, sp0, sp1, sp2, sp3, beg);
     __builtin_amdgcn_wave_barrier();
-    tail_dma<DH, FULL>(Kt + 2 * kImg, a.K, h, id0, id1, id2, id3, L, lane);
-    tail_dma<DH, FULL>(Kt + 3 * kImg, a.V, h, id0, id1, id2, id3, L, lane);
+    tail_dma<DH, FULL>(tails, a.K, h, id0, id1, id2, id3, L, lane);
+    tail_dma<DH, FULL>(tails + kImg, a.V, h, id0, id1, id2, id3, L, lane);
     main_load<DH, FULL>(ring, tile_ptr<const float>(a.K, id0, h), a.K.row_stride,
                         tile_ptr<const float>(a.V, id0, h), a.V.row_stride, L, lane);
   }
@@ -1089,15 +1103,16 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? 3 : 4) void bwd_dst
     const bool more = p0 + 4 < end;
     if (more) AMPCONV_IDS(nid0, nid1, nid2, nid3, nsp0, nsp1, nsp2, nsp3, p0 + 4);
     const bool live = p0 + g < end;                    // lane group g <-> edge p0 + g of the tail tiles
-    float *Ktail = Kt + (2 + 2 * cur) * kImg, *Vtail = Ktail + kImg;
+    float *Ktail = tails + 2 * cur * kImg, *Vtail = Ktail + kImg;
 
-    // this batch's tail rows were issued a batch ago (or in the prologue), BEFORE the staged loads of
-    // the first main tile: everything but those youngest loads must have landed
-    if (FULL) {
-      if (MainRegs<DH>::NP == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    // this batch's tail images: the first batch's were issued in the prologue just BEFORE the staged
+    // loads of the first main tile (everything but those youngest loads must have landed); a later
+    // batch's were issued four main phases ago, and every main phase since has waited for loads
+    // younger than them (vector-memory operations retire in order)
+    if (p0 == beg) {
+      if (!FULL) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (MainRegs<DH>::NP == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     __builtin_amdgcn_wave_barrier();
     f32x4 St[2], dPt[2];
@@ -1124,17 +1139,17 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? 3 : 4) void bwd_dst
     for (int e = 0; e < 4; ++e) {
       if (p0 + e >= end) break;
       main_to_lds<DH, FULL>(Kt, ring, L, lane);
+      if (e == 0 && more) {          // next batch's tail rows -> the other pair of images; issued BEFORE
+        float *Knext = tails + 2 * (cur ^ 1) * kImg;   // this phase's staged loads, so that the wait for
+        tail_dma<DH, FULL>(Knext, a.K, h, nid0, nid1, nid2, nid3, L, lane);           // those (next phase)
+        tail_dma<DH, FULL>(Knext + kImg, a.V, h, nid0, nid1, nid2, nid3, L, lane);    // does not stall on them
+      }
       {
         const bool has_next = e < 3 ? p0 + e + 1 < end : more;
         const int next = e == 0 ? id1 : e == 1 ? id2 : e == 2 ? id3 : nid0;
         if (has_next)
           main_load<DH, FULL>(ring, tile_ptr<const float>(a.K, next, h), a.K.row_stride,
                               tile_ptr<const float>(a.V, next, h), a.V.row_stride, L, lane);
-      }
-      if (e == 0 && more) {          // next batch's tail rows -> the other pair of images
-        float *Knext = Kt + (2 + 2 * (cur ^ 1)) * kImg;
-        tail_dma<DH, FULL>(Knext, a.K, h, nid0, nid1, nid2, nid3, L, lane);
-        tail_dma<DH, FULL>(Knext + kImg, a.V, h, nid0, nid1, nid2, nid3, L, lane);
       }
       __builtin_amdgcn_wave_barrier();
       const bool mine = g == e;
