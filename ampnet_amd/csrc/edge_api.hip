@@ -94,8 +94,19 @@ extern "C" int ampconv_fwd_edge(ampconv_view_t Q, ampconv_view_t K, ampconv_view
     return ampconv_fwd_edge_mfma(Q, K, V, rowptr, col, qidx, n_rows, L, D, H, O, HubArgs{nullptr, 0},
                                  (hipStream_t)stream);
   }
-  if (!force_generic() && ampconv_block_supported(L, D, H, views, 4))
-    return ampconv_fwd_edge_block(Q, K, V, rowptr, col, qidx, n_rows, L, D, H, O, (hipStream_t)stream);
+  if (!force_generic() && ampconv_block_supported(L, D, H, views, 4)) {
+    hipStream_t st = (hipStream_t)stream;
+    if (hub_plan && hub_chunks > 0 && hub_ws && !qidx) {      // long segments: main + hub + combine
+      if (int rc = ampconv_fwd_edge_block(Q, K, V, rowptr, col, nullptr, n_rows, L, D, H, O, hub_args(hub_plan, 1), st))
+        return rc;
+      ampconv_view_t P = partial_view(hub_ws, 0, hub_chunks, L, D, H);
+      if (int rc = ampconv_fwd_edge_block(Q, K, V, rowptr, col, nullptr, hub_chunks, L, D, H, P,
+                                          hub_args(hub_plan, 2), st))
+        return rc;
+      return ampconv_hub_combine(hub_plan, hub_chunks, (const float *)P.ptr, O, rowptr, L, D, H, 1.f, 0, st);
+    }
+    return ampconv_fwd_edge_block(Q, K, V, rowptr, col, qidx, n_rows, L, D, H, O, HubArgs{nullptr, 0}, st);
+  }
   return ampconv_fwd_edge_generic(Q, K, V, rowptr, col, qidx, n_rows, L, D, H, O,
                                   (hipStream_t)stream);
 }
@@ -162,8 +173,21 @@ extern "C" int ampconv_bwd_edge_dst(ampconv_view_t Q, ampconv_view_t K, ampconv_
                                      HubArgs{nullptr, 0}, sa, (hipStream_t)stream);
   }
   // (a statistics buffer sized for the edge_mfma layout must not reach these kernels)
-  if (!force_generic() && ampconv_block_supported(L, D, H, views, 5) && !(stats && ampconv_mfma_supported(L, D, H)))
-    return ampconv_bwd_edge_dst_block(Q, K, V, dObar, rowptr, col, n_rows, L, D, H, dQ, sa, (hipStream_t)stream);
+  if (!force_generic() && ampconv_block_supported(L, D, H, views, 5) && !(stats && ampconv_mfma_supported(L, D, H))) {
+    hipStream_t st = (hipStream_t)stream;
+    if (hub_plan && hub_chunks > 0 && hub_ws) {
+      if (int rc = ampconv_bwd_edge_dst_block(Q, K, V, dObar, rowptr, col, n_rows, L, D, H, dQ,
+                                              hub_args(hub_plan, 1), sa, st))
+        return rc;
+      ampconv_view_t P = partial_view(hub_ws, 0, hub_chunks, L, D, H);
+      if (int rc = ampconv_bwd_edge_dst_block(Q, K, V, dObar, rowptr, col, hub_chunks, L, D, H, P,
+                                              hub_args(hub_plan, 2), sa, st))
+        return rc;
+      return ampconv_hub_combine(hub_plan, hub_chunks, (const float *)P.ptr, dQ, nullptr, L, D, H,
+                                 1.f / sqrtf((float)(D / H)), 0, st);
+    }
+    return ampconv_bwd_edge_dst_block(Q, K, V, dObar, rowptr, col, n_rows, L, D, H, dQ, HubArgs{nullptr, 0}, sa, st);
+  }
   if (stats) return AMPCONV_E_BADARG;     // this shape's kernels keep no statistics (ampconv_softmax_stats_bytes = 0)
   return ampconv_bwd_edge_dst_generic(Q, K, V, dObar, rowptr, col, n_rows, L, D, H, dQ,
                                       (hipStream_t)stream);
@@ -229,9 +253,25 @@ extern "C" int ampconv_bwd_edge_src(ampconv_view_t Q, ampconv_view_t K, ampconv_
                                      HubArgs{nullptr, 0}, sa, (hipStream_t)stream);
   }
   // the workgroup-per-unit source pass exists only with the statistics; without them: generic kernels
-  if (stats && !force_generic() && ampconv_block_supported(L, D, H, views, 6) && !ampconv_mfma_supported(L, D, H))
-    return ampconv_bwd_edge_src_block(Q, K, V, dObar, cscptr, crow, cinv, n_src, L, D, H, dK, dV, stats,
-                                      (hipStream_t)stream);
+  if (stats && !force_generic() && ampconv_block_supported(L, D, H, views, 6) && !ampconv_mfma_supported(L, D, H)) {
+    hipStream_t st = (hipStream_t)stream;
+    if (hub_plan && hub_chunks > 0 && hub_ws) {
+      if (int rc = ampconv_bwd_edge_src_block(Q, K, V, dObar, cscptr, crow, cinv, n_src, L, D, H, dK, dV,
+                                              hub_args(hub_plan, 1), stats, st))
+        return rc;
+      ampconv_view_t PK = partial_view(hub_ws, 0, hub_chunks, L, D, H);
+      ampconv_view_t PV = partial_view(hub_ws, 1, hub_chunks, L, D, H);
+      if (int rc = ampconv_bwd_edge_src_block(Q, K, V, dObar, cscptr, crow, cinv, hub_chunks, L, D, H, PK, PV,
+                                              hub_args(hub_plan, 2), stats, st))
+        return rc;
+      if (int rc = ampconv_hub_combine(hub_plan, hub_chunks, (const float *)PK.ptr, dK, nullptr, L, D, H,
+                                       0.6931471805599453f, 0, st))
+        return rc;
+      return ampconv_hub_combine(hub_plan, hub_chunks, (const float *)PV.ptr, dV, nullptr, L, D, H, 1.f, 0, st);
+    }
+    return ampconv_bwd_edge_src_block(Q, K, V, dObar, cscptr, crow, cinv, n_src, L, D, H, dK, dV,
+                                      HubArgs{nullptr, 0}, stats, st);
+  }
   if (stats) return AMPCONV_E_BADARG;
   return ampconv_bwd_edge_src_generic(Q, K, V, dObar, cscptr, crow, cinv, n_src, L, D, H, dK,
                                       dV, (hipStream_t)stream);

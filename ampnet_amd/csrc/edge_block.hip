@@ -138,6 +138,7 @@ struct BArgs {
   const float *cinv;
   const int32_t *spos;
   float *stats;
+  HubArgs hub;              // long-segment plan (hub.hip): mode 1 skips long rows, mode 2 = one unit per chunk
   int64_t n_units;
   int L, dh, H, ntok;
   float qscale, oscale;
@@ -185,10 +186,10 @@ __global__ __launch_bounds__(256) void fwd_block(BArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int64_t r = blockIdx.x / a.H;
-  const int h = blockIdx.x % a.H;
+  int64_t r, onode;
+  int h, beg, end, deg;
+  if (!map_unit(a.hub, a.ptr, blockIdx.x, a.H, r, onode, h, beg, end, deg)) return;    // block-uniform
   const int L = a.L, dh = a.dh, ntok = a.ntok, g = lane >> 4;
-  const int beg = a.ptr[r], end = a.ptr[r + 1], deg = end - beg;
   float *Kt = lds, *Vt = lds + 16 * ntok * DHP;
   const int64_t d = a.qidx ? a.qidx[r] : r;
 
@@ -241,7 +242,9 @@ __global__ __launch_bounds__(256) void fwd_block(BArgs a) {
       }
     __syncthreads();
   }
-  store_ct<DHP, VEC>(a.O, r, h, OT, deg > 0 ? 1.f / (float)deg : 0.f, wave, L, dh, lane);
+  // hub pass: unnormalised partial tile, the combine pass applies 1/deg
+  store_ct<DHP, VEC>(a.O, onode, h, OT, a.hub.mode == 2 ? 1.f : (deg > 0 ? 1.f / (float)deg : 0.f), wave, L, dh,
+                     lane);
 }
 
 // ---------------------------------------------------------------- backward, destination pass
@@ -251,10 +254,10 @@ __global__ __launch_bounds__(256) void bwd_dst_block(BArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int64_t r = blockIdx.x / a.H;
-  const int h = blockIdx.x % a.H;
+  int64_t r, onode;
+  int h, beg, end, deg;
+  if (!map_unit(a.hub, a.ptr, blockIdx.x, a.H, r, onode, h, beg, end, deg)) return;
   const int L = a.L, dh = a.dh, ntok = a.ntok, g = lane >> 4;
-  const int beg = a.ptr[r], end = a.ptr[r + 1], deg = end - beg;
   float *Kt = lds, *Vt = lds + 16 * ntok * DHP;
   const float inv = deg > 0 ? 1.f / (float)deg : 0.f;       // dO is the gradient of the MEAN
 
@@ -330,7 +333,7 @@ __global__ __launch_bounds__(256) void bwd_dst_block(BArgs a) {
       }
     __syncthreads();
   }
-  store_ct<DHP, VEC>(a.O, r, h, dQT, a.oscale, wave, L, dh, lane);
+  store_ct<DHP, VEC>(a.O, onode, h, dQT, a.hub.mode == 2 ? 1.f : a.oscale, wave, L, dh, lane);
 }
 
 // ---------------------------------------------------------------- backward, source pass (needs the statistics)
@@ -340,10 +343,10 @@ __global__ __launch_bounds__(256) void bwd_src_block(BArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int64_t s = blockIdx.x / a.H;
-  const int h = blockIdx.x % a.H;
+  int64_t s, onode;
+  int h, beg, end, deg;
+  if (!map_unit(a.hub, a.ptr, blockIdx.x, a.H, s, onode, h, beg, end, deg)) return;
   const int L = a.L, dh = a.dh, ntok = a.ntok, g = lane >> 4, n = lane & 15;
-  const int beg = a.ptr[s], end = a.ptr[s + 1];
   float *Qt = lds, *Gt = lds + 16 * ntok * DHP;
 
   float kB[KK], vB[KK];
@@ -405,8 +408,8 @@ __global__ __launch_bounds__(256) void bwd_src_block(BArgs a) {
       }
     __syncthreads();
   }
-  store_ct<DHP, VEC>(a.dK, s, h, dKT, a.oscale, wave, L, dh, lane);
-  store_ct<DHP, VEC>(a.dV, s, h, dVT, 1.f, wave, L, dh, lane);
+  store_ct<DHP, VEC>(a.dK, onode, h, dKT, a.hub.mode == 2 ? 1.f : a.oscale, wave, L, dh, lane);
+  store_ct<DHP, VEC>(a.dV, onode, h, dVT, 1.f, wave, L, dh, lane);
 }
 
 inline int vec_of(const ampconv_view_t *views, int n, int dh) {
@@ -453,8 +456,9 @@ int ampconv_block_stats_floats(int L) { return 2 * 16 * ((L + 15) / 16); }
 
 int ampconv_fwd_edge_block(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V, const int32_t *rowptr,
                            const int32_t *col, const int32_t *qidx, int64_t n_rows, int L, int D, int H,
-                           ampconv_view_t O, hipStream_t stream) {
+                           ampconv_view_t O, HubArgs hub, hipStream_t stream) {
   BArgs a = base_args(n_rows, L, D, H);
+  a.hub = hub;
   a.Q = Q; a.K = K; a.V = V; a.O = O;
   a.ptr = rowptr; a.idx = col; a.qidx = qidx;
   const ampconv_view_t views[] = {Q, K, V, O};
@@ -464,8 +468,9 @@ int ampconv_fwd_edge_block(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
 
 int ampconv_bwd_edge_dst_block(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V, ampconv_view_t dO,
                                const int32_t *rowptr, const int32_t *col, int64_t n_rows, int L, int D, int H,
-                               ampconv_view_t dQ, StatsArgs sa, hipStream_t stream) {
+                               ampconv_view_t dQ, HubArgs hub, StatsArgs sa, hipStream_t stream) {
   BArgs a = base_args(n_rows, L, D, H);
+  a.hub = hub;
   a.Q = Q; a.K = K; a.V = V; a.dO = dO; a.O = dQ;
   a.ptr = rowptr; a.idx = col; a.spos = sa.spos; a.stats = sa.stats;
   a.oscale = 1.f / sqrtf((float)a.dh);
@@ -480,10 +485,11 @@ int ampconv_bwd_edge_dst_block(ampconv_view_t Q, ampconv_view_t K, ampconv_view_
 
 int ampconv_bwd_edge_src_block(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V, ampconv_view_t dO,
                                const int32_t *cscptr, const int32_t *crow, const float *cinv, int64_t n_src,
-                               int L, int D, int H, ampconv_view_t dK, ampconv_view_t dV, const float *stats,
-                               hipStream_t stream) {
+                               int L, int D, int H, ampconv_view_t dK, ampconv_view_t dV, HubArgs hub,
+                               const float *stats, hipStream_t stream) {
   if (!stats) return AMPCONV_E_BADARG;
   BArgs a = base_args(n_src, L, D, H);
+  a.hub = hub;
   a.Q = Q; a.K = K; a.V = V; a.dO = dO; a.dK = dK; a.dV = dV;
   a.ptr = cscptr; a.idx = crow; a.cinv = cinv; a.stats = const_cast<float *>(stats);
   a.oscale = 0.6931471805599453f;       // dK = ln2 * sum dS^T (Q * log2e / sqrt(dh))

@@ -658,3 +658,38 @@ def test_batched_tail_kernels_large_scores(dev, monkeypatch):
     slow = run()
     for name, a, b in zip(['y', 'dx', 'gWin', 'gWo'], fast, slow):
         assert_close_scaled(a, b, name, atol=3e-5, rtol=3e-4)      # saturated softmaxes amplify rounding
+
+
+@pytest.mark.parametrize('shape', [(300, 3000, 40, 100, 2), (300, 3000, 24, 128, 2)], ids=['L40_dh50', 'L24_dh64'])
+def test_block_kernels_long_segments(shape, dev, monkeypatch):
+    """Workgroup-per-unit kernels (edge_block.hip) on a graph with a hub destination and a hub source
+    (segments of ~600 edges, cut into 64-edge chunks -> partial tiles -> ordered combine) against the
+    shape-generic kernels, which walk every segment in one piece."""
+    from ampnet_amd import AMPConv, graph_cache
+    N, E, L, D, H = shape
+    g = torch.Generator().manual_seed(L + D)
+    ei = torch.randint(0, N, (2, E), generator=g)
+    ei[1, :600] = 3
+    ei[0, 600:1200] = 5
+    ei[1, ei[1] == 7] = 8
+    ei = ei.to(dev)
+    torch.manual_seed(2)
+    layer = AMPConv(D, H).to(dev)
+    x = torch.randn(N, L * D, generator=g).to(dev)
+    dy = torch.randn(N, L * D, generator=g).to(dev)
+
+    def run():
+        graph_cache.clear()
+        layer.zero_grad(set_to_none=True)
+        xg = x.clone().requires_grad_(True)
+        y = layer(xg, ei)
+        y.backward(dy)
+        m = layer.multi_head_attention
+        return [t.detach().cpu().numpy() for t in (y, xg.grad, m.in_proj_weight.grad, m.out_proj.weight.grad)]
+
+    fast = run()
+    assert graph_cache.get(ei, N).hub_dst_chunks > 0 and graph_cache.get(ei, N).hub_src_chunks > 0
+    monkeypatch.setenv('AMPCONV_FORCE_GENERIC', '1')
+    slow = run()
+    for name, a, b in zip(['y', 'dx', 'gWin', 'gWo'], fast, slow):
+        assert_close_scaled(a, b, name)
