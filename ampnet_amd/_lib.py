@@ -9,6 +9,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('AMPCONV_LIB_PATH', os.path.join(_HERE, 'libampconv.so'))   # override: dev A/B builds
 
+EXPECTED_ABI = 101          # AMPCONV_VERSION of include/ampconv.h this binding was written against
+
 AMPCONV_F32 = 0
 AMPCONV_BF16 = 1
 AMPCONV_F32_EXACT = 2      # native fp32 MFMA
@@ -86,6 +88,12 @@ def load():
         fn = getattr(lib, name)           # AttributeError if the export is missing
         fn.restype = res
         fn.argtypes = args
+    got = lib.ampconv_version()
+    if got != EXPECTED_ABI:
+        # argument lists differ between ABI versions (101 inserted the statistics pointers): a stale
+        # or foreign build would reinterpret pointers as dtype / stream arguments
+        raise AmpconvError(f'{LIB_PATH} has ABI version {got}, this binding needs {EXPECTED_ABI}: rebuild it '
+                           '(python -c "import __graft_entry__ as g; g.build(force=True)")')
     _lib = lib
     return lib
 

@@ -15,6 +15,9 @@ All arithmetic runs in libampconv.so (hand-written HIP for gfx950) plus dense
 GEMMs on the per-node rows; there is no CPU or eager fallback -- inputs that are
 not on the GPU, or a missing shared library, raise.
 """
+import os
+import warnings
+
 import torch
 import torch.nn as nn
 
@@ -58,7 +61,14 @@ class AMPConv(MessagePassing):
         self._attn_ctx = None
         self._attn_output = None
         self._attn_output_weights = None
-        self.retain_attention = True            # keep what the lazy per-edge outputs need
+        # what the lazy per-edge outputs (attn_output, attn_output_weights) need is the projection
+        # buffer [N*L, 3D] -- 61 GB at BASELINE config 4.  True: always keep it until the next forward;
+        # False: never; 'auto' (default): keep it while it is at most AMPCONV_RETAIN_LIMIT_MB (512 MiB:
+        # every graph the reference's scripts visualise), drop it above -- reading the attributes then
+        # raises instead of pinning tens of GB after backward.
+        self.retain_attention = 'auto'
+        self._attn_dropped_bytes = 0
+        self._attn_param_versions = None
         # how fp32 products run on the matrix cores: 'default' | 'exact' | 'bf16x9' | 'bf16x6'
         # (include/ampconv.h, dtype codes); inputs, outputs and accumulation are fp32 in every mode
         self.precision = 'default'
@@ -108,6 +118,8 @@ class AMPConv(MessagePassing):
         if edge_index.device != x.device:
             raise ValueError(f'edge_index is on {edge_index.device} but x is on {x.device}')
         csr = graph_cache.get(edge_index, x.size(0))
+        # the previous call's projection buffer goes before this call allocates its own (peak memory)
+        self._attn_ctx = self._attn_output = self._attn_output_weights = None
         if self.softmax:
             y, qkv, _ = F_.AMPConvFunction.apply(x, x, *self._params(), csr, self.num_heads, True,
                                                  _lib.PRECISIONS[self.precision], self.gemm_precision)
@@ -128,6 +140,7 @@ class AMPConv(MessagePassing):
             raise ValueError(f'x_i {tuple(x_i.shape)} and x_j {tuple(x_j.shape)} differ')
         E = x_i.size(0)
         csr = EdgeCSR.identity(E, x_i.device)
+        self._attn_ctx = self._attn_output = self._attn_output_weights = None
         if self.softmax:
             y, q, kv = F_.AMPConvFunction.apply(x_i, x_j, *self._params(), csr, self.num_heads, False,
                                                 _lib.PRECISIONS[self.precision], self.gemm_precision)
@@ -149,17 +162,35 @@ class AMPConv(MessagePassing):
         n = int(dim_size) if dim_size is not None else int(index.max().item()) + 1
         ar = torch.arange(index.numel(), dtype=torch.int64, device=index.device)
         csr = EdgeCSR(torch.stack([ar % n, index.to(torch.int64)]), n)
-        return F_.segment_mean(inputs.to(torch.float32), csr)
+        return F_.segment_mean(inputs.to(torch.float32), csr, index.to(torch.int64))
 
     # ------------------------------------------------------------------ lazy per-edge outputs
     def _set_attn_ctx(self, q_buf, kv_buf, edge_index, L, shared):
         self._attn_output = None
         self._attn_output_weights = None
-        if not self.retain_attention:
-            self._attn_ctx = None
+        self._attn_ctx = None
+        self._attn_dropped_bytes = 0
+        nbytes = q_buf.numel() * q_buf.element_size() + (0 if kv_buf is None else kv_buf.numel() * kv_buf.element_size())
+        keep = self.retain_attention
+        if keep == 'auto':
+            keep = nbytes <= (int(os.environ.get('AMPCONV_RETAIN_LIMIT_MB', 512)) << 20)
+        if not keep:
+            self._attn_dropped_bytes = nbytes
             return
         self._attn_ctx = (q_buf.detach(), None if kv_buf is None else kv_buf.detach(),
                           edge_index, L, shared)
+        # attn_output is produced lazily with the out-projection parameters: remember which version
+        # of them the forward pass saw (an optimizer step in between changes the result)
+        m = self.multi_head_attention
+        self._attn_param_versions = (m.out_proj.weight._version, m.out_proj.bias._version)
+
+    def _attn_missing(self, name):
+        if self._attn_dropped_bytes:
+            raise RuntimeError(
+                f'{name} was not retained: the projection buffer of the last forward is '
+                f'{self._attn_dropped_bytes / 2**30:.1f} GiB (retain_attention={self.retain_attention!r}); set '
+                f'layer.retain_attention = True before the forward pass to keep it')
+        return None
 
     def _attn_views(self):
         q_buf, kv_buf, edge_index, L, shared = self._attn_ctx
@@ -178,7 +209,9 @@ class AMPConv(MessagePassing):
     def attn_output_weights(self):
         """[E, L, L]: w[e, row, col] = how much destination token `row` attends to source
         token `col`, mean over heads, original edge order (amp_conv.py:43-47)."""
-        if self._attn_output_weights is None and self._attn_ctx is not None:
+        if self._attn_output_weights is None and self._attn_ctx is None:
+            return self._attn_missing('attn_output_weights')
+        if self._attn_output_weights is None:
             Qv, Kv, _, edge_index, L = self._attn_views()
             weights = F_.attention_weights if self.softmax else FL_.attention_scores
             self._attn_output_weights = weights(Qv, Kv, edge_index.contiguous(), L, self.embed_dim,
@@ -192,7 +225,14 @@ class AMPConv(MessagePassing):
     @property
     def attn_output(self):
         """[E, L, D] per-edge attention output after the out-projection (amp_conv.py:39)."""
-        if self._attn_output is None and self._attn_ctx is not None:
+        if self._attn_output is None and self._attn_ctx is None:
+            return self._attn_missing('attn_output')
+        if self._attn_output is None:
+            m = self.multi_head_attention
+            if self._attn_param_versions != (m.out_proj.weight._version, m.out_proj.bias._version):
+                warnings.warn('attn_output is computed lazily with the CURRENT out_proj parameters, which changed '
+                              'since the forward pass (the reference stores the forward-time value): read it '
+                              'before optimizer.step()', RuntimeWarning, stacklevel=2)
             Qv, Kv, Vv, edge_index, L = self._attn_views()
             D, H = self.embed_dim, self.num_heads
             E = edge_index.size(1)

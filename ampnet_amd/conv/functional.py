@@ -16,6 +16,7 @@ Data layout in HBM (fp32):
 import contextlib
 import ctypes
 import os
+import threading
 
 import torch
 
@@ -40,6 +41,9 @@ GEMM_PRECISIONS = ('fp32', 'bf16x3')
 SOFTMAX_STATS = os.environ.get('AMPCONV_SOFTMAX_STATS', '1') != '0'
 
 
+_GEMM_SWITCH_LOCK = threading.RLock()
+
+
 @contextlib.contextmanager
 def gemm_precision(mode):
     """How the dense fp32 projections run.  'fp32': plain fp32 MFMA GEMMs (rocBLAS, ~135-150
@@ -47,28 +51,34 @@ def gemm_precision(mode):
     planes and sums three bf16 MFMA products in fp32 (what ROCm serves as "TF32" on gfx950, which
     has no xf32 matrix instruction): ~2x the rate, element error ~5e-6 of the largest output
     instead of ~6e-7 (tools/bench_gemm.py).  Inputs, outputs and accumulation stay fp32; the
-    edge kernels are not affected.  torch's switches are process-global, so they are set for the
-    duration of the block and restored."""
+    edge kernels are not affected.
+
+    torch's switches (allow_tf32, preferred BLAS library, HIPBLASLT_ALLOW_TF32) are PROCESS-GLOBAL:
+    they are set for the duration of the block and restored, under a lock so that two layers (the
+    autograd thread runs backward) never interleave their set/restore.  fp32 GEMMs issued by OTHER
+    threads while a 'bf16x3' block is open run in that mode too -- keep the default 'fp32' if that
+    matters (tests/test_gpu_parity.py::test_gemm_precision_is_restored pins the restore)."""
     if mode not in GEMM_PRECISIONS:
         raise ValueError(f'gemm precision must be one of {GEMM_PRECISIONS}, got {mode!r}')
     if mode == 'fp32':
         yield
         return
-    prev_env = os.environ.get('HIPBLASLT_ALLOW_TF32')
-    prev_tf32 = torch.backends.cuda.matmul.allow_tf32
-    prev_lib = torch.backends.cuda.preferred_blas_library()
-    os.environ['HIPBLASLT_ALLOW_TF32'] = '1'
-    torch.backends.cuda.matmul.allow_tf32 = True
-    torch.backends.cuda.preferred_blas_library('hipblaslt')
-    try:
-        yield
-    finally:
-        torch.backends.cuda.preferred_blas_library(prev_lib)
-        torch.backends.cuda.matmul.allow_tf32 = prev_tf32
-        if prev_env is None:
-            os.environ.pop('HIPBLASLT_ALLOW_TF32', None)
-        else:
-            os.environ['HIPBLASLT_ALLOW_TF32'] = prev_env
+    with _GEMM_SWITCH_LOCK:
+        prev_env = os.environ.get('HIPBLASLT_ALLOW_TF32')
+        prev_tf32 = torch.backends.cuda.matmul.allow_tf32
+        prev_lib = torch.backends.cuda.preferred_blas_library()
+        os.environ['HIPBLASLT_ALLOW_TF32'] = '1'
+        torch.backends.cuda.matmul.allow_tf32 = True
+        torch.backends.cuda.preferred_blas_library('hipblaslt')
+        try:
+            yield
+        finally:
+            torch.backends.cuda.preferred_blas_library(prev_lib)
+            torch.backends.cuda.matmul.allow_tf32 = prev_tf32
+            if prev_env is None:
+                os.environ.pop('HIPBLASLT_ALLOW_TF32', None)
+            else:
+                os.environ['HIPBLASLT_ALLOW_TF32'] = prev_env
 
 
 def _tn_matmul(a, b, chunks=128):
@@ -236,14 +246,36 @@ def attention_weights(Qv, Kv, edge_index, L, D, H):
     return W
 
 
-def segment_mean(msg, csr):
-    """PyG aggr='mean' of an [E, F] message matrix over the dst-sorted CSR."""
-    lib = _lib.load()
-    msg = msg.contiguous()
-    N, F = csr.num_nodes, msg.size(1)
-    out = torch.empty(N, F, dtype=torch.float32, device=msg.device)
-    with torch.cuda.device(msg.device):
-        rc = lib.ampconv_segment_mean(msg.data_ptr(), csr.rowptr.data_ptr(), csr.eperm.data_ptr(),
-                                      N, F, out.data_ptr(), _stream())
-    _lib.check(rc, 'ampconv_segment_mean')
-    return out
+class SegmentMeanFunction(torch.autograd.Function):
+    """PyG aggr='mean' of an [E, F] message matrix over the dst-sorted CSR; differentiable in the
+    messages (d msg[e] = d out[dst(e)] / in-degree(dst(e))), so the decomposed public path
+    message() -> aggregate() trains like the fused propagate()."""
+
+    @staticmethod
+    def forward(ctx, msg, csr, index):
+        lib = _lib.load()
+        msg = msg.contiguous()
+        N, F = csr.num_nodes, msg.size(1)
+        out = torch.empty(N, F, dtype=torch.float32, device=msg.device)
+        with torch.cuda.device(msg.device):
+            rc = lib.ampconv_segment_mean(msg.data_ptr(), csr.rowptr.data_ptr(), csr.eperm.data_ptr(),
+                                          N, F, out.data_ptr(), _stream())
+        _lib.check(rc, 'ampconv_segment_mean')
+        ctx.csr, ctx.index = csr, index
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        csr = ctx.csr
+        deg = (csr.rowptr[1:] - csr.rowptr[:-1]).clamp(min=1).to(dout.dtype)
+        return (dout / deg[:, None]).index_select(0, ctx.index), None, None
+
+
+def segment_mean(msg, csr, index=None):
+    """PyG aggr='mean' of an [E, F] message matrix over the dst-sorted CSR.  `index` (the int64
+    destination of every message, original order) is needed only for the gradient."""
+    if index is None:
+        if msg.requires_grad and torch.is_grad_enabled():
+            raise ValueError('segment_mean of messages that require grad needs `index`')
+        index = torch.empty(0, dtype=torch.int64, device=msg.device)
+    return SegmentMeanFunction.apply(msg, csr, index)

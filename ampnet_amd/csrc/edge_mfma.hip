@@ -33,6 +33,14 @@ constexpr int kWavesPerBlock = AMPCONV_WPB;
 #ifndef AMPCONV_PF_SRC
 #define AMPCONV_PF_SRC 1
 #endif
+#ifndef AMPCONV_SRC_WAVES
+#define AMPCONV_SRC_WAVES 3      // waves per SIMD the source pass is compiled for (register budget 168 / 256)
+#endif
+#ifdef AMPCONV_NO_SCHED_FENCE
+#define SCHED_FENCE()
+#else
+#define SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
 #ifdef AMPCONV_SETPRIO
 #define PRIO(x) __builtin_amdgcn_s_setprio(x)
 #else
@@ -565,10 +573,17 @@ __device__ __forceinline__ void pair_to_lds_tail(float *ldsA, float *stash, int 
   }
 }
 
-template <int DH, bool FULL>
-__global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? 3 : 4) void bwd_src_mfma_t4(BwdArgs a) {
+// NT4: the source's own tail tokens 16..19 (the padded second COLUMN tile of S / dP and of the dK^T /
+// dV^T accumulators, 25 % useful on 16x16x4) run on v_mfma_f32_4x4x1_16b_f32 instead (mfma_tile.h,
+// "4-granular products"): per edge and head 40 16x16x4 + 40 4x4x1 instead of 80 16x16x4, i.e.
+// ~1650 instead of 2560 matrix-pipe cycles.  The softmax is element-wise with the statistics, so the
+// phase-1 result (one register: lane (g, sg, j) = destination token 4 sg + g, source token 16 + j)
+// goes straight back in as the B operand of phase 2.
+template <int DH, bool FULL, bool NT4>
+__global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? AMPCONV_SRC_WAVES : 4) void bwd_src_mfma_t4(BwdArgs a) {
   using C = TileCfg<DH>;
   constexpr int kStash = 4 * 2 * 4 * DH;
+  constexpr int NTM = NT4 ? 1 : 2;           // 16-wide column tiles on the 16x16x4 path
   __shared__ __attribute__((aligned(16))) float lds_all[kWavesPerBlock][2 * C::TILE_FLOATS + kStash];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -577,18 +592,23 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? 3 : 4) void bwd_src
   int64_t s, onode;
   int h, beg, end, deg;
   if (!map_unit(a.hub, a.ptr, unit, a.H, s, onode, h, beg, end, deg)) return;
-  const int L = a.L, n = lane & 15, g = lane >> 4;
+  const int L = a.L, n = lane & 15, g = lane >> 4, sg = (lane >> 2) & 3, jt = lane & 3;
   float *Qt = lds_all[wave], *Gt = Qt + C::TILE_FLOATS, *stash = Qt + 2 * C::TILE_FLOATS;
   const float oscale = a.hub.mode == 2 ? 1.f : a.oscale;
 
-  float kB[2][C::KK], vB[2][C::KK];
+  float kB[NTM][C::KK], vB[NTM][C::KK];
+  float kT[NT4 ? C::KK : 1], vT[NT4 ? C::KK : 1];
   {
     const float *kb = tile_ptr<const float>(a.K, s, h);
     const float *vb = tile_ptr<const float>(a.V, s, h);
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
+    for (int nt = 0; nt < NTM; ++nt) {
       rowop_from_global<DH>(kB[nt], kb, a.K.row_stride, nt, true, 1.f, L, lane);
       rowop_from_global<DH>(vB[nt], vb, a.V.row_stride, nt, true, 1.f, L, lane);
+    }
+    if constexpr (NT4) {
+      tailop_from_global<DH>(kT, kb, a.K.row_stride, 1.f, L, lane);
+      tailop_from_global<DH>(vT, vb, a.V.row_stride, 1.f, L, lane);
     }
   }
   if (!FULL) {
@@ -597,10 +617,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? 3 : 4) void bwd_src
   }
   // slots of a last, partial batch and token rows >= L are read by the MFMAs: keep them finite
   for (int i = lane; i < kStash; i += AMPCONV_WAVE) stash[i] = 0.f;
-  f32x4 dKT[C::MC][2], dVT[C::MC][2];
+  f32x4 dKT[C::MC][NTM], dVT[C::MC][NTM];
+  f32x4 dK4[C::MC], dV4[C::MC];              // NT4: block (g, sg), reg rr, lane jt: channel 16 hf + 4 g + rr, token 16 + jt
 #pragma unroll
-  for (int mc = 0; mc < C::MC; ++mc)
-    dKT[mc][0] = dKT[mc][1] = dVT[mc][0] = dVT[mc][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int mc = 0; mc < C::MC; ++mc) {
+#pragma unroll
+    for (int nt = 0; nt < NTM; ++nt) dKT[mc][nt] = dVT[mc][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    dK4[mc] = dV4[mc] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 
   PairRegs<DH> qg;
   float inv_next = 0.f;
@@ -615,6 +639,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? 3 : 4) void bwd_src
     fetch(beg);
   }
   const bool v0 = n < L, v1 = 16 + n < L;
+  const bool vt = FULL || 16 + jt < L;       // NT4: this lane's source tail token exists
+  // NT4 phase 2: this lane's index of row 4 sg, channel 4 g + (lane & 3) in the main images / in the
+  // stash (Q rows; the dO rows lie 4 rows further); the other rows and the second channel half
+  // are XOR constants away (nt_accumulate)
+  const int nt_main = lds_idx<DH>(4 * sg, 4 * g + jt), nt_stash = tail_idx<DH>(8 * sg, 4 * g + jt);
 
   for (int p0 = beg; p0 < end; p0 += 4) {
 #pragma unroll 1
@@ -627,31 +656,66 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? 3 : 4) void bwd_src
       const float *sbm = a.stats + ((int64_t)p * a.H + h) * kStatsPerUnit;
       const f32x4 l4 = *reinterpret_cast<const f32x4 *>(sbm + 4 * g);
       const f32x4 d4 = *reinterpret_cast<const f32x4 *>(sbm + kLmax + 4 * g);
+      float lT = 0.f, dT = 0.f;              // NT4: statistics of destination token 4 sg + g
+      if constexpr (NT4) {
+        lT = sbm[4 * sg + g];
+        dT = sbm[kLmax + 4 * sg + g];
+      }
       if (p + 1 < end) fetch(p + 1);
       __builtin_amdgcn_wave_barrier();
 
-      // main tile: destination tokens 0..15 of this edge
+      // main tile: destination tokens 0..15 of this edge.  S first, then dP (NT4: one after the other
+      // keeps only one row operand and one pair of result tiles live at a time)
       f32x4 S0, S1, dP0, dP1;
       S0 = S1 = dP0 = dP1 = f32x4{0.f, 0.f, 0.f, 0.f};
-      {
-        float qA[C::KK], gA[C::KK];
-        rowop_from_lds<DH>(qA, Qt, 0, lane);
-        rowop_from_lds<DH>(gA, Gt, 0, lane);
+      float pT = 0.f, dsT = 0.f;
+      if constexpr (NT4) {
+        {
+          float qA[C::KK];
+          rowop_from_lds<DH>(qA, Qt, 0, lane);
 #pragma unroll
-        for (int kk = 0; kk < C::KK; ++kk) {
-          S0 = MFMA16(qA[kk], kB[0][kk], S0);
-          S1 = MFMA16(qA[kk], kB[1][kk], S1);
-          dP0 = MFMA16(gA[kk], vB[0][kk], dP0);
-          dP1 = MFMA16(gA[kk], vB[1][kk], dP1);
+          for (int kk = 0; kk < C::KK; ++kk) {
+            S0 = MFMA16(qA[kk], kB[0][kk], S0);
+            S1 = MFMA4(qA[kk], kT[kk], S1, 0);          // 4x4x1 partials of the columns 16..19
+          }
         }
-      }
+        pT = (vt && (FULL || 4 * sg + g < L)) ? fast_exp2(reduce_transpose(S1) - lT) : 0.f;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float pa = v0 ? fast_exp2(S0[q] - l4[q]) : 0.f, pb = v1 ? fast_exp2(S1[q] - l4[q]) : 0.f;
-        S0[q] = pa;
-        S1[q] = pb;
-        dP0[q] = pa * (dP0[q] - d4[q]);          // dP now holds dS
-        dP1[q] = pb * (dP1[q] - d4[q]);
+        for (int q = 0; q < 4; ++q) S0[q] = v0 ? fast_exp2(S0[q] - l4[q]) : 0.f;
+        SCHED_FENCE();
+        {
+          float gA[C::KK];
+          rowop_from_lds<DH>(gA, Gt, 0, lane);
+#pragma unroll
+          for (int kk = 0; kk < C::KK; ++kk) {
+            dP0 = MFMA16(gA[kk], vB[0][kk], dP0);
+            dP1 = MFMA4(gA[kk], vT[kk], dP1, 0);
+          }
+        }
+        dsT = pT * (reduce_transpose(dP1) - dT);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dP0[q] = S0[q] * (dP0[q] - d4[q]);      // dP now holds dS
+      } else {
+        {
+          float qA[C::KK], gA[C::KK];
+          rowop_from_lds<DH>(qA, Qt, 0, lane);
+          rowop_from_lds<DH>(gA, Gt, 0, lane);
+#pragma unroll
+          for (int kk = 0; kk < C::KK; ++kk) {
+            S0 = MFMA16(qA[kk], kB[0][kk], S0);
+            S1 = MFMA16(qA[kk], kB[NTM - 1][kk], S1);
+            dP0 = MFMA16(gA[kk], vB[0][kk], dP0);
+            dP1 = MFMA16(gA[kk], vB[NTM - 1][kk], dP1);
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float pa = v0 ? fast_exp2(S0[q] - l4[q]) : 0.f, pb = v1 ? fast_exp2(S1[q] - l4[q]) : 0.f;
+          S0[q] = pa;
+          S1[q] = pb;
+          dP0[q] = pa * (dP0[q] - d4[q]);          // dP now holds dS
+          dP1[q] = pb * (dP1[q] - d4[q]);
+        }
       }
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
@@ -660,10 +724,16 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? 3 : 4) void bwd_src
           const int idx = lds_idx<DH>(col_token(t, g), n + 16 * mc);
           const float gC = Gt[idx], qC = Qt[idx];
           dVT[mc][0] = MFMA16(gC, S0[t], dVT[mc][0]);
-          dVT[mc][1] = MFMA16(gC, S1[t], dVT[mc][1]);
           dKT[mc][0] = MFMA16(qC, dP0[t], dKT[mc][0]);
-          dKT[mc][1] = MFMA16(qC, dP1[t], dKT[mc][1]);
+          if constexpr (!NT4) {
+            dVT[mc][NTM - 1] = MFMA16(gC, S1[t], dVT[mc][NTM - 1]);
+            dKT[mc][NTM - 1] = MFMA16(qC, dP1[t], dKT[mc][NTM - 1]);
+          }
         }
+      }
+      if constexpr (NT4) {
+        nt_accumulate<DH, false>(dV4, Gt, nt_main, pT);
+        nt_accumulate<DH, false>(dK4, Qt, nt_main, dsT);
       }
       __builtin_amdgcn_wave_barrier();
     }
@@ -675,6 +745,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? 3 : 4) void bwd_src
       const float *sb = a.stats + ((int64_t)pe * a.H + h) * kStatsPerUnit;
       const f32x4 l4 = *reinterpret_cast<const f32x4 *>(sb + 16);
       const f32x4 d4 = *reinterpret_cast<const f32x4 *>(sb + kLmax + 16);
+      // NT4: lane (g, sg, jt) <-> row 4 sg + g of the tail tile = (edge p0 + sg, destination token 16 + g)
+      const bool liveT = p0 + sg < end;
+      float lT = 0.f, dT = 0.f;
+      if constexpr (NT4) {
+        const float *sbT = a.stats + ((int64_t)(liveT ? p0 + sg : end - 1) * a.H + h) * kStatsPerUnit;
+        lT = sbT[16 + g];
+        dT = sbT[kLmax + 16 + g];
+      }
       f32x4 S0, S1, dP0, dP1;
       S0 = S1 = dP0 = dP1 = f32x4{0.f, 0.f, 0.f, 0.f};
       {
@@ -692,19 +770,32 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? 3 : 4) void bwd_src
 #pragma unroll
         for (int kk = 0; kk < C::KK; ++kk) {
           S0 = MFMA16(qA[kk], kB[0][kk], S0);
-          S1 = MFMA16(qA[kk], kB[1][kk], S1);
           dP0 = MFMA16(gA[kk], vB[0][kk], dP0);
-          dP1 = MFMA16(gA[kk], vB[1][kk], dP1);
+          if constexpr (NT4) {
+            S1 = MFMA4(qA[kk], kT[kk], S1, 0);
+            dP1 = MFMA4(gA[kk], vT[kk], dP1, 0);
+          } else {
+            S1 = MFMA16(qA[kk], kB[NTM - 1][kk], S1);
+            dP1 = MFMA16(gA[kk], vB[NTM - 1][kk], dP1);
+          }
         }
+      }
+      float pT = 0.f, dsT = 0.f;
+      if constexpr (NT4) {
+        const float zs = reduce_transpose(S1), zd = reduce_transpose(dP1);
+        pT = (vt && liveT && (FULL || 16 + g < L)) ? fast_exp2(zs - lT) : 0.f;
+        dsT = pT * (zd - dT);
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {       // C/D reg q of lane group g = token 16 + q of edge p0 + g
         const float pa = (v0 && live) ? fast_exp2(S0[q] - l4[q]) : 0.f;
-        const float pb = (v1 && live) ? fast_exp2(S1[q] - l4[q]) : 0.f;
         S0[q] = pa;
-        S1[q] = pb;
         dP0[q] = pa * (dP0[q] - d4[q]);
-        dP1[q] = pb * (dP1[q] - d4[q]);
+        if constexpr (!NT4) {
+          const float pb = (v1 && live) ? fast_exp2(S1[q] - l4[q]) : 0.f;
+          S1[q] = pb;
+          dP1[q] = pb * (dP1[q] - d4[q]);
+        }
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q) {       // k-slot g of step q: row 16 + q of edge g's tiles
@@ -713,10 +804,16 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? 3 : 4) void bwd_src
           const float qC = stash[tail_idx<DH>(8 * g + q, n + 16 * mc)];
           const float gC = stash[tail_idx<DH>(8 * g + 4 + q, n + 16 * mc)];
           dVT[mc][0] = MFMA16(gC, S0[q], dVT[mc][0]);
-          dVT[mc][1] = MFMA16(gC, S1[q], dVT[mc][1]);
           dKT[mc][0] = MFMA16(qC, dP0[q], dKT[mc][0]);
-          dKT[mc][1] = MFMA16(qC, dP1[q], dKT[mc][1]);
+          if constexpr (!NT4) {
+            dVT[mc][NTM - 1] = MFMA16(gC, S1[q], dVT[mc][NTM - 1]);
+            dKT[mc][NTM - 1] = MFMA16(qC, dP1[q], dKT[mc][NTM - 1]);
+          }
         }
+      }
+      if constexpr (NT4) {      // tail-tile row 4 sg + x = (edge sg, token 16 + x): stash row 8 sg + 4 isG + x
+        nt_accumulate<DH, true>(dV4, stash + 4 * DH, nt_stash, pT);
+        nt_accumulate<DH, true>(dK4, stash, nt_stash, dsT);
       }
       __builtin_amdgcn_wave_barrier();
     }
@@ -724,7 +821,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? 3 : 4) void bwd_src
 
   float *kb = tile_ptr<float>(a.dK, onode, h), *vb = tile_ptr<float>(a.dV, onode, h);
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
+  for (int nt = 0; nt < NTM; ++nt) {
     const int j = n + 16 * nt;
     if (j < L) {
 #pragma unroll
@@ -734,6 +831,20 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? 3 : 4) void bwd_src
         float4 v4 = make_float4(dVT[mc][nt][0], dVT[mc][nt][1], dVT[mc][nt][2], dVT[mc][nt][3]);
         *reinterpret_cast<float4 *>(kb + (int64_t)j * a.dK.row_stride + 4 * g + 16 * mc) = k4;
         *reinterpret_cast<float4 *>(vb + (int64_t)j * a.dV.row_stride + 4 * g + 16 * mc) = v4;
+      }
+    }
+  }
+  if constexpr (NT4) {          // the four sg partial sums of every block column, then one quad stores
+#pragma unroll
+    for (int hf = 0; hf < C::MC; ++hf) {
+      float4 k4, v4;
+      k4.x = quads_sum(dK4[hf][0]) * oscale; k4.y = quads_sum(dK4[hf][1]) * oscale;
+      k4.z = quads_sum(dK4[hf][2]) * oscale; k4.w = quads_sum(dK4[hf][3]) * oscale;
+      v4.x = quads_sum(dV4[hf][0]); v4.y = quads_sum(dV4[hf][1]);
+      v4.z = quads_sum(dV4[hf][2]); v4.w = quads_sum(dV4[hf][3]);
+      if (sg == 0 && 16 + jt < L) {
+        *reinterpret_cast<float4 *>(kb + (int64_t)(16 + jt) * a.dK.row_stride + 16 * hf + 4 * g) = k4;
+        *reinterpret_cast<float4 *>(vb + (int64_t)(16 + jt) * a.dV.row_stride + 16 * hf + 4 * g) = v4;
       }
     }
   }
@@ -1360,11 +1471,17 @@ int ampconv_bwd_edge_src_mfma(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t
   if (blocks > INT32_MAX) return AMPCONV_E_BADARG;
   const dim3 grid((unsigned)blocks), block(64 * kWavesPerBlock);
   static const bool t4 = !(std::getenv("AMPCONV_SRC_T4") && std::getenv("AMPCONV_SRC_T4")[0] == '0');
-  if (st.stats && t4) {
-    if (dh == 32 && L == kLmax) bwd_src_mfma_t4<32, true><<<grid, block, 0, stream>>>(a);
-    else if (dh == 32) bwd_src_mfma_t4<32, false><<<grid, block, 0, stream>>>(a);
-    else if (L == kLmax) bwd_src_mfma_t4<16, true><<<grid, block, 0, stream>>>(a);
-    else bwd_src_mfma_t4<16, false><<<grid, block, 0, stream>>>(a);
+  static const bool nt4 = !(std::getenv("AMPCONV_SRC_NT4") && std::getenv("AMPCONV_SRC_NT4")[0] == '0');
+  if (st.stats && t4 && nt4 && L > 16) {       // tail columns on 4x4x1 (only if there are tail tokens)
+    if (dh == 32 && L == kLmax) bwd_src_mfma_t4<32, true, true><<<grid, block, 0, stream>>>(a);
+    else if (dh == 32) bwd_src_mfma_t4<32, false, true><<<grid, block, 0, stream>>>(a);
+    else if (L == kLmax) bwd_src_mfma_t4<16, true, true><<<grid, block, 0, stream>>>(a);
+    else bwd_src_mfma_t4<16, false, true><<<grid, block, 0, stream>>>(a);
+  } else if (st.stats && t4) {
+    if (dh == 32 && L == kLmax) bwd_src_mfma_t4<32, true, false><<<grid, block, 0, stream>>>(a);
+    else if (dh == 32) bwd_src_mfma_t4<32, false, false><<<grid, block, 0, stream>>>(a);
+    else if (L == kLmax) bwd_src_mfma_t4<16, true, false><<<grid, block, 0, stream>>>(a);
+    else bwd_src_mfma_t4<16, false, false><<<grid, block, 0, stream>>>(a);
   } else if (st.stats) {
     if (dh == 32 && L == kLmax) bwd_src_mfma<32, true, AMPCONV_PF_SRC, true><<<grid, block, 0, stream>>>(a);
     else if (dh == 32) bwd_src_mfma<32, false, 1, true><<<grid, block, 0, stream>>>(a);

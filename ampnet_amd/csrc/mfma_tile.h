@@ -212,7 +212,24 @@ __device__ __forceinline__ void colop_from_lds(float (&op)[5], const float *lds,
   for (int s = 0; s < 5; ++s) op[s] = lds[lds_idx<DH>(col_token(s, ks), c)];
 }
 
-// all-reduce over the 4 lane groups (lanes l, l^16, l^32, l^48): the 20 tokens of a C/D column
+// all-reduce over the 4 lane groups (lanes l, l^16, l^32, l^48): the 20 tokens of a C/D column.
+// v_permlane16_swap / v_permlane32_swap (gfx950) exchange whole 16- / 32-lane rows between two
+// registers in the vector ALU (lane maps: tools/mfma4_probe.hip); `__shfl_xor` compiles to
+// ds_bpermute_b32, an LDS-crossbar round trip the wave has to wait for (lgkmcnt).
+// NB: take the builtin's result into an explicitly typed 2-vector and read .x / .y.  With `auto r` and
+// r[0] / r[1], clang (ROCm 7.2) emitted extractvalue 0 for BOTH elements (a + b became 2 a).
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void swap16(float &a, float &b) {   // a' = [a0 b0 a2 b2], b' = [a1 b1 a3 b3] (16-lane rows)
+  const u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  a = __uint_as_float(r.x);
+  b = __uint_as_float(r.y);
+}
+__device__ __forceinline__ void swap32(float &a, float &b) {   // a' = [a0 a1 b0 b1], b' = [a2 a3 b2 b3]
+  const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  a = __uint_as_float(r.x);
+  b = __uint_as_float(r.y);
+}
+#ifdef AMPCONV_SHFL_BPERMUTE
 __device__ __forceinline__ float groups_max(float x) {
   x = fmaxf(x, __shfl_xor(x, 16, 64));
   return fmaxf(x, __shfl_xor(x, 32, 64));
@@ -221,12 +238,118 @@ __device__ __forceinline__ float groups_sum(float x) {
   x += __shfl_xor(x, 16, 64);
   return x + __shfl_xor(x, 32, 64);
 }
+#else
+__device__ __forceinline__ float groups_max(float x) {
+  float a = x, b = x;
+  swap16(a, b);                  // a = [x0 x0 x2 x2], b = [x1 x1 x3 x3]
+  a = b = fmaxf(a, b);
+  swap32(a, b);                  // a = [m01 m01 m01 m01], b = [m23 m23 m23 m23]
+  return fmaxf(a, b);
+}
+__device__ __forceinline__ float groups_sum(float x) {
+  float a = x, b = x;
+  swap16(a, b);
+  a = b = a + b;
+  swap32(a, b);
+  return a + b;
+}
+#endif
+
+// ---- 4-granular products for the FIXED side's tail tokens 16..19 (v_mfma_f32_4x4x1_16b_f32).
+// A 16x16x4 tile spends a whole 16-wide column tile on those four tokens (25 % useful); the 4x4x1
+// form runs sixteen independent 4x4 outer products at the same per-MAC rate (9.3 vs 32 cycles per
+// instruction, measured: tools/mfma4_probe.hip), so the tail columns cost a quarter.
+//   lane l = (g = l >> 4, sg = (l >> 2) & 3, j = l & 3); block b = l >> 2:
+//   A: lane holds A_b[i = l & 3]; B: B_b[j]; D: reg r of lane (b, j) = D_b[r][j] += A_b[r] B_b[j].
+//   blgp 4 + x: every lane group reads its B from lanes 16 x .. 16 x + 15.
+// Phase 1 (contraction over the channels): A = the ROW operand of the streamed 16-row tile as the
+//   16x16x4 products use it (lane (m, ks) = tile[m][KK ks + kk]: block (ks, sg) = rows 4 sg .. 4 sg + 3,
+//   channel KK ks + kk), B = tailop (lane (ks, sg, j) = fixed[16 + j][KK ks + kk]); D = the 16 x 4
+//   result split over the four channel groups ks -> reduce_transpose sums them and leaves ONE
+//   register: lane (g, sg, j) = result[row 4 sg + g][column 16 + j].
+// Phase 2 (contraction over the streamed rows): that register is the B operand; with blgp 4 + x all
+//   blocks see rows 4 sg + x, the A operand is image[4 sg + x][16 hf + 4 g + rr] (nt_accumulate) and
+//   block (g, sg) accumulates out[16 hf + 4 g + rr][16 + j] over its rows; the four sg partial sums
+//   are added once per unit (quads_sum).
+#define MFMA4(a, b, c, blgp) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (c), 0, 0, (blgp))
+
+__device__ __forceinline__ f32x4 mfma4_rows(float a, float b, f32x4 c, int x) {   // x is a constant after unrolling
+  switch (x) {
+    case 0: return MFMA4(a, b, c, 4);
+    case 1: return MFMA4(a, b, c, 5);
+    case 2: return MFMA4(a, b, c, 6);
+    default: return MFMA4(a, b, c, 7);
+  }
+}
+
+// fixed-side tail operand straight from global memory (once per unit), scaled; rows >= L read as zero
+template <int DH>
+__device__ __forceinline__ void tailop_from_global(float (&op)[TileCfg<DH>::KK], const float *base,
+                                                   int64_t row_stride, float mul, int L, int lane) {
+  using C = TileCfg<DH>;
+  const int j = 16 + (lane & 3), ks = lane >> 4;
+#pragma unroll
+  for (int b = 0; b < C::KK / 4; ++b) {
+    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (j < L)
+      x = *reinterpret_cast<const float4 *>(base + (int64_t)j * row_stride + C::KK * ks + 4 * b);
+    op[4 * b + 0] = x.x * mul; op[4 * b + 1] = x.y * mul;
+    op[4 * b + 2] = x.z * mul; op[4 * b + 3] = x.w * mul;
+  }
+}
+
+// phase-1 partials (reg r of lane group ks = partial of row 4 sg + r) -> lane (g, sg, j) = row 4 sg + g
+__device__ __forceinline__ float reduce_transpose(const f32x4 &x) {
+  float x0 = x[0], x1 = x[1], x2 = x[2], x3 = x[3];
+  swap16(x0, x1);                // x0 = [x0.g0 x1.g0 x0.g2 x1.g2], x1 = [x0.g1 x1.g1 x0.g3 x1.g3]
+  float y01 = x0 + x1;           // group 0: x0 over ks 0,1; 1: x1 over ks 0,1; 2: x0 over ks 2,3; 3: x1 over ks 2,3
+  swap16(x2, x3);
+  float y23 = x2 + x3;
+  swap32(y01, y23);              // y01 = [x0|01 x1|01 x2|01 x3|01], y23 = [x0|23 x1|23 x2|23 x3|23]
+  return y01 + y23;
+}
+
+// phase 2 over one 16-row image: acc[hf] (block (g, sg), reg rr, lane j) += image[4 sg + x][16 hf + 4 g + rr] z[row 4 sg + x][j].
+// `base` = this lane's float index of image[4 sg][4 g + rr] (x = 0, hf = 0).  In both image layouts
+// (lds_idx / tail_idx) the row step x and the channel half hf reach the index only through bit
+// fields that `base` leaves zero or through the XOR swizzle, so every other index is base ^ a
+// compile-time constant (nt_xor; checked against the index functions by nt_xor_ok): ONE address
+// register per image instead of one per read.
+constexpr int nt_xor(int DH, bool tail_image, int x, int hf) {
+  int c = (x * DH) ^ (hf << 4);
+  if (!(tail_image && DH == 16)) c ^= (x >> 1) << 2;     // swz / swz_tail take row bit 1 into chunk bit 0
+  return c;
+}
+template <int DH, bool TAIL_IMAGE>
+__device__ __forceinline__ void nt_accumulate(f32x4 (&acc)[TileCfg<DH>::MC], const float *img, int base, float z) {
+#pragma unroll
+  for (int x = 0; x < 4; ++x) {
+#pragma unroll
+    for (int hf = 0; hf < TileCfg<DH>::MC; ++hf) {
+      const float a = img[base ^ nt_xor(DH, TAIL_IMAGE, x, hf)];
+      acc[hf] = mfma4_rows(a, z, acc[hf], x);
+    }
+  }
+}
+
+// sum over the four quads (sg) of every 16-lane row: row_ror:4, row_ror:8
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x);
+__device__ __forceinline__ float quads_sum(float x);
 
 // all-reduce over the 16 lanes of a DPP row (lane & 15): the columns of a C/D tile
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float x) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF,
                                                                0xF, true));
+}
+__device__ __forceinline__ float quads_sum(float x) {
+  x += dpp_mov<0x124>(x);    // row_ror:4
+  return x + dpp_mov<0x128>(x);    // row_ror:8
+}
+__device__ __forceinline__ float quads_max(float x) {
+  x = fmaxf(x, dpp_mov<0x124>(x));
+  return fmaxf(x, dpp_mov<0x128>(x));
 }
 __device__ __forceinline__ float row16_max(float x) {
   x = fmaxf(x, dpp_mov<0xB1>(x));    // quad_perm [1,0,3,2]

@@ -43,6 +43,7 @@ WORKLOADS = {
     'tiny': (2000, 20000, 20, 256, 8, 'smoke-sized graph of the config-4 layer shape'),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_PEAK_TFLOPS = {'f32': 157.3, 'bf16': 2500.0}   # same guide: fp32-input MFMA = vector rate; dense bf16
 
 
 class KernelTimer:
@@ -152,7 +153,7 @@ def cpu_baseline(L, D, H, ratio):
                       f'torch {torch.__version__} CPU, {cores} threads'}
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
@@ -167,17 +168,68 @@ def main():
     ap.add_argument('--gemm', default='fp32', choices=['fp32', 'bf16x3'],
                     help='dense fp32 projections: plain fp32 GEMMs (default, the headline number) or '
                          "hipBLASLt's 3-product bf16 split (ampnet_amd.conv.functional.gemm_precision)")
-    args = ap.parse_args()
+    return ap.parse_args()
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher around it: start N fresh worker processes of this
+    script (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment) BEFORE this
+    process touches the GPU, wait for them, and exit non-zero if any of them failed.  Mirrors the
+    reference's own mp.spawn of one process per rank
+    (experiments/cora_benchmark_graphsaint_distributed.py:130-142).  Rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+    port = os.environ.get('MASTER_PORT')
+    if port is None:
+        with socket.socket() as s:
+            s.bind(('127.0.0.1', 0))
+            port = str(s.getsockname()[1])
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rcs = [p.wait() for p in procs]
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        print(f'bench.py: ranks failed (rank, exit code): {bad}', file=sys.stderr)
+        sys.exit(1)
+    sys.exit(0)
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        launch_ranks(args.gpus)                               # never returns
 
     rank = int(os.environ.get('RANK', 0))
-    local_rank = int(os.environ.get('LOCAL_RANK', 0)) % max(1, torch.cuda.device_count())
     world = int(os.environ.get('WORLD_SIZE', 1))
-    assert torch.cuda.is_available(), 'bench.py needs a GPU'
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU '
+                         f'(python bench.py --gpus N starts them itself)')
+    backend = os.environ.get('AMPCONV_DIST_BACKEND', 'nccl')       # nccl == RCCL on ROCm (gloo: CPU-side tests)
+    if os.environ.get('AMPCONV_BENCH_LAUNCH_ONLY') == '1':
+        # rehearsal of the launch path on a machine without a GPU (tests/test_bench_launch.py): the
+        # ranks rendezvous, all-reduce one CPU tensor over gloo and rank 0 reports; nothing is measured
+        if world > 1:
+            dist.init_process_group('gloo')
+        t = torch.ones(1)
+        if world > 1:
+            dist.all_reduce(t)
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({'launch_only': True, 'n_gpus': world, 'ranks_seen': int(t.item())}), flush=True)
+        return
+    n_dev = torch.cuda.device_count()
+    assert n_dev > 0 and torch.cuda.is_available(), 'bench.py needs a GPU'
+    if backend == 'nccl' and world > n_dev:
+        raise SystemExit(f'bench.py: {world} ranks but {n_dev} GPUs visible (one process per GPU over RCCL)')
+    local_rank = int(os.environ.get('LOCAL_RANK', 0)) % n_dev     # gloo rehearsal: ranks may share a card
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        backend = os.environ.get('AMPCONV_DIST_BACKEND', 'nccl')   # nccl == RCCL on ROCm (gloo: tests only)
         dist.init_process_group(backend, **({'device_id': dev} if backend == 'nccl' else {}))
 
     from ampnet_amd import AMPConv, graph_cache, _lib
@@ -272,6 +324,12 @@ def main():
         achieved = alg[dom] / (ms[dom] * 1e-3) / 1e9
         value = world * E * args.steps / dt
         b_alg = (6 * E + 15 * N) * R + 16 * E                 # whole layer, SURVEY.md 8d
+        # SURVEY.md 8d names two rooflines: HBM for the edge phase, the matrix pipe for the per-node
+        # projections.  FLOPs per step: attention 14 L^2 D per edge, projections 24 L D^2 per node.
+        flops_attn, flops_proj = 14 * L * L * D * E, 24 * L * D * D * N
+        mfma_peak = MFMA_PEAK_TFLOPS[dt_name]
+        t_step = dt / args.steps
+        t_hbm, t_mfma = b_alg / (HBM_PEAK_GBS * 1e9), (flops_attn + flops_proj) / (mfma_peak * 1e12)
         traffic = None                                         # PMC-measured HBM bytes per launch
         try:                                                   # (profiles/pmc_traffic.json, same workload)
             pmc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
@@ -291,7 +349,16 @@ def main():
             'layer_hbm': {'algorithmic_bytes_per_step': b_alg,
                           'achieved_GBps_per_gpu': b_alg * args.steps / dt / 1e9,
                           'frac_of_8TBps': b_alg * args.steps / dt / 1e9 / HBM_PEAK_GBS},
+            'layer_flops': {'attention_per_step': flops_attn, 'projections_per_step': flops_proj,
+                            'achieved_TFLOPs_per_gpu': (flops_attn + flops_proj) / t_step / 1e12,
+                            'peak_TFLOPs': mfma_peak, 'frac_of_peak': (flops_attn + flops_proj) / t_step / 1e12 / mfma_peak,
+                            'peak_note': 'fp32-input MFMA = fp32 vector rate (157.3 TF)' if dt_name == 'f32'
+                                         else 'dense bf16 MFMA',
+                            'floor_ms': {'hbm_at_8TBps': 1e3 * t_hbm, 'mfma_at_peak': 1e3 * t_mfma},
+                            'binding': 'mfma' if t_mfma > t_hbm else 'hbm'},
             'kernels_ms': ms,
+            'timing': 'value = wall clock over the K steps between barrier+synchronize fences, max over ranks '
+                      '(the contract); kernels_ms = mean HIP-event duration per launch over the same steps',
             'roofline': {'kernel': dom, 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'algorithmic_bytes_per_launch': alg[dom], 'avg_launch_ms': ms[dom]},

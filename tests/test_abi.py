@@ -39,7 +39,9 @@ def test_library_exports_every_declared_symbol(built):
     for n in _declared():
         assert hasattr(lib, n), f'{n} declared in include/ampconv.h but not exported'
     lib.ampconv_version.restype = ctypes.c_int
-    assert lib.ampconv_version() >= 100
+    from ampnet_amd import _lib
+    header_version = int(re.search(r'#define\s+AMPCONV_VERSION\s+(\d+)', open(HEADER).read()).group(1))
+    assert lib.ampconv_version() == header_version == _lib.EXPECTED_ABI
 
 
 def test_python_binding_matches_header(built):
@@ -96,4 +98,13 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, '_lib', None)
     monkeypatch.setattr(_lib, 'LIB_PATH', str(tmp_path / 'nope.so'))
     with pytest.raises(_lib.AmpconvError, match='no non-HIP fallback'):
+        _lib.load()
+
+
+def test_abi_version_mismatch_fails_loudly(built, monkeypatch):
+    """A library of another ABI version must not load (its argument lists differ)."""
+    from ampnet_amd import _lib
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'EXPECTED_ABI', _lib.EXPECTED_ABI + 1)
+    with pytest.raises(_lib.AmpconvError, match='ABI version'):
         _lib.load()
