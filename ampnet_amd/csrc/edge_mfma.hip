@@ -33,8 +33,20 @@ constexpr int kWavesPerBlock = AMPCONV_WPB;
 #ifndef AMPCONV_PF_SRC
 #define AMPCONV_PF_SRC 1
 #endif
+#ifndef AMPCONV_DST_WAVES
+#define AMPCONV_DST_WAVES 3      // waves per SIMD the destination pass is compiled for (168 registers; 2 = 256)
+#endif
+#ifndef AMPCONV_FWD_WAVES
+#define AMPCONV_FWD_WAVES 3      // waves per SIMD the forward pass is compiled for (168 registers; 4 = 128)
+#endif
+#ifndef AMPCONV_PF_FWD_T4
+#define AMPCONV_PF_FWD_T4 2      // main tiles in flight per wave in fwd_mfma_t4 (1 or 2)
+#endif
+#ifndef AMPCONV_PF_SRC_T4
+#define AMPCONV_PF_SRC_T4 2      // edges in flight per wave in bwd_src_mfma_t4 (1, 2 or 4); 2 and 4 need AMPCONV_SRC_WAVES=2
+#endif
 #ifndef AMPCONV_SRC_WAVES
-#define AMPCONV_SRC_WAVES 3      // waves per SIMD the source pass is compiled for (register budget 168 / 256)
+#define AMPCONV_SRC_WAVES 2      // waves per SIMD the source pass is compiled for (register budget 256; 3 = 168)
 #endif
 #ifdef AMPCONV_NO_SCHED_FENCE
 #define SCHED_FENCE()
@@ -626,17 +638,41 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? AMPCONV_SRC_WAVES :
     dK4[mc] = dV4[mc] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
 
-  PairRegs<DH> qg;
-  float inv_next = 0.f;
+  // register ring: the tiles of the next PF edges are in flight while one edge computes (PF = 2 needs
+  // the 256-register budget of two waves per SIMD: AMPCONV_SRC_WAVES=2)
+  constexpr int PF = DH == 32 ? AMPCONV_PF_SRC_T4 : 1;      // dh = 16 stays within 128 registers (4 waves per SIMD)
+  PairRegs<DH> ring[PF];
+  float ring_inv[PF];
+  // statistics of an edge (lse / delta of its destination tokens 4g .. 4g+3 and, NT4, of token 4 sg + g).
+  // STATS_AHEAD: they travel with the edge's tiles, PF edges ahead; otherwise they are loaded at the start
+  // of the edge's own phase and the wave waits for them behind the first MFMAs (fewer live registers: what
+  // the 168-register build needs; the wait is hidden only while other waves keep the matrix pipe busy)
+  constexpr bool STATS_AHEAD = DH == 32 && AMPCONV_SRC_WAVES < 3;
+  struct EdgeStats { f32x4 l4, d4; float lT, dT; };
+  EdgeStats ring_st[PF];
   IdxWindow win;
-  auto fetch = [&](int p) {
-    const int64_t d = idxwin_get<true>(win, a.idx, a.cinv, p, end, lane, &inv_next);
-    pair_load<DH, FULL>(qg, tile_ptr<const float>(a.Q, d, h), a.Q.row_stride,
+  auto load_stats = [&](EdgeStats &st, int p) {
+    const float *sbm = a.stats + ((int64_t)p * a.H + h) * kStatsPerUnit;
+    st.l4 = *reinterpret_cast<const f32x4 *>(sbm + 4 * g);
+    st.d4 = *reinterpret_cast<const f32x4 *>(sbm + kLmax + 4 * g);
+    if constexpr (NT4) {
+      st.lT = sbm[4 * sg + g];
+      st.dT = sbm[kLmax + 4 * sg + g];
+    }
+  };
+  auto fetch = [&](PairRegs<DH> &buf, float &inv, EdgeStats &st, int p) {
+    const int64_t d = idxwin_get<true>(win, a.idx, a.cinv, p, end, lane, &inv);
+    if constexpr (STATS_AHEAD) load_stats(st, p);
+    pair_load<DH, FULL>(buf, tile_ptr<const float>(a.Q, d, h), a.Q.row_stride,
                         tile_ptr<const float>(a.dO, d, h), a.dO.row_stride, L, lane);
   };
   if (beg < end) {
     idxwin_load<true>(win, a.idx, a.cinv, beg, end, lane);
-    fetch(beg);
+#pragma unroll
+    for (int k = 0; k < PF; ++k) {
+      ring_inv[k] = 0.f;
+      if (beg + k < end) fetch(ring[k], ring_inv[k], ring_st[k], beg + k);
+    }
   }
   const bool v0 = n < L, v1 = 16 + n < L;
   const bool vt = FULL || 16 + jt < L;       // NT4: this lane's source tail token exists
@@ -645,23 +681,32 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? AMPCONV_SRC_WAVES :
   // are XOR constants away (nt_accumulate)
   const int nt_main = lds_idx<DH>(4 * sg, 4 * g + jt), nt_stash = tail_idx<DH>(8 * sg, 4 * g + jt);
 
+  // statistics of the batch's tail tile: tokens 16..19 of edge p0 + g (l4 / d4) and, NT4, token 16 + g of edge p0 + sg
+  auto load_tail_stats = [&](EdgeStats &st, int p0) {
+    const float *sb = a.stats + ((int64_t)(p0 + g < end ? p0 + g : end - 1) * a.H + h) * kStatsPerUnit;
+    st.l4 = *reinterpret_cast<const f32x4 *>(sb + 16);
+    st.d4 = *reinterpret_cast<const f32x4 *>(sb + kLmax + 16);
+    if constexpr (NT4) {
+      const float *sbT = a.stats + ((int64_t)(p0 + sg < end ? p0 + sg : end - 1) * a.H + h) * kStatsPerUnit;
+      st.lT = sbT[16 + g];
+      st.dT = sbT[kLmax + 16 + g];
+    }
+  };
   for (int p0 = beg; p0 < end; p0 += 4) {
-#pragma unroll 1
+    EdgeStats tail_st;
+    if constexpr (STATS_AHEAD) load_tail_stats(tail_st, p0);     // used four main phases later
+#pragma unroll(PF == 1 ? 1 : 4)
     for (int e = 0; e < 4; ++e) {
       const int p = p0 + e;
       if (p >= end) break;
+      PairRegs<DH> &qg = ring[e % PF];             // batches are 4 edges long: the ring slot of an edge is e % PF
+      float &inv_next = ring_inv[e % PF];
       pair_to_lds_tail<DH, FULL>(Qt, stash, e, qg, a.qscale, inv_next, L, lane);
-      // statistics of this edge's tokens 4g .. 4g+3: issued ahead of the tile loads of the next
-      // edge, needed only after the first 32 MFMAs
-      const float *sbm = a.stats + ((int64_t)p * a.H + h) * kStatsPerUnit;
-      const f32x4 l4 = *reinterpret_cast<const f32x4 *>(sbm + 4 * g);
-      const f32x4 d4 = *reinterpret_cast<const f32x4 *>(sbm + kLmax + 4 * g);
-      float lT = 0.f, dT = 0.f;              // NT4: statistics of destination token 4 sg + g
-      if constexpr (NT4) {
-        lT = sbm[4 * sg + g];
-        dT = sbm[kLmax + 4 * sg + g];
-      }
-      if (p + 1 < end) fetch(p + 1);
+      EdgeStats st = ring_st[e % PF];
+      if constexpr (!STATS_AHEAD) load_stats(st, p);   // ahead of the tile loads of the next edge
+      const f32x4 l4 = st.l4, d4 = st.d4;
+      const float lT = st.lT, dT = st.dT;
+      if (p + PF < end) fetch(qg, inv_next, ring_st[e % PF], p + PF);
       __builtin_amdgcn_wave_barrier();
 
       // main tile: destination tokens 0..15 of this edge.  S first, then dP (NT4: one after the other
@@ -741,18 +786,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? AMPCONV_SRC_WAVES :
     // tail tile of the (up to) four edges p0 .. p0+3: lane group g <-> edge p0 + g
     {
       const bool live = p0 + g < end;
-      const int pe = live ? p0 + g : end - 1;
-      const float *sb = a.stats + ((int64_t)pe * a.H + h) * kStatsPerUnit;
-      const f32x4 l4 = *reinterpret_cast<const f32x4 *>(sb + 16);
-      const f32x4 d4 = *reinterpret_cast<const f32x4 *>(sb + kLmax + 16);
       // NT4: lane (g, sg, jt) <-> row 4 sg + g of the tail tile = (edge p0 + sg, destination token 16 + g)
       const bool liveT = p0 + sg < end;
-      float lT = 0.f, dT = 0.f;
-      if constexpr (NT4) {
-        const float *sbT = a.stats + ((int64_t)(liveT ? p0 + sg : end - 1) * a.H + h) * kStatsPerUnit;
-        lT = sbT[16 + g];
-        dT = sbT[kLmax + 16 + g];
-      }
+      EdgeStats tl = tail_st;
+      if constexpr (!STATS_AHEAD) load_tail_stats(tl, p0);
+      const f32x4 l4 = tl.l4, d4 = tl.d4;
+      const float lT = tl.lT, dT = tl.dT;
       f32x4 S0, S1, dP0, dP1;
       S0 = S1 = dP0 = dP1 = f32x4{0.f, 0.f, 0.f, 0.f};
       {
@@ -932,9 +971,16 @@ __device__ __forceinline__ void tail_to_lds(float *img, const TailRegs<DH> &t, i
   }
 }
 
-template <int DH, bool FULL>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void fwd_mfma_t4(FwdArgs a) {
+// NT4: the destination's own tail tokens 16..19 (the padded second COLUMN tile) run on
+// v_mfma_f32_4x4x1_16b_f32 (mfma_tile.h, "4-granular products"): phase 1 leaves ONE register per 16-row
+// tile, lane (g, sg, j) = S^T[source token 4 sg + g][destination token 16 + j]; the column softmax of edge e
+// runs over the 16 lanes that share j (quad rotation + row swaps) with lane quad sg == e folding in the
+// batch's tail tile (its row 4 sg + g = source token 16 + g of edge sg); phase 2 takes the probabilities
+// back as the B operand.  Per edge and head: 20 16x16x4 + 20 4x4x1 instead of 40 16x16x4.
+template <int DH, bool FULL, bool NT4>
+__global__ __launch_bounds__(64 * kWavesPerBlock, AMPCONV_FWD_WAVES) void fwd_mfma_t4(FwdArgs a) {
   using C = TileCfg<DH>;
+  constexpr int NTM = NT4 ? 1 : 2;           // 16-wide destination-token column tiles on the 16x16x4 path
   __shared__ __attribute__((aligned(16))) float lds_all[kWavesPerBlock][4 * 16 * DH];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -943,21 +989,29 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void fwd_mfma_t4(FwdArgs a) {
   int64_t r, onode;
   int h, beg, end, deg;
   if (!map_unit(a.hub, a.rowptr, unit, a.H, r, onode, h, beg, end, deg)) return;
-  const int L = a.L, g = lane >> 4, n = lane & 15;
+  const int L = a.L, g = lane >> 4, n = lane & 15, sg = (lane >> 2) & 3, jt = lane & 3;
   float *Kt = lds_all[wave], *Vt = Kt + 16 * DH, *Ktail = Kt + 32 * DH, *Vtail = Kt + 48 * DH;
   const int64_t d = a.qidx ? a.qidx[r] : r;
 
-  float qB[2][C::KK];
+  float qB[NTM][C::KK];
+  float qT[NT4 ? C::KK : 1];
   {
     const float *qb = tile_ptr<const float>(a.Q, d, h);
-    rowop_from_global<DH>(qB[0], qb, a.Q.row_stride, 0, true, a.qscale, L, lane);
-    rowop_from_global<DH>(qB[1], qb, a.Q.row_stride, 1, true, a.qscale, L, lane);
+#pragma unroll
+    for (int nt = 0; nt < NTM; ++nt) rowop_from_global<DH>(qB[nt], qb, a.Q.row_stride, nt, true, a.qscale, L, lane);
+    if constexpr (NT4) tailop_from_global<DH>(qT, qb, a.Q.row_stride, a.qscale, L, lane);
   }
   if (!FULL)
     for (int i = lane; i < 4 * 16 * DH; i += AMPCONV_WAVE) Kt[i] = 0.f;
-  f32x4 OT[C::MC][2];
+  f32x4 OT[C::MC][NTM];
+  f32x4 O4[C::MC];                           // NT4: block (g, sg), reg rr, lane jt: channel 16 hf + 4 g + rr, token 16 + jt
 #pragma unroll
-  for (int mc = 0; mc < C::MC; ++mc) OT[mc][0] = OT[mc][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int mc = 0; mc < C::MC; ++mc) {
+#pragma unroll
+    for (int nt = 0; nt < NTM; ++nt) OT[mc][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    O4[mc] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int nt_base = lds_idx<DH>(4 * sg, 4 * g + jt);        // NT4 phase 2: row 4 sg, channel 4 g + jt of a 16-row image
 
   // sources of the edges of the current / next batch (wave-uniform scalars; positions clamped to
   // the segment, the window is walked strictly forwards)
@@ -972,13 +1026,17 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void fwd_mfma_t4(FwdArgs a) {
     o3 = idxwin_get<false>(win, a.col, nullptr, p_ + 3 < end ? p_ + 3 : end - 1, end, lane, nullptr); \
   } while (0)
   TailRegs<DH> ktn, vtn;
-  MainRegs<DH> ring;
+  constexpr int PF = DH == 32 ? AMPCONV_PF_FWD_T4 : 1;     // main tiles of the next PF edges in flight (ring slot = e % PF)
+  MainRegs<DH> ring[PF];
   if (beg < end) {
     idxwin_load<false>(win, a.col, nullptr, beg, end, lane);
     AMPCONV_IDS(id0, id1, id2, id3, beg);
     tail_load<DH, FULL>(ktn, a.K, h, id0, id1, id2, id3, L, lane);
-    main_load<DH, FULL>(ring, tile_ptr<const float>(a.K, id0, h), a.K.row_stride,
+    main_load<DH, FULL>(ring[0], tile_ptr<const float>(a.K, id0, h), a.K.row_stride,
                         tile_ptr<const float>(a.V, id0, h), a.V.row_stride, L, lane);
+    if (PF == 2 && beg + 1 < end)
+      main_load<DH, FULL>(ring[PF - 1], tile_ptr<const float>(a.K, id1, h), a.K.row_stride,
+                          tile_ptr<const float>(a.V, id1, h), a.V.row_stride, L, lane);
   }
 
   for (int p0 = beg; p0 < end; p0 += 4) {
@@ -991,23 +1049,33 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void fwd_mfma_t4(FwdArgs a) {
     if (more) tail_load<DH, FULL>(ktn, a.K, h, nid0, nid1, nid2, nid3, L, lane);   // a whole batch ahead
     tail_load<DH, FULL>(vtn, a.V, h, id0, id1, id2, id3, L, lane);                  // this batch's closing operand
     __builtin_amdgcn_wave_barrier();
-    f32x4 St[2];
-    St[0] = St[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 St[NTM];
+    f32x4 St4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int nt = 0; nt < NTM; ++nt) St[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     {
       float kt[C::KK];
       rowop_from_lds<DH>(kt, Ktail, 0, lane);
 #pragma unroll
       for (int kk = 0; kk < C::KK; ++kk) {
-        St[0] = MFMA16(kt[kk], qB[0][kk], St[0]);
-        St[1] = MFMA16(kt[kk], qB[1][kk], St[1]);
+#pragma unroll
+        for (int nt = 0; nt < NTM; ++nt) St[nt] = MFMA16(kt[kk], qB[nt][kk], St[nt]);
+        if constexpr (NT4) St4 = MFMA4(kt[kk], qT[kk], St4, 0);
       }
+    }
+    // NT4: lane (g, sg, jt) = tail score of (edge p0 + sg, source token 16 + g) against destination token 16 + jt
+    float zt = 0.f, PtT = 0.f;
+    if constexpr (NT4) {
+      zt = reduce_transpose(St4);
+      if (p0 + sg >= end || (!FULL && 16 + g >= L)) zt = kNegBig;
     }
     // per lane (edge g, destination column): tail max tm, u = exp2(S - tm) and their sum, once per
     // batch; an edge's main phase only rescales them by exp2(tm - m) / l.  (The destination pass keeps
     // the per-edge form: the four extra live registers spill inside its loop and the gain is lost.)
-    float tm[2], tsum[2], csel[2] = {0.f, 0.f};
+    float tm[NTM], tsum[NTM], csel[NTM];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
+    for (int nt = 0; nt < NTM; ++nt) {
+      csel[nt] = 0.f;
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         if (!live || (!FULL && 16 + q >= L)) St[nt][q] = kNegBig;
@@ -1021,29 +1089,33 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void fwd_mfma_t4(FwdArgs a) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       if (p0 + e >= end) break;
-      main_to_lds<DH, FULL>(Kt, ring, L, lane);
-      {
-        const bool has_next = e < 3 ? p0 + e + 1 < end : more;
-        const int next = e == 0 ? id1 : e == 1 ? id2 : e == 2 ? id3 : nid0;
+      main_to_lds<DH, FULL>(Kt, ring[e % PF], L, lane);
+      {      // edge p0 + e + PF: ids of this batch, then of the next (clamped ids are never fetched: has_next)
+        const bool has_next = p0 + e + PF < end;
+        const int next = PF == 1 ? (e == 0 ? id1 : e == 1 ? id2 : e == 2 ? id3 : nid0)
+                                 : (e == 0 ? id2 : e == 1 ? id3 : e == 2 ? nid0 : nid1);
         if (has_next)
-          main_load<DH, FULL>(ring, tile_ptr<const float>(a.K, next, h), a.K.row_stride,
+          main_load<DH, FULL>(ring[e % PF], tile_ptr<const float>(a.K, next, h), a.K.row_stride,
                               tile_ptr<const float>(a.V, next, h), a.V.row_stride, L, lane);
       }
       __builtin_amdgcn_wave_barrier();
-      f32x4 S[2];
+      f32x4 S[NTM];
+      f32x4 S4 = f32x4{0.f, 0.f, 0.f, 0.f};
       {
         float kA[C::KK];
         rowop_from_lds<DH>(kA, Kt, 0, lane);
-        S[0] = S[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int nt = 0; nt < NTM; ++nt) S[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < C::KK; ++kk) {
-          S[0] = MFMA16(kA[kk], qB[0][kk], S[0]);
-          S[1] = MFMA16(kA[kk], qB[1][kk], S[1]);
+#pragma unroll
+          for (int nt = 0; nt < NTM; ++nt) S[nt] = MFMA16(kA[kk], qB[nt][kk], S[nt]);
+          if constexpr (NT4) S4 = MFMA4(kA[kk], qT[kk], S4, 0);
         }
       }
       const bool mine = g == e;                          // this lane group holds edge e's tail rows
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
+      for (int nt = 0; nt < NTM; ++nt) {
         f32x4 &s = S[nt];
         if (!FULL) {
 #pragma unroll
@@ -1061,23 +1133,36 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void fwd_mfma_t4(FwdArgs a) {
         for (int q = 0; q < 4; ++q) s[q] *= inv;
         csel[nt] = mine ? ct * inv : csel[nt];             // edge e's tail rows: P^T = u * csel
       }
+      float pz = 0.f;
+      if constexpr (NT4) {        // columns 16..19: softmax over the 16 lanes that share jt (+ quad e of the tail tile)
+        const bool mineT = sg == e;
+        float z = reduce_transpose(S4);
+        if (!FULL && 4 * sg + g >= L) z = kNegBig;
+        const float m = groups_max(quads_max(fmaxf(z, mineT ? zt : kNegBig)));
+        pz = fast_exp2(z - m);
+        const float pt = mineT ? fast_exp2(zt - m) : 0.f;
+        const float inv = fast_rcp(groups_sum(quads_sum(pz + pt)));
+        pz *= inv;
+        PtT = mineT ? pt * inv : PtT;
+      }
 #pragma unroll
       for (int mc = 0; mc < C::MC; ++mc) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const float vA = Vt[lds_idx<DH>(4 * g + q, n + 16 * mc)];
-          OT[mc][0] = MFMA16(vA, S[0][q], OT[mc][0]);
-          OT[mc][1] = MFMA16(vA, S[1][q], OT[mc][1]);
+#pragma unroll
+          for (int nt = 0; nt < NTM; ++nt) OT[mc][nt] = MFMA16(vA, S[nt][q], OT[mc][nt]);
         }
       }
+      if constexpr (NT4) nt_accumulate<DH, false>(O4, Vt, nt_base, pz);
       __builtin_amdgcn_wave_barrier();
     }
 
     // closing product of the batch: contraction over (edge g, token 16 + q)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {          // u = 0 for edges beyond the segment and tokens beyond L
-      St[0][q] *= csel[0];
-      St[1][q] *= csel[1];
+    for (int nt = 0; nt < NTM; ++nt) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) St[nt][q] *= csel[nt];   // u = 0 for edges beyond the segment and tokens beyond L
     }
     tail_to_lds<DH, FULL>(Vtail, vtn, L, lane);
     __builtin_amdgcn_wave_barrier();
@@ -1086,10 +1171,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void fwd_mfma_t4(FwdArgs a) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const float vA = Vtail[lds_idx<DH>(4 * g + q, n + 16 * mc)];
-        OT[mc][0] = MFMA16(vA, St[0][q], OT[mc][0]);
-        OT[mc][1] = MFMA16(vA, St[1][q], OT[mc][1]);
+#pragma unroll
+        for (int nt = 0; nt < NTM; ++nt) OT[mc][nt] = MFMA16(vA, St[nt][q], OT[mc][nt]);
       }
     }
+    if constexpr (NT4) nt_accumulate<DH, false>(O4, Vtail, nt_base, PtT);   // row 4 sg + x = (edge sg, token 16 + x)
     __builtin_amdgcn_wave_barrier();
     id0 = nid0; id1 = nid1; id2 = nid2; id3 = nid3;
   }
@@ -1098,7 +1184,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void fwd_mfma_t4(FwdArgs a) {
   const float inv = a.hub.mode == 2 ? 1.f : (deg > 0 ? 1.f / (float)deg : 0.f);
   float *ob = tile_ptr<float>(a.O, onode, h);
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
+  for (int nt = 0; nt < NTM; ++nt) {
     const int i = n + 16 * nt;
     if (i < L) {
 #pragma unroll
@@ -1107,6 +1193,16 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void fwd_mfma_t4(FwdArgs a) {
                                OT[mc][nt][3] * inv);
         *reinterpret_cast<float4 *>(ob + (int64_t)i * a.O.row_stride + 4 * g + 16 * mc) = o;
       }
+    }
+  }
+  if constexpr (NT4) {          // the four sg partial sums of every block column, then one quad stores
+#pragma unroll
+    for (int hf = 0; hf < C::MC; ++hf) {
+      float4 o;
+      o.x = quads_sum(O4[hf][0]) * inv; o.y = quads_sum(O4[hf][1]) * inv;
+      o.z = quads_sum(O4[hf][2]) * inv; o.w = quads_sum(O4[hf][3]) * inv;
+      if (sg == 0 && 16 + jt < L)
+        *reinterpret_cast<float4 *>(ob + (int64_t)(16 + jt) * a.O.row_stride + 16 * hf + 4 * g) = o;
     }
   }
 }
@@ -1147,8 +1243,12 @@ __device__ __forceinline__ void tail_dma(float *img, const ampconv_view_t &view,
   }
 }
 
-template <int DH, bool FULL, bool STATS>
-__global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? 3 : 4) void bwd_dst_mfma_t4(BwdArgs a) {
+// NT4: the destination's own tail tokens 16..19 (second column tile) on v_mfma_f32_4x4x1_16b_f32, as in
+// fwd_mfma_t4: phase 1 leaves one register per product and 16-row tile (lane (g, sg, j) = source token
+// 4 sg + g, destination token 16 + j); max, sum and delta of a column are all-reduces over the 16 lanes that
+// share j, quad sg == e folding in the batch's tail tile.  Per edge and head 30 16x16x4 + 30 4x4x1 instead of 60.
+template <int DH, bool FULL, bool STATS, bool NT4>
+__global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? AMPCONV_DST_WAVES : 4) void bwd_dst_mfma_t4(BwdArgs a) {
   using C = TileCfg<DH>;
   constexpr int kImg = 16 * DH;
   // two separate LDS objects: the compiler orders every LDS read behind an LDS-DMA it cannot prove
@@ -1163,28 +1263,40 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? 3 : 4) void bwd_dst
   int64_t r, onode;
   int h, beg, end, deg;
   if (!map_unit(a.hub, a.ptr, unit, a.H, r, onode, h, beg, end, deg)) return;
-  const int L = a.L, g = lane >> 4, n = lane & 15;
+  constexpr int NTM = NT4 ? 1 : 2;           // 16-wide destination-token column tiles on the 16x16x4 path
+  const int L = a.L, g = lane >> 4, n = lane & 15, sg = (lane >> 2) & 3, jt = lane & 3;
   float *Kt = lds_all[wave], *Vt = Kt + kImg, *tails = lds_tails[wave];
   const float inv = deg > 0 ? 1.f / (float)deg : 0.f;       // dO is the gradient of the MEAN
   const float oscale = a.hub.mode == 2 ? 1.f : a.oscale;
 
-  float qB[2][C::KK], dOB[2][C::KK];
+  float qB[NTM][C::KK], dOB[NTM][C::KK];
+  float qT[NT4 ? C::KK : 1], gT[NT4 ? C::KK : 1];
   {
     const float *qb = tile_ptr<const float>(a.Q, r, h);
     const float *gb = tile_ptr<const float>(a.dO, r, h);
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
+    for (int nt = 0; nt < NTM; ++nt) {
       rowop_from_global<DH>(qB[nt], qb, a.Q.row_stride, nt, true, a.qscale, L, lane);
       rowop_from_global<DH>(dOB[nt], gb, a.dO.row_stride, nt, true, inv, L, lane);
+    }
+    if constexpr (NT4) {
+      tailop_from_global<DH>(qT, qb, a.Q.row_stride, a.qscale, L, lane);
+      tailop_from_global<DH>(gT, gb, a.dO.row_stride, inv, L, lane);
     }
   }
   if (!FULL) {
     for (int i = lane; i < 2 * kImg; i += AMPCONV_WAVE) Kt[i] = 0.f;
     for (int i = lane; i < 4 * kImg; i += AMPCONV_WAVE) tails[i] = 0.f;
   }
-  f32x4 dQT[C::MC][2];
+  f32x4 dQT[C::MC][NTM];
+  f32x4 dQ4[C::MC];                          // NT4: block (g, sg), reg rr, lane jt: channel 16 hf + 4 g + rr, token 16 + jt
 #pragma unroll
-  for (int mc = 0; mc < C::MC; ++mc) dQT[mc][0] = dQT[mc][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int mc = 0; mc < C::MC; ++mc) {
+#pragma unroll
+    for (int nt = 0; nt < NTM; ++nt) dQT[mc][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    dQ4[mc] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int nt_base = lds_idx<DH>(4 * sg, 4 * g + jt);        // NT4 phase 2: row 4 sg, channel 4 g + jt of a 16-row image
 
   IdxWindow win;
   const float *wts = reinterpret_cast<const float *>(a.spos);
@@ -1226,25 +1338,43 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? 3 : 4) void bwd_dst
       else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     }
     __builtin_amdgcn_wave_barrier();
-    f32x4 St[2], dPt[2];
-    St[0] = St[1] = dPt[0] = dPt[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 St[NTM], dPt[NTM];
+    f32x4 St4 = f32x4{0.f, 0.f, 0.f, 0.f}, dPt4 = St4;
+#pragma unroll
+    for (int nt = 0; nt < NTM; ++nt) St[nt] = dPt[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     {
       float kt[C::KK], vt[C::KK];
       rowop_from_lds<DH>(kt, Ktail, 0, lane);
       rowop_from_lds<DH>(vt, Vtail, 0, lane);
 #pragma unroll
       for (int kk = 0; kk < C::KK; ++kk) {
-        St[0] = MFMA16(kt[kk], qB[0][kk], St[0]);
-        St[1] = MFMA16(kt[kk], qB[1][kk], St[1]);
-        dPt[0] = MFMA16(vt[kk], dOB[0][kk], dPt[0]);
-        dPt[1] = MFMA16(vt[kk], dOB[1][kk], dPt[1]);
+#pragma unroll
+        for (int nt = 0; nt < NTM; ++nt) {
+          St[nt] = MFMA16(kt[kk], qB[nt][kk], St[nt]);
+          dPt[nt] = MFMA16(vt[kk], dOB[nt][kk], dPt[nt]);
+        }
+        if constexpr (NT4) {
+          St4 = MFMA4(kt[kk], qT[kk], St4, 0);
+          dPt4 = MFMA4(vt[kk], gT[kk], dPt4, 0);
+        }
       }
+    }
+    // NT4: lane (g, sg, jt) = (edge p0 + sg, source token 16 + g) against destination token 16 + jt
+    float zt = 0.f, dzt = 0.f, DsT = 0.f;
+    if constexpr (NT4) {
+      zt = reduce_transpose(St4);
+      dzt = reduce_transpose(dPt4);
+      if (p0 + sg >= end || (!FULL && 16 + g >= L)) zt = kNegBig;
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-      if (!live || (!FULL && 16 + q >= L)) St[0][q] = St[1][q] = kNegBig;
-    const float tm0 = fmaxf(fmaxf(St[0][0], St[0][1]), fmaxf(St[0][2], St[0][3]));
-    const float tm1 = fmaxf(fmaxf(St[1][0], St[1][1]), fmaxf(St[1][2], St[1][3]));
+      if (!live || (!FULL && 16 + q >= L)) {
+#pragma unroll
+        for (int nt = 0; nt < NTM; ++nt) St[nt][q] = kNegBig;
+      }
+    float tmx[NTM];
+#pragma unroll
+    for (int nt = 0; nt < NTM; ++nt) tmx[nt] = fmaxf(fmaxf(St[nt][0], St[nt][1]), fmaxf(St[nt][2], St[nt][3]));
 
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -1269,8 +1399,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? 3 : 4) void bwd_dst
         const float pos = e == 0 ? sp0 : e == 1 ? sp1 : e == 2 ? sp2 : sp3;
         sb = a.stats + ((int64_t)__builtin_bit_cast(int, pos) * a.H + h) * kStatsPerUnit;
       }
+      f32x4 S4 = f32x4{0.f, 0.f, 0.f, 0.f}, dP4 = S4;
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
+      for (int nt = 0; nt < NTM; ++nt) {
         f32x4 S0 = f32x4{0.f, 0.f, 0.f, 0.f}, dP0 = S0;
         {
           float kA[C::KK], vA[C::KK];
@@ -1280,6 +1411,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? 3 : 4) void bwd_dst
           for (int kk = 0; kk < C::KK; ++kk) {
             S0 = MFMA16(kA[kk], qB[nt][kk], S0);
             dP0 = MFMA16(vA[kk], dOB[nt][kk], dP0);
+            if constexpr (NT4) {
+              S4 = MFMA4(kA[kk], qT[kk], S4, 0);
+              dP4 = MFMA4(vA[kk], gT[kk], dP4, 0);
+            }
           }
         }
         if (!FULL) {
@@ -1288,7 +1423,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? 3 : 4) void bwd_dst
             if (4 * g + q >= L) S0[q] = kNegBig;
         }
         float m = fmaxf(fmaxf(S0[0], S0[1]), fmaxf(S0[2], S0[3]));
-        m = groups_max(fmaxf(m, mine ? (nt == 0 ? tm0 : tm1) : kNegBig));
+        m = groups_max(fmaxf(m, mine ? tmx[nt] : kNegBig));
         f32x4 pt;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -1328,22 +1463,47 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? 3 : 4) void bwd_dst
           }
         }
       }
+      if constexpr (NT4) {        // columns 16..19: all-reduces over the 16 lanes that share jt (+ quad e of the tail tile)
+        const bool mineT = sg == e;
+        float z = reduce_transpose(S4);
+        const float dz = reduce_transpose(dP4);
+        if (!FULL && 4 * sg + g >= L) z = kNegBig;
+        const float m = groups_max(quads_max(fmaxf(z, mineT ? zt : kNegBig)));
+        float pz = fast_exp2(z - m), pt = mineT ? fast_exp2(zt - m) : 0.f;
+        const float l = groups_sum(quads_sum(pz + pt));
+        const float rinv = fast_rcp(l);
+        pz *= rinv;
+        pt *= rinv;
+        const float delta = groups_sum(quads_sum(fmaf(pz, dz, pt * dzt)));
+        if (STATS) {
+          if (lane < 4) {          // g == 0, sg == 0: destination token 16 + jt
+            sb[16 + jt] = m + __builtin_amdgcn_logf(l);
+            sb[kLmax + 16 + jt] = delta;
+          }
+        }
+        DsT = mineT ? pt * (dzt - delta) : DsT;                 // dS^T of edge e's tail rows
+        nt_accumulate<DH, false>(dQ4, Kt, nt_base, pz * (dz - delta));
+      }
       __builtin_amdgcn_wave_barrier();
     }
 
     // closing product of the batch: contraction over (edge g, token 16 + q)
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-      if (!live) dPt[0][q] = dPt[1][q] = 0.f;
+      if (!live) {
+#pragma unroll
+        for (int nt = 0; nt < NTM; ++nt) dPt[nt][q] = 0.f;
+      }
 #pragma unroll
     for (int mc = 0; mc < C::MC; ++mc) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const float kC = Ktail[lds_idx<DH>(4 * g + q, n + 16 * mc)];
-        dQT[mc][0] = MFMA16(kC, dPt[0][q], dQT[mc][0]);
-        dQT[mc][1] = MFMA16(kC, dPt[1][q], dQT[mc][1]);
+#pragma unroll
+        for (int nt = 0; nt < NTM; ++nt) dQT[mc][nt] = MFMA16(kC, dPt[nt][q], dQT[mc][nt]);
       }
     }
+    if constexpr (NT4) nt_accumulate<DH, false>(dQ4, Ktail, nt_base, DsT);   // row 4 sg + x = (edge sg, token 16 + x)
     __builtin_amdgcn_wave_barrier();
     id0 = nid0; id1 = nid1; id2 = nid2; id3 = nid3;
     sp0 = nsp0; sp1 = nsp1; sp2 = nsp2; sp3 = nsp3;
@@ -1353,7 +1513,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? 3 : 4) void bwd_dst
 
   float *ob = tile_ptr<float>(a.dQ, onode, h);
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
+  for (int nt = 0; nt < NTM; ++nt) {
     const int i = n + 16 * nt;
     if (i < L) {
 #pragma unroll
@@ -1362,6 +1522,16 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? 3 : 4) void bwd_dst
                                dQT[mc][nt][2] * oscale, dQT[mc][nt][3] * oscale);
         *reinterpret_cast<float4 *>(ob + (int64_t)i * a.dQ.row_stride + 4 * g + 16 * mc) = o;
       }
+    }
+  }
+  if constexpr (NT4) {          // the four sg partial sums of every block column, then one quad stores
+#pragma unroll
+    for (int hf = 0; hf < C::MC; ++hf) {
+      float4 o;
+      o.x = quads_sum(dQ4[hf][0]) * oscale; o.y = quads_sum(dQ4[hf][1]) * oscale;
+      o.z = quads_sum(dQ4[hf][2]) * oscale; o.w = quads_sum(dQ4[hf][3]) * oscale;
+      if (sg == 0 && 16 + jt < L)
+        *reinterpret_cast<float4 *>(ob + (int64_t)(16 + jt) * a.dQ.row_stride + 16 * hf + 4 * g) = o;
     }
   }
 }
@@ -1394,11 +1564,19 @@ int ampconv_fwd_edge_mfma(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
   if (blocks > INT32_MAX) return AMPCONV_E_BADARG;
   const dim3 grid((unsigned)blocks), block(64 * kWavesPerBlock);
   static const bool t4 = !(std::getenv("AMPCONV_FWD_T4") && std::getenv("AMPCONV_FWD_T4")[0] == '0');
+  static const bool nt4 = !(std::getenv("AMPCONV_FWD_NT4") && std::getenv("AMPCONV_FWD_NT4")[0] == '0');
   if (t4 && L > 16) {                    // batched tails pay only if there are tail tokens
-    if (dh == 32 && L == kLmax) fwd_mfma_t4<32, true><<<grid, block, 0, stream>>>(a);
-    else if (dh == 32) fwd_mfma_t4<32, false><<<grid, block, 0, stream>>>(a);
-    else if (L == kLmax) fwd_mfma_t4<16, true><<<grid, block, 0, stream>>>(a);
-    else fwd_mfma_t4<16, false><<<grid, block, 0, stream>>>(a);
+    if (nt4) {                           // destination tail columns on 4x4x1
+      if (dh == 32 && L == kLmax) fwd_mfma_t4<32, true, true><<<grid, block, 0, stream>>>(a);
+      else if (dh == 32) fwd_mfma_t4<32, false, true><<<grid, block, 0, stream>>>(a);
+      else if (L == kLmax) fwd_mfma_t4<16, true, true><<<grid, block, 0, stream>>>(a);
+      else fwd_mfma_t4<16, false, true><<<grid, block, 0, stream>>>(a);
+    } else {
+      if (dh == 32 && L == kLmax) fwd_mfma_t4<32, true, false><<<grid, block, 0, stream>>>(a);
+      else if (dh == 32) fwd_mfma_t4<32, false, false><<<grid, block, 0, stream>>>(a);
+      else if (L == kLmax) fwd_mfma_t4<16, true, false><<<grid, block, 0, stream>>>(a);
+      else fwd_mfma_t4<16, false, false><<<grid, block, 0, stream>>>(a);
+    }
     return ampconv_launch_status();
   }
   if (dh == 32 && L == kLmax) fwd_mfma<32, true, AMPCONV_PF_FWD><<<grid, block, 0, stream>>>(a);
@@ -1425,18 +1603,20 @@ int ampconv_bwd_edge_dst_mfma(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t
   if (blocks > INT32_MAX) return AMPCONV_E_BADARG;
   const dim3 grid((unsigned)blocks), block(64 * kWavesPerBlock);
   static const bool t4 = !(std::getenv("AMPCONV_DST_T4") && std::getenv("AMPCONV_DST_T4")[0] == '0');
+  static const bool nt4 = !(std::getenv("AMPCONV_DST_NT4") && std::getenv("AMPCONV_DST_NT4")[0] == '0');
   if (t4 && L > 16) {                    // batched tails pay only if there are tail tokens
-    if (st.stats) {
-      if (dh == 32 && L == kLmax) bwd_dst_mfma_t4<32, true, true><<<grid, block, 0, stream>>>(a);
-      else if (dh == 32) bwd_dst_mfma_t4<32, false, true><<<grid, block, 0, stream>>>(a);
-      else if (L == kLmax) bwd_dst_mfma_t4<16, true, true><<<grid, block, 0, stream>>>(a);
-      else bwd_dst_mfma_t4<16, false, true><<<grid, block, 0, stream>>>(a);
-    } else {
-      if (dh == 32 && L == kLmax) bwd_dst_mfma_t4<32, true, false><<<grid, block, 0, stream>>>(a);
-      else if (dh == 32) bwd_dst_mfma_t4<32, false, false><<<grid, block, 0, stream>>>(a);
-      else if (L == kLmax) bwd_dst_mfma_t4<16, true, false><<<grid, block, 0, stream>>>(a);
-      else bwd_dst_mfma_t4<16, false, false><<<grid, block, 0, stream>>>(a);
-    }
+#define AMPCONV_DST_LAUNCH(DH_, FULL_)                                                                  \
+  do {                                                                                                  \
+    if (st.stats && nt4) bwd_dst_mfma_t4<DH_, FULL_, true, true><<<grid, block, 0, stream>>>(a);        \
+    else if (st.stats) bwd_dst_mfma_t4<DH_, FULL_, true, false><<<grid, block, 0, stream>>>(a);         \
+    else if (nt4) bwd_dst_mfma_t4<DH_, FULL_, false, true><<<grid, block, 0, stream>>>(a);              \
+    else bwd_dst_mfma_t4<DH_, FULL_, false, false><<<grid, block, 0, stream>>>(a);                      \
+  } while (0)
+    if (dh == 32 && L == kLmax) AMPCONV_DST_LAUNCH(32, true);
+    else if (dh == 32) AMPCONV_DST_LAUNCH(32, false);
+    else if (L == kLmax) AMPCONV_DST_LAUNCH(16, true);
+    else AMPCONV_DST_LAUNCH(16, false);
+#undef AMPCONV_DST_LAUNCH
     return ampconv_launch_status();
   }
   if (st.stats) {
@@ -1472,26 +1652,28 @@ int ampconv_bwd_edge_src_mfma(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t
   const dim3 grid((unsigned)blocks), block(64 * kWavesPerBlock);
   static const bool t4 = !(std::getenv("AMPCONV_SRC_T4") && std::getenv("AMPCONV_SRC_T4")[0] == '0');
   static const bool nt4 = !(std::getenv("AMPCONV_SRC_NT4") && std::getenv("AMPCONV_SRC_NT4")[0] == '0');
+  // developer knob: unused dynamic LDS per block, to lower the occupancy in experiments
+  static const unsigned dyn = std::getenv("AMPCONV_SRC_DYNLDS") ? (unsigned)atoi(std::getenv("AMPCONV_SRC_DYNLDS")) : 0u;
   if (st.stats && t4 && nt4 && L > 16) {       // tail columns on 4x4x1 (only if there are tail tokens)
-    if (dh == 32 && L == kLmax) bwd_src_mfma_t4<32, true, true><<<grid, block, 0, stream>>>(a);
-    else if (dh == 32) bwd_src_mfma_t4<32, false, true><<<grid, block, 0, stream>>>(a);
-    else if (L == kLmax) bwd_src_mfma_t4<16, true, true><<<grid, block, 0, stream>>>(a);
-    else bwd_src_mfma_t4<16, false, true><<<grid, block, 0, stream>>>(a);
+    if (dh == 32 && L == kLmax) bwd_src_mfma_t4<32, true, true><<<grid, block, dyn, stream>>>(a);
+    else if (dh == 32) bwd_src_mfma_t4<32, false, true><<<grid, block, dyn, stream>>>(a);
+    else if (L == kLmax) bwd_src_mfma_t4<16, true, true><<<grid, block, dyn, stream>>>(a);
+    else bwd_src_mfma_t4<16, false, true><<<grid, block, dyn, stream>>>(a);
   } else if (st.stats && t4) {
-    if (dh == 32 && L == kLmax) bwd_src_mfma_t4<32, true, false><<<grid, block, 0, stream>>>(a);
-    else if (dh == 32) bwd_src_mfma_t4<32, false, false><<<grid, block, 0, stream>>>(a);
-    else if (L == kLmax) bwd_src_mfma_t4<16, true, false><<<grid, block, 0, stream>>>(a);
-    else bwd_src_mfma_t4<16, false, false><<<grid, block, 0, stream>>>(a);
+    if (dh == 32 && L == kLmax) bwd_src_mfma_t4<32, true, false><<<grid, block, dyn, stream>>>(a);
+    else if (dh == 32) bwd_src_mfma_t4<32, false, false><<<grid, block, dyn, stream>>>(a);
+    else if (L == kLmax) bwd_src_mfma_t4<16, true, false><<<grid, block, dyn, stream>>>(a);
+    else bwd_src_mfma_t4<16, false, false><<<grid, block, dyn, stream>>>(a);
   } else if (st.stats) {
-    if (dh == 32 && L == kLmax) bwd_src_mfma<32, true, AMPCONV_PF_SRC, true><<<grid, block, 0, stream>>>(a);
-    else if (dh == 32) bwd_src_mfma<32, false, 1, true><<<grid, block, 0, stream>>>(a);
-    else if (L == kLmax) bwd_src_mfma<16, true, AMPCONV_PF_SRC, true><<<grid, block, 0, stream>>>(a);
-    else bwd_src_mfma<16, false, 1, true><<<grid, block, 0, stream>>>(a);
+    if (dh == 32 && L == kLmax) bwd_src_mfma<32, true, AMPCONV_PF_SRC, true><<<grid, block, dyn, stream>>>(a);
+    else if (dh == 32) bwd_src_mfma<32, false, 1, true><<<grid, block, dyn, stream>>>(a);
+    else if (L == kLmax) bwd_src_mfma<16, true, AMPCONV_PF_SRC, true><<<grid, block, dyn, stream>>>(a);
+    else bwd_src_mfma<16, false, 1, true><<<grid, block, dyn, stream>>>(a);
   } else {
-    if (dh == 32 && L == kLmax) bwd_src_mfma<32, true, AMPCONV_PF_SRC, false><<<grid, block, 0, stream>>>(a);
-    else if (dh == 32) bwd_src_mfma<32, false, 1, false><<<grid, block, 0, stream>>>(a);
-    else if (L == kLmax) bwd_src_mfma<16, true, AMPCONV_PF_SRC, false><<<grid, block, 0, stream>>>(a);
-    else bwd_src_mfma<16, false, 1, false><<<grid, block, 0, stream>>>(a);
+    if (dh == 32 && L == kLmax) bwd_src_mfma<32, true, AMPCONV_PF_SRC, false><<<grid, block, dyn, stream>>>(a);
+    else if (dh == 32) bwd_src_mfma<32, false, 1, false><<<grid, block, dyn, stream>>>(a);
+    else if (L == kLmax) bwd_src_mfma<16, true, AMPCONV_PF_SRC, false><<<grid, block, dyn, stream>>>(a);
+    else bwd_src_mfma<16, false, 1, false><<<grid, block, dyn, stream>>>(a);
   }
   return ampconv_launch_status();
 }

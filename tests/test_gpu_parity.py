@@ -693,3 +693,101 @@ def test_block_kernels_long_segments(shape, dev, monkeypatch):
     slow = run()
     for name, a, b in zip(['y', 'dx', 'gWin', 'gWo'], fast, slow):
         assert_close_scaled(a, b, name)
+
+
+def test_message_aggregate_gradients_match_fused(dev):
+    """The decomposed public path message() -> aggregate() (PyG's propagate by hand) must train like the
+    fused propagate(): same output, same gradients w.r.t. x and the parameters (aggregate()
+    used to return a tensor without grad_fn)."""
+    from ampnet_amd import AMPConv
+    torch.manual_seed(3)
+    N, E, L, D, H = 40, 300, 20, 128, 4
+    layer = AMPConv(D, H).to(dev)
+    with torch.no_grad():
+        layer.multi_head_attention.in_proj_bias.normal_(0, 0.1)
+        layer.multi_head_attention.out_proj.bias.normal_(0, 0.1)
+    x = torch.randn(N, L * D, device=dev)
+    dy = torch.randn(N, L * D, device=dev)
+    ei = torch.randint(0, N, (2, E), device=dev)
+    ei[1, ei[1] == 3] = 4                                      # node 3 receives nothing
+
+    xa = x.clone().requires_grad_(True)
+    ya = layer(xa, ei)
+    ya.backward(dy)
+    ga = [xa.grad.clone()] + [p.grad.clone() for p in layer.parameters()]
+    layer.zero_grad(set_to_none=True)
+
+    xb = x.clone().requires_grad_(True)
+    msg = layer.message(xb.index_select(0, ei[1]), xb.index_select(0, ei[0]))
+    yb = layer.aggregate(msg, ei[1], dim_size=N)
+    assert yb.requires_grad
+    yb.backward(dy)
+    gb = [xb.grad] + [p.grad for p in layer.parameters()]
+    assert_close_scaled(yb.detach().cpu().numpy(), ya.detach().cpu().numpy(), 'y (message+aggregate vs fused)')
+    assert (yb[3] == 0).all()
+    for name, a, b in zip(['dx', 'g_in_w', 'g_in_b', 'g_out_w', 'g_out_b'], ga, gb):
+        assert_close_scaled(b.cpu().numpy(), a.cpu().numpy(), name + ' (message+aggregate vs fused)')
+
+
+def test_retain_attention_auto(dev, monkeypatch):
+    """Default 'auto': small graphs keep what the lazy per-edge attributes need, large projection buffers are
+    dropped and reading the attributes says so instead of pinning them (61 GB at config 4)."""
+    from ampnet_amd import AMPConv
+    torch.manual_seed(4)
+    layer = AMPConv(128, 4).to(dev)
+    assert layer.retain_attention == 'auto'
+    x = torch.randn(50, 20 * 128, device=dev)
+    ei = torch.randint(0, 50, (2, 200), device=dev)
+    with torch.no_grad():
+        layer(x, ei)
+    assert layer.attn_output_weights.shape == (200, 20, 20)
+    assert layer.attn_output.shape == (200, 20, 128)
+    monkeypatch.setenv('AMPCONV_RETAIN_LIMIT_MB', '0')
+    with torch.no_grad():
+        layer(x, ei)
+    assert layer._attn_ctx is None
+    with pytest.raises(RuntimeError, match='not retained'):
+        layer.attn_output_weights
+    layer.retain_attention = True
+    with torch.no_grad():
+        layer(x, ei)
+    assert layer.attn_output_weights is not None
+    with torch.no_grad():                                     # parameters changed since forward: warn
+        layer.multi_head_attention.out_proj.bias.add_(1.0)
+    with pytest.warns(RuntimeWarning, match='out_proj'):
+        layer.attn_output
+
+
+def test_gemm_precision_is_restored(dev):
+    """A plain fp32 GEMM after a 'bf16x3' block is bit-equal to the same GEMM before it (the switches are
+    process-global; functional.gemm_precision restores them under a lock)."""
+    from ampnet_amd.conv.functional import gemm_precision
+    torch.manual_seed(6)
+    a = torch.randn(4096, 512, device=dev)
+    b = torch.randn(512, 768, device=dev)
+    before = a @ b
+    with gemm_precision('bf16x3'):
+        inside = a @ b
+    after = a @ b
+    assert torch.equal(before, after)
+    assert inside.shape == before.shape
+
+
+def test_bench_launches_two_ranks(dev):
+    """`python bench.py --gpus 2` starts its two ranks itself and reports n_gpus = 2 (gloo here: both ranks
+    share the one card of the test box; on the 8-GPU node the same path runs over RCCL)."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, AMPCONV_DIST_BACKEND='gloo')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--workload', 'tiny',
+                        '--steps', '2', '--warmup', '1', '--no-cpu-baseline', '--no-alt-gemm'], env=env, timeout=600,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['config']['parallelism'] == 'dp2' and out['value'] > 0
