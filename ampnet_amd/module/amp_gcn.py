@@ -2,10 +2,15 @@
 
 Mirrors reference src/ampnet/module/amp_gcn.py:20-118 (constructor arguments, sub-module names and
 therefore state-dict keys: feature_embedding_table, conv1, conv2, final_linear_out) and :239-276
-(forward: dropout_adj -> featurise -> conv1 -> ReLU -> conv2 -> ReLU -> token-mean-pool -> Linear
--> log_softmax).  Out of scope and not reproduced: the matplotlib/seaborn gradient and activation
-plots (:278-405) and the PCA featuriser variant (:185-237).  The per-node Python sampling loop of
-:132-149 is replaced by csrc/featurizer.hip; the random stream is this library's (seeded).
+(forward: dropout_adj -> featurise -> conv1 -> ReLU -> conv2 -> ReLU -> token pooling -> Linear
+-> log_softmax).  Both featuriser branches of :120-183 are here: down-sampling of the present features
+(:127-153, the Cora harness) and the full-width branch (:170-181, `downsample_feature_vectors=False`,
+the XOR harness of synthetic_benchmark/xor_training_utils.py:58-72); both poolings of :268-271 (token mean,
+or token 0 with `average_pooling_flag=False`).  Out of scope and not reproduced: the matplotlib/seaborn
+gradient and activation plots (:278-405) and the PCA featuriser variant (:185-237).  The per-node Python
+sampling loop of :132-149 is replaced by csrc/featurizer.hip; the random stream is this library's (seeded);
+`forward(data, feature_indices=...)` takes the indices of another stream (tests: the reference's own).
+Pinned against the reference's class by tests/golden/model_*.npz (oracle/make_golden_ampgcn.py).
 """
 import torch
 import torch.nn as nn
@@ -80,10 +85,31 @@ class FeatureTokens(nn.Module):
                                                        empty.data_ptr(), _stream()), 'ampconv_feat_sample_present')
         return idx, empty
 
+    def forward_all(self, x, feature_repeats):
+        """Full-width branch (amp_gcn.py:170-181): token f of a node = concat(tile(table, feature_repeats)[f],
+        zscore(x)[node, f]) for EVERY feature column f; no sampling (returns indices None like the reference)."""
+        if not x.is_cuda or x.dtype != torch.float32:
+            raise ValueError('FeatureTokens needs float32 node features on the GPU (no CPU fallback)')
+        x = x.contiguous()
+        reps = int(feature_repeats) if feature_repeats else 1
+        table = self.feature_embedding_table.weight
+        if reps > 1:
+            table = table.repeat(reps, 1)                       # torch.tile(weight, [feature_repeats, 1])
+        if table.size(0) != x.size(1) or x.size(1) != self.num_sampled_vectors:
+            raise ValueError(f'full-width tokens need num_node_features * feature_repeats ({table.size(0)}) == '
+                             f'x.shape[1] ({x.size(1)}) == num_sampled_vectors ({self.num_sampled_vectors}) '
+                             '(torch.cat / reshape of amp_gcn.py:174-181 raise otherwise)')
+        idx = torch.arange(x.size(1), dtype=torch.int32, device=x.device).repeat(x.size(0), 1)
+        mean, inv_std = self.zscore_stats(x)
+        tokens = _BuildTokens.apply(table.contiguous(), x, mean, inv_std, idx)
+        return tokens.view(x.size(0), -1), None
+
     def forward(self, x, idx=None):
         if not x.is_cuda or x.dtype != torch.float32:
             raise ValueError('FeatureTokens needs float32 node features on the GPU (no CPU fallback)')
         x = x.contiguous()
+        if idx is not None:
+            idx = torch.as_tensor(idx, device=x.device).to(torch.int32)
         if idx is None:
             idx, empty = self.sample(x)
             if int(empty.item()):
@@ -102,10 +128,15 @@ class AMPGCN(nn.Module):
         super().__init__()
         assert embedding_dim == feat_emb_dim + val_emb_dim, \
             "Feature and value dimensions do not add up to total embedding dimension"
-        if not downsample_feature_vectors or not average_pooling_flag or val_emb_dim != 1:
-            raise NotImplementedError('only the down-sampling / average-pooling configuration of the '
-                                      'reference harnesses is implemented')
+        if val_emb_dim != 1:
+            raise ValueError('val_emb_dim must be 1: the reference concatenates ONE z-scored value per token '
+                             '(amp_gcn.py:147,175; its reshape raises for any other value)')
         self.device = device
+        self.downsampling_vectors = downsample_feature_vectors
+        self.average_pooling_flag = average_pooling_flag
+        self.feature_repeats = feature_repeats
+        self.feat_emb_dim, self.val_emb_dim = feat_emb_dim, val_emb_dim
+        self.dropout_rate = dropout_rate
         self.emb_dim = embedding_dim
         self.num_sampled_vectors = num_sampled_vectors
         self.num_node_features = num_node_features
@@ -117,6 +148,9 @@ class AMPGCN(nn.Module):
         # same sub-module names as the reference => same state-dict keys
         self._tokens = [FeatureTokens(num_node_features, feat_emb_dim, num_sampled_vectors, seed)]
         self.feature_embedding_table = self._tokens[0].feature_embedding_table
+        if not average_pooling_flag:               # defined (and in the state dict) but never used by forward,
+            self.cls_token = nn.Parameter(torch.zeros(1, 1, self.emb_dim))    # exactly as amp_gcn.py:55-57,268-271
+            nn.init.normal_(self.cls_token, std=.02)
         self.conv1 = AMPConv(embed_dim=embedding_dim, num_heads=num_heads)
         self.drop1 = nn.Dropout(p=dropout_rate)
         self.conv2 = AMPConv(embed_dim=embedding_dim, num_heads=num_heads)
@@ -130,7 +164,10 @@ class AMPGCN(nn.Module):
         if self.training and self.dropout_adj_rate > 0:                       # dropout_adj (amp_gcn.py:241)
             keep = torch.rand(edge_index.size(1), device=edge_index.device) >= self.dropout_adj_rate
             edge_index = edge_index[:, keep]
-        x, sampled = self._tokens[0](x, feature_indices)
+        if self.downsampling_vectors:
+            x, sampled = self._tokens[0](x, feature_indices)
+        else:
+            x, sampled = self._tokens[0].forward_all(x, self.feature_repeats)
         self.sampled_node_feat_indices = sampled
         x = self.drop1(x)
         x = self.conv1(x, edge_index)
@@ -141,6 +178,7 @@ class AMPGCN(nn.Module):
         self.conv2_embedding = x
         x = F.relu(x)
         x = self.drop3(x)
-        x = x.reshape(x.shape[0], x.shape[1] // self.emb_dim, self.emb_dim).mean(dim=1)   # token average pooling
+        x = x.reshape(x.shape[0], x.shape[1] // self.emb_dim, self.emb_dim)
+        x = x.mean(dim=1) if self.average_pooling_flag else x[:, 0]      # token mean / token 0 (amp_gcn.py:268-271)
         x = self.final_linear_out(x)
         return F.log_softmax(x, dim=1) if self.softmax_out else self.act_out(x)

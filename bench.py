@@ -41,7 +41,14 @@ WORKLOADS = {
              'bf16 storage'),
     'cora': (2708, 10556, 20, 128, 4, 'BASELINE config 1/2 shape: Cora-sized random graph, L=20, D=128, H=4'),
     'tiny': (2000, 20000, 20, 256, 8, 'smoke-sized graph of the config-4 layer shape'),
+    # GraphSAINT batches (BASELINE config 4 as written): the graph and its features stay resident, every step
+    # draws one random-walk subgraph per rank (experiments/cora_benchmark_graphsaint.py:80-82,96-116)
+    'cfg4-saint': (1_000_000, 10_000_000, 20, 256, 8,
+                   'BASELINE config 4, GraphSAINT batches: resident uniform random graph 1M nodes / 10M edges, '
+                   'per step one random-walk subgraph per GPU (2000 roots x walk length 50), L=20, D=256, H=8'),
+    'tiny-saint': (20_000, 200_000, 20, 256, 8, 'smoke-sized GraphSAINT-batch run (200 roots x walk length 10)'),
 }
+SAINT = {'cfg4-saint': (2000, 50), 'tiny-saint': (200, 10)}          # (roots per batch, walk length)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_PEAK_TFLOPS = {'f32': 157.3, 'bf16': 2500.0}   # same guide: fp32-input MFMA = vector rate; dense bf16
 
@@ -197,6 +204,105 @@ def launch_ranks(n):
     sys.exit(0)
 
 
+def run_saint(args, rank, world, dev, layer, reducer, N, E, L, D, H, desc, dt_name, tdt, R):
+    """GraphSAINT-batch mode: per rank per step GraphSAINTRandomWalkSampler.sample() -> row gather of the
+    resident features -> AMPConv forward + backward on the induced subgraph -> gradient all-reduce.
+    `value` = sampled edges processed by all ranks per second; the sampler's share of the step and the
+    host read-backs it costs (sub-graph sizes, needed to size the batch's tensors) are reported."""
+    import types
+    from ampnet_amd import GraphSAINTRandomWalkSampler, graph_cache, _lib
+    roots, walk = SAINT[args.workload]
+    x, ei, _ = make_batch(N, E, L, D, 13, dev, tdt)           # the same resident graph on every rank (seed 13)
+    del _
+    sampler = GraphSAINTRandomWalkSampler(types.SimpleNamespace(edge_index=ei, num_nodes=N), batch_size=roots,
+                                          walk_length=walk, num_steps=1, seed=13 + rank, num_nodes=N)
+    n_max = roots * (walk + 1)
+    g = torch.Generator(device=dev).manual_seed(99 + rank)
+    dy_buf = torch.randn(n_max, L * D, generator=g, device=dev).to(tdt)
+
+    timer = KernelTimer()
+    timed_lib = TimedLib(_lib.load(), timer)
+    orig_load = _lib.load
+    _lib.load = lambda: timed_lib
+    ev = []
+    sizes = []
+
+    def step(timed):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        node_idx, ei_sub, _, _ = sampler.sample()
+        e1.record()
+        graph_cache.clear()
+        layer.zero_grad(set_to_none=True)
+        xs = x.index_select(0, node_idx).requires_grad_(True)
+        y = layer(xs, ei_sub)
+        y.backward(dy_buf[: xs.size(0)])
+        if world > 1:
+            reducer.allreduce()
+        if timed:
+            ev.append((e0, e1))
+            sizes.append((int(node_idx.numel()), int(ei_sub.size(1))))
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    fence()
+    dt = time.perf_counter() - t0
+    timer.enabled = False
+    _lib.load = orig_load
+    tot = torch.tensor([dt, float(sum(e for _, e in sizes)), float(sum(n for n, _ in sizes))], dtype=torch.float64,
+                       device=dev)
+    if world > 1:
+        tmax = tot[:1].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        tot[0] = tmax[0]
+    dt, edges_all, nodes_all = (float(v) for v in tot.tolist())
+    if rank != 0:
+        return
+    ms = timer.summary()
+    n_avg = sum(n for n, _ in sizes) / len(sizes)
+    e_avg = sum(e for _, e in sizes) / len(sizes)
+    alg = {'ampconv_fwd_edge': (2 * e_avg + 2 * n_avg) * R, 'ampconv_bwd_edge_dst': (2 * e_avg + 3 * n_avg) * R,
+           'ampconv_bwd_edge_src': (2 * e_avg + 4 * n_avg) * R}
+    dom = max(ms, key=ms.get)
+    achieved = alg[dom] / (ms[dom] * 1e-3) / 1e9
+    sampler_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
+    flops = 14 * L * L * D * e_avg + 24 * L * D * D * n_avg
+    t_step = dt / args.steps
+    out = {
+        'metric': 'AMPConv edges/sec (fwd+bwd), GraphSAINT subgraph batches', 'value': edges_all / dt, 'unit': 'edges/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * t_step,
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': dt_name, 'data': 'synthetic',
+        'config': {'workload': f'{args.workload}: {desc}; sampler + feature-row gather + one AMPConv layer fwd+bwd incl. CSR '
+                               f'build of the subgraph' + (' + RCCL grad all-reduce' if world > 1 else ''),
+                   'N': N, 'E': E, 'L': L, 'D': D, 'H': H, 'roots': roots, 'walk_length': walk,
+                   'parallelism': f'dp{world}', 'gemm': args.gemm if dt_name == 'f32' else 'bf16'},
+        'batch': {'nodes_avg': n_avg, 'edges_avg': e_avg, 'sampler_ms': sampler_ms,
+                  'sampler_share_of_step': sampler_ms / (1e3 * t_step),
+                  'host_readbacks_per_batch': 'sampler: sub-graph node and edge counts (2), CSR build: bounds flag + '
+                                              'long-segment chunk counts (1); all inside the timed step'},
+        'layer_flops': {'per_step': flops, 'achieved_TFLOPs_per_gpu': flops / t_step / 1e12,
+                        'peak_TFLOPs': MFMA_PEAK_TFLOPS[dt_name],
+                        'frac_of_peak': flops / t_step / 1e12 / MFMA_PEAK_TFLOPS[dt_name]},
+        'kernels_ms': ms,
+        'roofline': {'kernel': dom, 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                     'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'algorithmic_bytes_per_launch': alg[dom],
+                     'avg_launch_ms': ms[dom]},
+    }
+    print(json.dumps(out), flush=True)
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -251,6 +357,13 @@ def main():
     if world > 1:
         broadcast_parameters(layer, src=0)
     reducer = GradientAllReducer(layer.parameters())
+
+    if args.workload in SAINT:
+        run_saint(args, rank, world, dev, layer, reducer, N, E, L, D, H, desc, dt_name, tdt, R)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     x, ei, dy = make_batch(N, E, L, D, 1234 + rank, dev, tdt, rmat=args.workload == 'cfg5')   # own graph per rank
     x.requires_grad_(True)

@@ -25,8 +25,14 @@ def golden_files(two_layer=False, linear=False):
     """Fixtures written by oracle/make_golden.py.  linear=True: the softmax-free variant
     (linear_*.npz, from the reference's custom_multihead_attn.py)."""
     fs = sorted(glob.glob(os.path.join(GOLDEN_DIR, '*.npz')))
+    fs = [f for f in fs if not os.path.basename(f).startswith('model_')]      # whole-model fixtures: model_files()
     fs = [f for f in fs if os.path.basename(f).startswith('linear_') == linear]
     return [f for f in fs if ('2layer' in os.path.basename(f)) == two_layer]
+
+
+def model_files():
+    """Whole-model fixtures written by oracle/make_golden_ampgcn.py from the reference's AMPGCN."""
+    return sorted(glob.glob(os.path.join(GOLDEN_DIR, 'model_*.npz')))
 
 
 def load_golden(path):

@@ -120,3 +120,47 @@ def test_harness_learns_on_synthetic_cora():
         sys.argv = argv
     assert history[-1][0] < history[0][0]
     assert acc > 0.4
+
+
+# ---- the whole model against the REFERENCE's own AMPGCN outputs (tests/golden/model_*.npz, written by
+# oracle/make_golden_ampgcn.py from src/ampnet/module/amp_gcn.py loaded by file path): Cora harness
+# configuration with the reference's sampled feature indices, XOR configuration (full-width featuriser),
+# token-0 pooling.  fp32 tolerance of SURVEY 8c.
+def _cfg_value(v):
+    if v in ('True', 'False'):
+        return v == 'True'
+    if v == 'None':
+        return None
+    try:
+        return int(v)
+    except ValueError:
+        return float(v)
+
+
+@pytest.mark.parametrize('path', __import__('conftest').model_files(),
+                         ids=[__import__('os').path.basename(p)[:-4] for p in __import__('conftest').model_files()])
+def test_model_matches_reference_fixture(path):
+    from conftest import load_golden, assert_close_scaled
+    from ampnet_amd import AMPGCN
+    g = load_golden(path)
+    cfg = {k: _cfg_value(v) for k, v in zip(g['cfg_keys'].tolist(), g['cfg_vals'].tolist())}
+    dev = torch.device('cuda:0')
+    model = AMPGCN(device=dev, **cfg).to(dev)
+    state = {k[len('param.'):]: torch.from_numpy(v) for k, v in g.items() if k.startswith('param.')}
+    model.load_state_dict(state)                              # the reference's state dict loads by key
+    model.train()
+    data = types.SimpleNamespace(x=torch.from_numpy(g['x']).to(dev), edge_index=torch.from_numpy(g['edge_index']).to(dev))
+    idx = g.get('sampled_node_feat_indices')
+    logits = model(data, feature_indices=None if idx is None else torch.from_numpy(idx).to(dev))
+    (logits * torch.from_numpy(g['dlogits']).to(dev)).sum().backward()
+    assert_close_scaled(logits.detach().cpu().numpy(), g['logits'], 'logits')
+    assert_close_scaled(model.conv1_embedding.detach().cpu().numpy(), g['conv1_embedding'], 'conv1_embedding')
+    assert_close_scaled(model.conv2_embedding.detach().cpu().numpy(), g['conv2_embedding'], 'conv2_embedding')
+    if idx is None:
+        assert model.sampled_node_feat_indices is None
+    for name, p in model.named_parameters():
+        key = 'grad.' + name
+        if key in g:
+            assert_close_scaled(p.grad.cpu().numpy(), g[key], key)
+        else:
+            assert p.grad is None, name                       # cls_token: defined, never used (amp_gcn.py:55-57)

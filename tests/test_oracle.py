@@ -124,3 +124,31 @@ def test_numpy_oracle_two_layer(path):
     assert_close_scaled(dW2, g['l2_g_in_proj_weight'], 'l2_g_in_proj_weight')
     assert_close_scaled(dbo1, g['l1_g_out_proj_bias'], 'l1_g_out_proj_bias')
     assert_close_scaled(dWo2, g['l2_g_out_proj_weight'], 'l2_g_out_proj_weight')
+
+
+# ---- whole-model fixtures generated FROM the reference's AMPGCN (oracle/make_golden_ampgcn.py) pin the
+# numpy restatement of the model (featuriser branches, poolings) on the CPU
+def _model_cfg(g):
+    return dict(zip(g['cfg_keys'].tolist(), g['cfg_vals'].tolist()))
+
+
+@pytest.mark.parametrize('path', __import__('conftest').model_files(),
+                         ids=[os.path.basename(p)[:-4] for p in __import__('conftest').model_files()])
+def test_ampgcn_oracle_matches_reference_model(path):
+    from conftest import load_golden, assert_close_scaled
+    from oracle.ampgcn_numpy import AMPGCNOracle
+    g = load_golden(path)
+    cfg = _model_cfg(g)
+    state = {k[len('param.'):]: v for k, v in g.items() if k.startswith('param.')}
+    reps = cfg['feature_repeats']
+    o = AMPGCNOracle(state, int(cfg['num_heads']), average_pooling=cfg['average_pooling_flag'] == 'True',
+                     feature_repeats=1 if reps == 'None' else int(reps))
+    logits = o.forward(g['x'], g['edge_index'], g.get('sampled_node_feat_indices'))
+    assert_close_scaled(logits, g['logits'], 'logits')
+    assert_close_scaled(o.e1, g['conv1_embedding'], 'conv1_embedding')
+    assert_close_scaled(o.e2, g['conv2_embedding'], 'conv2_embedding')
+    grads = o.backward(g['dlogits'])
+    for k, v in grads.items():
+        assert_close_scaled(v, g['grad.' + k], 'grad ' + k)
+    if cfg['average_pooling_flag'] == 'False':
+        assert 'param.cls_token' in g and 'grad.cls_token' not in g      # defined, never used (amp_gcn.py:55-57)

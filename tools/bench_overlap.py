@@ -1,0 +1,84 @@
+"""Developer experiment: do the fp32 projection GEMMs (matrix-pipe bound) and the edge kernels (HBM /
+latency bound, matrix pipe ~50 % busy) overlap when issued on two HIP streams?
+
+    python tools/bench_overlap.py [N E]
+Times (a) the two backward edge passes alone, (b) a set of GEMMs alone, (c) both concurrently."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+from ampnet_amd import _lib, EdgeCSR  # noqa: E402
+from ampnet_amd.conv import functional as F_  # noqa: E402
+
+
+def main():
+    args = [a for a in sys.argv[1:] if not a.startswith('--')]
+    N, E = (int(args[0]), int(args[1])) if len(args) == 2 else (100000, 1000000)
+    L, D, H = 20, 256, 8
+    dev = torch.device('cuda:0')
+    lib = _lib.load()
+    dh = D // H
+    torch.manual_seed(0)
+    qkv = torch.randn(N * L, 3 * D, device=dev)
+    dobar = torch.randn(N * L, D, device=dev)
+    x = torch.randn(N * L, D, device=dev)
+    w = torch.randn(D, D, device=dev)
+    ei = torch.randint(0, N, (2, E), device=dev)
+    csr = EdgeCSR(ei, N)
+    Qv, Kv, Vv = (F_._view(qkv, i * D, L, dh) for i in range(3))
+    dqkv = torch.empty(N * L, 3 * D, device=dev)
+    dQv, dKv, dVv = (F_._view(dqkv, i * D, L, dh) for i in range(3))
+    dOv = F_._view(dobar, 0, L, dh)
+    nstat = lib.ampconv_softmax_stats_bytes(E, L, D, H, 0)
+    stats = torch.empty(nstat // 4, device=dev)
+    spos = csr.csc_positions()
+    side = torch.cuda.Stream()
+    out1 = torch.empty(N * L, D, device=dev)
+
+    def edges():
+        st = torch.cuda.current_stream().cuda_stream
+        _lib.check(lib.ampconv_bwd_edge_dst(Qv, Kv, Vv, dOv, csr.rowptr.data_ptr(), csr.col.data_ptr(), N, L, D, H, dQv,
+                                            None, 0, None, spos.data_ptr(), stats.data_ptr(), 0, st), 'dst')
+        _lib.check(lib.ampconv_bwd_edge_src(Qv, Kv, Vv, dOv, csr.cscptr.data_ptr(), csr.crow.data_ptr(),
+                                            csr.cinv.data_ptr(), N, L, D, H, dKv, dVv, None, 0, None, stats.data_ptr(), 0,
+                                            st), 'src')
+
+    def gemms(k):
+        for _ in range(k):
+            torch.mm(x, w, out=out1)                 # [N L, D] x [D, D]: 2 N L D^2 flop each
+
+    def timed(fn, iters=5):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters
+
+    flop = 2 * N * L * D * D
+    t_e = timed(edges)
+    for k in (2, 4, 6):
+        t_g = timed(lambda: gemms(k))
+
+        def both():
+            cur = torch.cuda.current_stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                gemms(k)
+            edges()
+            cur.wait_stream(side)
+        t_b = timed(both)
+        print(f'N={N} E={E}: edge passes {t_e:.2f} ms | {k} GEMMs {t_g:.2f} ms ({k * flop / t_g / 1e9:.0f} TFLOP/s) | '
+              f'concurrent {t_b:.2f} ms (serial sum {t_e + t_g:.2f}, saved {t_e + t_g - t_b:.2f} ms = '
+              f'{100 * (t_e + t_g - t_b) / min(t_e, t_g):.0f} % of the shorter)')
+
+
+if __name__ == '__main__':
+    main()
