@@ -126,6 +126,10 @@ class AMPConvFunction(torch.autograd.Function):
             dtype = _lib.AMPCONV_BF16
             if w_in.dtype != torch.bfloat16:
                 raise ValueError('bf16 inputs need bf16 parameters: call layer.to(torch.bfloat16)')
+            if dh != 32 or L > 20:
+                raise ValueError(f'bf16 storage is implemented for head dimension 32 and at most 20 tokens per node '
+                                 f'(csrc/edge_mfma_bf16.hip; BASELINE config 5); got head dimension {dh}, {L} tokens: '
+                                 'use float32 for this shape')
         Nq, Nk = xq.size(0), xkv.size(0)
         xq2 = xq.contiguous().view(Nq * L, D)
         with torch.cuda.device(xq.device), gemm_precision(gemm):
@@ -207,15 +211,12 @@ class AMPConvFunction(torch.autograd.Function):
             _lib.check(rc, 'ampconv_bwd_edge_src')
             # in_proj_bias gradient without a pass over all of dQKV: softmax rows sum to 1, so the
             # column sum of dV over every source token equals the column sum of dObar over the rows
-            # that receive messages (the same masked sum as db_out), and the K bias shifts every
-            # score of a row equally, i.e. has gradient exactly 0 (torch's autograd returns ~1e-9 noise)
+            # that receive messages, and dObar = dY Wo is linear in dY, so that sum is (masked column sum of
+            # dY) Wo = db_out Wo: a [D] x [D, D] product instead of a second 20 GB reduction pass.  The K bias
+            # shifts every score of a row equally, i.e. has gradient exactly 0 (torch's autograd returns ~1e-9 noise)
             db_v = None
             if shared and dy2.dtype == torch.float32:
-                scratch_v = torch.empty_like(scratch)          # `scratch` still backs db_out
-                rc = lib.ampconv_masked_colsum(dobar.data_ptr(), csr.rowptr.data_ptr(), Nq, L, D,
-                                               scratch_v.data_ptr(), io, _stream())
-                _lib.check(rc, 'ampconv_masked_colsum')
-                db_v = scratch_v[:D]
+                db_v = scratch[:D] @ w_out
             del dobar, stats
             if shared:
                 dw_in = _tn_matmul(dqkv, xq2)

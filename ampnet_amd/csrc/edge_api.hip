@@ -76,7 +76,10 @@ extern "C" int ampconv_fwd_edge(ampconv_view_t Q, ampconv_view_t K, ampconv_view
     return ampconv_fwd_edge_bf16(Q, K, V, rowptr, col, qidx, n_rows, L, D, H, O, HubArgs{nullptr, 0}, st);
   }
   if (!force_generic() && ampconv_mfma_supported(L, D, H) && ampconv_mfma_views_ok(views, 4)) {
-    if (const int np = split_products(dtype, L, D, H))
+    // the split-operand kernels have no long-segment (hub) pass: with a plan the native fp32 kernels run
+    // (exact fp32 as well) instead of one wave walking a hub's whole segment
+    const bool hubs = hub_plan && hub_chunks > 0 && hub_ws && !qidx;
+    if (const int np = hubs ? 0 : split_products(dtype, L, D, H))
       return ampconv_fwd_edge_split(np, Q, K, V, rowptr, col, qidx, n_rows, L, D, H, O,
                                     (hipStream_t)stream);
     if (hub_plan && hub_chunks > 0 && hub_ws && !qidx) {      // long segments: main + hub + combine
@@ -154,7 +157,8 @@ extern "C" int ampconv_bwd_edge_dst(ampconv_view_t Q, ampconv_view_t K, ampconv_
     return ampconv_bwd_edge_dst_bf16(Q, K, V, dObar, rowptr, col, n_rows, L, D, H, dQ, HubArgs{nullptr, 0}, st);
   }
   if (!force_generic() && ampconv_mfma_supported(L, D, H) && ampconv_mfma_views_ok(views, 5)) {
-    if (const int np = split_products(dtype, L, D, H))
+    const bool hubs = hub_plan && hub_chunks > 0 && hub_ws;      // see ampconv_fwd_edge
+    if (const int np = hubs ? 0 : split_products(dtype, L, D, H))
       return stats ? AMPCONV_E_BADARG : ampconv_bwd_edge_dst_split(np, Q, K, V, dObar, rowptr, col, n_rows, L, D, H, dQ,
                                         (hipStream_t)stream);
     if (hub_plan && hub_chunks > 0 && hub_ws) {
@@ -230,7 +234,8 @@ extern "C" int ampconv_bwd_edge_src(ampconv_view_t Q, ampconv_view_t K, ampconv_
                                      HubArgs{nullptr, 0}, st);
   }
   if (!force_generic() && ampconv_mfma_supported(L, D, H) && ampconv_mfma_views_ok(views, 6)) {
-    if (const int np = split_products(dtype, L, D, H))
+    const bool hubs = hub_plan && hub_chunks > 0 && hub_ws;      // see ampconv_fwd_edge
+    if (const int np = hubs ? 0 : split_products(dtype, L, D, H))
       return stats ? AMPCONV_E_BADARG : ampconv_bwd_edge_src_split(np, Q, K, V, dObar, cscptr, crow, cinv, n_src, L, D, H,
                                         dK, dV, (hipStream_t)stream);
     if (hub_plan && hub_chunks > 0 && hub_ws) {

@@ -33,6 +33,9 @@ constexpr int kWavesPerBlock = AMPCONV_WPB;
 #ifndef AMPCONV_PF_SRC
 #define AMPCONV_PF_SRC 1
 #endif
+#ifndef AMPCONV_PF_DST_T4
+#define AMPCONV_PF_DST_T4 1      // main tiles in flight per wave in bwd_dst_mfma_t4 (1 or 2; 2 needs AMPCONV_DST_WAVES=2)
+#endif
 #ifndef AMPCONV_DST_WAVES
 #define AMPCONV_DST_WAVES 3      // waves per SIMD the destination pass is compiled for (168 registers; 2 = 256)
 #endif
@@ -1310,7 +1313,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? AMPCONV_DST_WAVES :
     o2 = idxwin_get<STATS>(win, a.idx, wts, p_ + 2 < end ? p_ + 2 : end - 1, end, lane, &s2);           \
     o3 = idxwin_get<STATS>(win, a.idx, wts, p_ + 3 < end ? p_ + 3 : end - 1, end, lane, &s3);           \
   } while (0)
-  MainRegs<DH> ring;
+  // main tiles of the next PF edges in flight (ring slot = e % PF).  The ordering argument for the LDS-DMA
+  // of the tail images below holds for PF = 2 as well: the DMA of batch b + 1 goes out in phase 0 of the FULL
+  // batch b ahead of that phase's staged loads, and phase 2 waits for exactly those loads.
+  constexpr int PF = DH == 32 ? AMPCONV_PF_DST_T4 : 1;
+  MainRegs<DH> ring[PF];
   int cur = 0;
   if (beg < end) {
     idxwin_load<STATS>(win, a.idx, wts, beg, end, lane);
@@ -1318,8 +1325,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? AMPCONV_DST_WAVES :
     __builtin_amdgcn_wave_barrier();
     tail_dma<DH, FULL>(tails, a.K, h, id0, id1, id2, id3, L, lane);
     tail_dma<DH, FULL>(tails + kImg, a.V, h, id0, id1, id2, id3, L, lane);
-    main_load<DH, FULL>(ring, tile_ptr<const float>(a.K, id0, h), a.K.row_stride,
+    main_load<DH, FULL>(ring[0], tile_ptr<const float>(a.K, id0, h), a.K.row_stride,
                         tile_ptr<const float>(a.V, id0, h), a.V.row_stride, L, lane);
+    if (PF == 2 && beg + 1 < end)
+      main_load<DH, FULL>(ring[PF - 1], tile_ptr<const float>(a.K, id1, h), a.K.row_stride,
+                          tile_ptr<const float>(a.V, id1, h), a.V.row_stride, L, lane);
   }
 
   for (int p0 = beg; p0 < end; p0 += 4) {
@@ -1379,17 +1389,18 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? AMPCONV_DST_WAVES :
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       if (p0 + e >= end) break;
-      main_to_lds<DH, FULL>(Kt, ring, L, lane);
+      main_to_lds<DH, FULL>(Kt, ring[e % PF], L, lane);
       if (e == 0 && more) {          // next batch's tail rows -> the other pair of images; issued BEFORE
         float *Knext = tails + 2 * (cur ^ 1) * kImg;   // this phase's staged loads, so that the wait for
         tail_dma<DH, FULL>(Knext, a.K, h, nid0, nid1, nid2, nid3, L, lane);           // those (next phase)
         tail_dma<DH, FULL>(Knext + kImg, a.V, h, nid0, nid1, nid2, nid3, L, lane);    // does not stall on them
       }
       {
-        const bool has_next = e < 3 ? p0 + e + 1 < end : more;
-        const int next = e == 0 ? id1 : e == 1 ? id2 : e == 2 ? id3 : nid0;
+        const bool has_next = p0 + e + PF < end;
+        const int next = PF == 1 ? (e == 0 ? id1 : e == 1 ? id2 : e == 2 ? id3 : nid0)
+                                 : (e == 0 ? id2 : e == 1 ? id3 : e == 2 ? nid0 : nid1);
         if (has_next)
-          main_load<DH, FULL>(ring, tile_ptr<const float>(a.K, next, h), a.K.row_stride,
+          main_load<DH, FULL>(ring[e % PF], tile_ptr<const float>(a.K, next, h), a.K.row_stride,
                               tile_ptr<const float>(a.V, next, h), a.V.row_stride, L, lane);
       }
       __builtin_amdgcn_wave_barrier();

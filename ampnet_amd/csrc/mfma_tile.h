@@ -42,9 +42,12 @@ struct TileCfg {
 
 // XOR swizzle of the 16-byte chunk index inside a token row (conflict-free ds_write_b128,
 // row-operand ds_read_b128 and column-operand ds_read_b32; see tools/lds_layout_check.py)
+// Bit 2 takes row bits 2 ^ 3 so that the four rows 4 sg + x (sg = 0..3) of a 4x4x1 phase-2 read land on four
+// different chunk pairs (nt_accumulate: lanes (g, sg, rr) read row 4 sg + x, chunk 4 hf + g -- 2-way conflicts
+// with bit 2 = row bit 2 alone); the other access patterns keep their cost (tools/lds_layout_check.py).
 template <int DH>
 __device__ __forceinline__ int swz(int j) {
-  return ((((j >> 2) & 1) << 2) | ((j >> 1) & 3)) & (DH / 4 - 1);
+  return (((((j >> 2) ^ (j >> 3)) & 1) << 2) | ((j >> 1) & 3)) & (DH / 4 - 1);
 }
 template <int DH>
 __device__ __forceinline__ int lds_idx(int j, int c) {

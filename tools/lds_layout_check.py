@@ -92,6 +92,7 @@ if __name__ == '__main__':
         for stride in range(DH, DH + 17, 4):
             for name, f in [('none', lambda j: 0),
                             ('f1', lambda j: ((((j >> 2) & 1) << 2) | ((j >> 1) & 3)) % (DH // 4)),
+                            ('f1x', lambda j: (((((j >> 2) ^ (j >> 3)) & 1) << 2) | ((j >> 1) & 3)) % (DH // 4)),   # swz<DH> since round 2
                             ('f2', lambda j: (j >> 1) % (DH // 4)),
                             ('f3', lambda j: (j >> 2) % (DH // 4)),
                             ('f4', lambda j: j % (DH // 4)),
