@@ -75,6 +75,27 @@ class NodePartition:
             dist.all_reduce(out, op=dist.ReduceOp.SUM, group=self.group)
         return out
 
+    # ---- the same two collectives, started asynchronously: `wait()` on the returned handle before the result is
+    # used.  With RCCL the collective runs on the communicator's own stream (xGMI links + a few CUs), so the dense
+    # GEMMs issued between start and wait overlap it; gloo (tests) completes inside the call.
+    class _Done:
+        def wait(self):
+            return True
+
+    def all_gather_rows_start(self, t):
+        t = t.contiguous()
+        if self.world == 1 or not self.native:
+            return self.all_gather_rows(t), self._Done()
+        out = torch.empty(self.world * t.size(0), t.size(1), dtype=t.dtype, device=t.device)
+        return out, dist.all_gather_into_tensor(out, t, group=self.group, async_op=True)
+
+    def reduce_scatter_rows_start(self, t):
+        t = t.contiguous()
+        if self.world == 1 or not self.native:
+            return self.reduce_scatter_rows(t), self._Done()
+        out = torch.empty(t.size(0) // self.world, t.size(1), dtype=t.dtype, device=t.device)
+        return out, dist.reduce_scatter_tensor(out, t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
     def reduce_scatter_rows(self, t):
         """[world * rows, C] partial sums per rank -> [rows, C]: the sum over ranks of this rank's slice."""
         t = t.contiguous()
@@ -101,8 +122,12 @@ class _PartitionedFunction(torch.autograd.Function):
         dev = x_local.device
         x2 = x_local.contiguous().view(nl * L, D)
         with torch.cuda.device(dev):
-            qkv = torch.addmm(b_in, x2, w_in.t())                       # local rows, [nl*L, 3D]
-            kv_all = part.all_gather_rows(qkv[:, D:])                   # every node's K|V, [NP*L, 2D]
+            # K|V of the local rows first, their all-gather in flight while the Q projection runs
+            kv_loc = torch.addmm(b_in[D:], x2, w_in[D:].t())            # [nl*L, 2D]
+            kv_all, work = part.all_gather_rows_start(kv_loc)           # every node's K|V, [NP*L, 2D]
+            qkv = torch.addmm(b_in[:D], x2, w_in[:D].t())               # Q of the local rows, [nl*L, D]
+            work.wait()
+            del kv_loc
             Qv = F_._view(qkv, 0, L, dh)
             Kv, Vv = F_._view(kv_all, 0, L, dh), F_._view(kv_all, D, L, dh)
             obar = torch.empty(nl * L, D, dtype=x_local.dtype, device=dev)
@@ -133,9 +158,9 @@ class _PartitionedFunction(torch.autograd.Function):
             dobar = dy2.mm(w_out)
             Qv, dOv = F_._view(qkv, 0, L, dh), F_._view(dobar, 0, L, dh)
             Kv, Vv = F_._view(kv_all, 0, L, dh), F_._view(kv_all, D, L, dh)
-            dqkv = torch.empty(nl * L, 3 * D, dtype=torch.float32, device=dev)
+            dq = torch.empty(nl * L, D, dtype=torch.float32, device=dev)
             dkv_all = torch.empty(NP * L, 2 * D, dtype=torch.float32, device=dev)     # partial sums, all sources
-            dQv = F_._view(dqkv, 0, L, dh)
+            dQv = F_._view(dq, 0, L, dh)
             dKv, dVv = F_._view(dkv_all, 0, L, dh), F_._view(dkv_all, D, L, dh)
             stats = spos = None
             nstat = lib.ampconv_softmax_stats_bytes(csr.num_edges, L, D, H, ctx.dtype) if F_.SOFTMAX_STATS else 0
@@ -153,11 +178,17 @@ class _PartitionedFunction(torch.autograd.Function):
                                           F_._ptr(stats), ctx.dtype, _stream())
             _lib.check(rc, 'ampconv_bwd_edge_src')
             del dobar, stats
-            dqkv[:, D:] = part.reduce_scatter_rows(dkv_all)              # this rank's rows of dK|dV, summed
+            # this rank's rows of dK|dV, summed over ranks: in flight while the Q-side products run
+            dkv, work = part.reduce_scatter_rows_start(dkv_all)
+            dw_q = F_._tn_matmul(dq, x2)
+            db_q = dq.sum(dim=0)
+            dx = dq.mm(w_in[:D]) if ctx.needs_input_grad[0] else None
+            work.wait()
             del dkv_all
-            dw_in = F_._tn_matmul(dqkv, x2)
-            db_in = dqkv.sum(dim=0)
-            dx = dqkv.mm(w_in).view(nl, L * D) if ctx.needs_input_grad[0] else None
+            dw_in = torch.cat([dw_q, F_._tn_matmul(dkv, x2)], dim=0)
+            db_in = torch.cat([db_q, dkv.sum(dim=0)])
+            if dx is not None:
+                dx = dx.addmm_(dkv, w_in[D:]).view(nl, L * D)
         return dx, dw_in, db_in, dw_out, db_out, None, None, None, None
 
 

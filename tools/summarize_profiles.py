@@ -1,6 +1,6 @@
 """Turn the rocprofv3 CSVs of a profiled `bench.py` run into the summaries kept under profiles/.
 
-    python tools/summarize_profiles.py gpurun_out/prof2 r01
+    python tools/summarize_profiles.py gpurun_out/prof_r02 r02      (directory written by tools/run_profiles.sh)
 
 expects <dir>/stats_kernel_stats.csv (--kernel-trace --stats), <dir>/fetch_counter_collection.csv
 (--pmc FETCH_SIZE) and <dir>/write_counter_collection.csv (--pmc WRITE_SIZE), each with the bench log
@@ -53,7 +53,7 @@ def main():
     ms = b['kernels_ms']
     with open(os.path.join(out, f'{tag}_cfg4_kernel_stats.md'), 'w') as f:
         f.write(f'# rocprofv3 --kernel-trace --stats ({tag}, final code of the round)\n\n')
-        f.write('Command (on the MI355X box): `rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof2 '
+        f.write(f'Command (on the MI355X box, tools/run_profiles.sh): `rocprofv3 --kernel-trace --stats --output-format csv -d {d} '
                 '-o stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt-gemm`\n\n')
         f.write(f"Workload {cfg['workload'].split(':')[0]} (N={cfg['N']}, E={cfg['E']}, L={cfg['L']}, D={cfg['D']}, "
                 f"H={cfg['H']}, fp32), 3 steps recorded (1 warm-up + 2 timed).\n")
@@ -86,7 +86,7 @@ def main():
     json.dump(js, open(os.path.join(out, 'pmc_traffic.json'), 'w'), indent=1)
     with open(os.path.join(out, f'{tag}_cfg4_pmc_traffic.md'), 'w') as f:
         f.write(f'# rocprofv3 PMC HBM traffic ({tag}, final code), cfg4 (1M nodes / 10M edges, L=20, D=256, H=8)\n\n')
-        f.write('Commands: `rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/prof2 -o fetch -- '
+        f.write(f'Commands: `rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d {d} -o fetch -- '
                 'python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-alt-gemm` and the same with `--pmc WRITE_SIZE '
                 '-o write` (separate passes: TCC slots).\n\nUnits: counter values are KiB; FETCH_SIZE is doubled (gfx950 '
                 'counts 128-B requests of wide coalesced reads as 64 B, MI355X_MICROARCH.md "HBM").  "statistics" = the '
@@ -95,6 +95,42 @@ def main():
         f.write('| kernel | FETCH_SIZE KiB (raw) | WRITE_SIZE KiB | HBM bytes per launch (2*fetch + write) | algorithmic '
                 'bytes per launch | statistics | traffic / (algorithmic + statistics) |\n|---|---|---|---|---|---|---|\n')
         f.writelines(lines)
+    # cfg5 (RMAT, bf16 storage) kernel stats of the same session, if present
+    c5 = os.path.join(d, 'cfg5_kernel_stats.csv')
+    if os.path.exists(c5):
+        b5 = bench_line(os.path.join(d, 'bench_cfg5.log'))
+        shutil.copy(c5, os.path.join(out, f'{tag}_cfg5_kernel_stats.csv'))
+        rows5 = list(csv.DictReader(open(c5)))
+        with open(os.path.join(out, f'{tag}_cfg5_kernel_stats.md'), 'w') as f:
+            f.write(f'# rocprofv3 --kernel-trace --stats, cfg5 ({tag}, final code of the round)\n\n')
+            f.write(f'Command: `rocprofv3 --kernel-trace --stats --output-format csv -d {d} -o cfg5 -- python3 bench.py '
+                    '--workload cfg5 --steps 2 --warmup 1 --no-cpu-baseline`\n\n')
+            c = b5['config']
+            k5 = b5['kernels_ms']
+            f.write(f"Workload {c['workload'].split(',')[0]} (N={c['N']}, E={c['E']}, L={c['L']}, D={c['D']}, H={c['H']}, bf16 "
+                    f"storage), 3 steps recorded.  Bench line of this profiled run: {b5['value'] / 1e6:.2f} M edges/s, "
+                    f"{b5['ms_per_step']:.1f} ms/step; HIP-event averages per C-ABI call (main + long-segment pass + combine): "
+                    f"fwd {k5['ampconv_fwd_edge']:.1f} / bwd_dst {k5['ampconv_bwd_edge_dst']:.1f} / bwd_src "
+                    f"{k5['ampconv_bwd_edge_src']:.1f} ms.\n\n")
+            f.write('| kernel | calls | avg ms | total ms | % |\n|---|---|---|---|---|\n')
+            for r in rows5[:22]:
+                f.write(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['AverageNs']) / 1e6:.3f} | "
+                        f"{float(r['TotalDurationNs']) / 1e6:.1f} | {r['Percentage']} |\n")
+    sq = os.path.join(d, 'sq_summary.txt')
+    if os.path.exists(sq):
+        with open(os.path.join(out, f'{tag}_sq_counters.md'), 'w') as f:
+            f.write(f'# SQ counters of the edge kernels ({tag}; tools/prof_sq.sh + tools/summarize_sq2.py)\n\n')
+            f.write('Two `rocprofv3 --pmc ... --kernel-trace` passes over `tools/bench_kernels.py` (100 k nodes / 1 M edges, L=20, '
+                    'D=256, H=8, fp32): `SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU '
+                    'SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE` and `SQ_WAVE_CYCLES '
+                    'SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_VALU_MFMA_COEXEC_CYCLES '
+                    'SQ_ACTIVE_INST_VMEM GRBM_GUI_ACTIVE`.  Fractions are of SQ_WAVE_CYCLES; mfma_busy = '
+                    'SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (duration x clock), clock = GRBM_GUI_ACTIVE / 8 / duration.  '
+                    f'`{tag}_final` = the kernels as shipped (fixed-side tail tokens on v_mfma_f32_4x4x1), `{tag}_nt4off` = the '
+                    'same build with AMPCONV_FWD_NT4=0 AMPCONV_DST_NT4=0 AMPCONV_SRC_NT4=0 (all products on 16x16x4, the '
+                    'round-1 tiling).  Profiled runs are a few % slower than un-profiled ones.\n\n```\n')
+            f.write(open(sq).read())
+            f.write('```\n')
 
 
 if __name__ == '__main__':
