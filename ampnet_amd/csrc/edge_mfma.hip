@@ -40,10 +40,10 @@ constexpr int kWavesPerBlock = AMPCONV_WPB;
 #define AMPCONV_DST_WAVES 3      // waves per SIMD the destination pass is compiled for (168 registers; 2 = 256)
 #endif
 #ifndef AMPCONV_FWD_WAVES
-#define AMPCONV_FWD_WAVES 3      // waves per SIMD the forward pass is compiled for (168 registers; 4 = 128)
+#define AMPCONV_FWD_WAVES 4      // waves per SIMD the forward pass is compiled for (128 registers; 3 = 168): 7.5 vs 8.1 ms
 #endif
 #ifndef AMPCONV_PF_FWD_T4
-#define AMPCONV_PF_FWD_T4 2      // main tiles in flight per wave in fwd_mfma_t4 (1 or 2)
+#define AMPCONV_PF_FWD_T4 1      // main tiles in flight per wave in fwd_mfma_t4 (1 or 2; 2 needs AMPCONV_FWD_WAVES=3)
 #endif
 #ifndef AMPCONV_PF_SRC_T4
 #define AMPCONV_PF_SRC_T4 2      // edges in flight per wave in bwd_src_mfma_t4 (1, 2 or 4); 2 and 4 need AMPCONV_SRC_WAVES=2
@@ -553,9 +553,12 @@ __global__ LB_SRC void bwd_src_mfma(BwdArgs a) {
 //
 // LDS per wave: the two 16-row main images (rows 16..19 of the 20-row images stay unused) and a
 // stash [4 edges][Q | dO][4 tokens][DH]; stash row rho = 8 e + 4 isG + t, chunk swizzle swz_tail.
+// the stash swizzles like a 16-row image whose row 4 e + t is (edge e, token 16 + t): conflict-free for the row / column /
+// 4x4x1 operand reads (round 1's function had 2-way conflicts on the first two) and the same chunk-bit-2 rule as the main
+// images, which nt_accumulate / nt_fix_halves rely on
 template <int DH>
 __device__ __forceinline__ int swz_tail(int rho) {
-  return DH == 32 ? ((((rho >> 3) & 3) << 1) | ((rho >> 1) & 1)) : ((rho >> 3) & 3);
+  return swz<DH>(4 * (rho >> 3) + (rho & 3));
 }
 template <int DH>
 __device__ __forceinline__ int tail_idx(int rho, int c) {
@@ -780,8 +783,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? AMPCONV_SRC_WAVES :
         }
       }
       if constexpr (NT4) {
-        nt_accumulate<DH, false>(dV4, Gt, nt_main, pT);
-        nt_accumulate<DH, false>(dK4, Qt, nt_main, dsT);
+        nt_accumulate<DH>(dV4, Gt, nt_main, pT);
+        nt_accumulate<DH>(dK4, Qt, nt_main, dsT);
       }
       __builtin_amdgcn_wave_barrier();
     }
@@ -854,8 +857,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? AMPCONV_SRC_WAVES :
         }
       }
       if constexpr (NT4) {      // tail-tile row 4 sg + x = (edge sg, token 16 + x): stash row 8 sg + 4 isG + x
-        nt_accumulate<DH, true>(dV4, stash + 4 * DH, nt_stash, pT);
-        nt_accumulate<DH, true>(dK4, stash, nt_stash, dsT);
+        nt_accumulate<DH>(dV4, stash + 4 * DH, nt_stash, pT);
+        nt_accumulate<DH>(dK4, stash, nt_stash, dsT);
       }
       __builtin_amdgcn_wave_barrier();
     }
@@ -877,6 +880,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? AMPCONV_SRC_WAVES :
     }
   }
   if constexpr (NT4) {          // the four sg partial sums of every block column, then one quad stores
+    nt_fix_halves<DH>(dK4, lane);
+    nt_fix_halves<DH>(dV4, lane);
 #pragma unroll
     for (int hf = 0; hf < C::MC; ++hf) {
       float4 k4, v4;
@@ -1157,7 +1162,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, AMPCONV_FWD_WAVES) void fwd_mf
           for (int nt = 0; nt < NTM; ++nt) OT[mc][nt] = MFMA16(vA, S[nt][q], OT[mc][nt]);
         }
       }
-      if constexpr (NT4) nt_accumulate<DH, false>(O4, Vt, nt_base, pz);
+      if constexpr (NT4) nt_accumulate<DH>(O4, Vt, nt_base, pz);
       __builtin_amdgcn_wave_barrier();
     }
 
@@ -1178,7 +1183,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, AMPCONV_FWD_WAVES) void fwd_mf
         for (int nt = 0; nt < NTM; ++nt) OT[mc][nt] = MFMA16(vA, St[nt][q], OT[mc][nt]);
       }
     }
-    if constexpr (NT4) nt_accumulate<DH, false>(O4, Vtail, nt_base, PtT);   // row 4 sg + x = (edge sg, token 16 + x)
+    if constexpr (NT4) nt_accumulate<DH>(O4, Vtail, nt_base, PtT);   // row 4 sg + x = (edge sg, token 16 + x)
     __builtin_amdgcn_wave_barrier();
     id0 = nid0; id1 = nid1; id2 = nid2; id3 = nid3;
   }
@@ -1199,6 +1204,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, AMPCONV_FWD_WAVES) void fwd_mf
     }
   }
   if constexpr (NT4) {          // the four sg partial sums of every block column, then one quad stores
+    nt_fix_halves<DH>(O4, lane);
 #pragma unroll
     for (int hf = 0; hf < C::MC; ++hf) {
       float4 o;
@@ -1493,7 +1499,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? AMPCONV_DST_WAVES :
           }
         }
         DsT = mineT ? pt * (dzt - delta) : DsT;                 // dS^T of edge e's tail rows
-        nt_accumulate<DH, false>(dQ4, Kt, nt_base, pz * (dz - delta));
+        nt_accumulate<DH>(dQ4, Kt, nt_base, pz * (dz - delta));
       }
       __builtin_amdgcn_wave_barrier();
     }
@@ -1514,7 +1520,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? AMPCONV_DST_WAVES :
         for (int nt = 0; nt < NTM; ++nt) dQT[mc][nt] = MFMA16(kC, dPt[nt][q], dQT[mc][nt]);
       }
     }
-    if constexpr (NT4) nt_accumulate<DH, false>(dQ4, Ktail, nt_base, DsT);   // row 4 sg + x = (edge sg, token 16 + x)
+    if constexpr (NT4) nt_accumulate<DH>(dQ4, Ktail, nt_base, DsT);   // row 4 sg + x = (edge sg, token 16 + x)
     __builtin_amdgcn_wave_barrier();
     id0 = nid0; id1 = nid1; id2 = nid2; id3 = nid3;
     sp0 = nsp0; sp1 = nsp1; sp2 = nsp2; sp3 = nsp3;
@@ -1536,6 +1542,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? AMPCONV_DST_WAVES :
     }
   }
   if constexpr (NT4) {          // the four sg partial sums of every block column, then one quad stores
+    nt_fix_halves<DH>(dQ4, lane);
 #pragma unroll
     for (int hf = 0; hf < C::MC; ++hf) {
       float4 o;
