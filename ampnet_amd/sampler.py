@@ -51,18 +51,23 @@ class GraphSAINTRandomWalkSampler:
         return self.num_steps
 
     # -- visualize_graphsaint_subgraphs.py:195-199 + :107-110
-    def sample(self):
-        """One sub-graph: (node_idx [n_sub] sorted, edge_index [2, e_sub] relabelled, edge_id [e_sub])."""
+    def sample(self, walks=None):
+        """One sub-graph: (node_idx [n_sub] sorted, edge_index [2, e_sub] relabelled, edge_id [e_sub], walks).
+        `walks` ([n_walks, walk_length + 1] int64 on the device): replay given walks instead of drawing new ones
+        (tests/test_gpu_sampler.py replays the walks of the reference-generated fixture)."""
         lib, dev, st = self._lib, self.device, _stream
         csr = self.csr
         with torch.cuda.device(dev):
-            start = torch.randint(0, self.N, (self.batch_size,), generator=self._gen, device=dev)
-            walks = torch.empty(self.batch_size, self.walk_length + 1, dtype=torch.int64, device=dev)
-            self._draw += 1
-            _lib.check(lib.ampconv_saint_random_walk(csr.cscptr.data_ptr(), csr.crow.data_ptr(), start.data_ptr(),
-                                                     self.batch_size, self.walk_length,
-                                                     (self._seed * 1000003 + self._draw) & (2 ** 64 - 1),
-                                                     walks.data_ptr(), st()), 'ampconv_saint_random_walk')
+            if walks is not None:
+                walks = walks.to(device=dev, dtype=torch.int64).contiguous()
+            else:
+                start = torch.randint(0, self.N, (self.batch_size,), generator=self._gen, device=dev)
+                walks = torch.empty(self.batch_size, self.walk_length + 1, dtype=torch.int64, device=dev)
+                self._draw += 1
+                _lib.check(lib.ampconv_saint_random_walk(csr.cscptr.data_ptr(), csr.crow.data_ptr(), start.data_ptr(),
+                                                         self.batch_size, self.walk_length,
+                                                         (self._seed * 1000003 + self._draw) & (2 ** 64 - 1),
+                                                         walks.data_ptr(), st()), 'ampconv_saint_random_walk')
             _lib.check(lib.ampconv_saint_nodes(walks.data_ptr(), walks.numel(), self.N, self._mark.data_ptr(),
                                                self._relabel.data_ptr(), self._node_buf.data_ptr(),
                                                self._cnt2.data_ptr(), self._ws.data_ptr(), self._ws.numel(), st()),
@@ -112,15 +117,18 @@ class GraphSAINTRandomWalkSampler:
             yield self._collate(node_idx, edge_index, edge_id)
 
     # -- visualize_graphsaint_subgraphs.py:137-173
-    def _compute_norm(self):
+    def _compute_norm(self, walks=None):
+        """node_norm / edge_norm from repeated sampling (visualize_graphsaint_subgraphs.py:137-173).
+        `walks`: an iterable of walk tensors to replay, in drawing order (tests)."""
         lib, dev = self._lib, self.device
+        replay = iter(walks) if walks is not None else None
         node_count = torch.zeros(self.N, dtype=torch.float32, device=dev)
         edge_count = torch.zeros(max(self.E, 1), dtype=torch.float32, device=dev)
         num_samples = total = 0
         with torch.cuda.device(dev):
             while total < self.N * self.sample_coverage:
                 for _ in range(self.num_steps):
-                    node_idx, _, edge_id, _ = self.sample()
+                    node_idx, _, edge_id, _ = self.sample(next(replay) if replay is not None else None)
                     _lib.check(lib.ampconv_saint_add_counts(node_idx.data_ptr(), node_idx.numel(),
                                                             node_count.data_ptr(), _stream()), 'add_counts')
                     _lib.check(lib.ampconv_saint_add_counts(edge_id.data_ptr(), edge_id.numel(),

@@ -25,7 +25,7 @@ def golden_files(two_layer=False, linear=False):
     """Fixtures written by oracle/make_golden.py.  linear=True: the softmax-free variant
     (linear_*.npz, from the reference's custom_multihead_attn.py)."""
     fs = sorted(glob.glob(os.path.join(GOLDEN_DIR, '*.npz')))
-    fs = [f for f in fs if not os.path.basename(f).startswith('model_')]      # whole-model fixtures: model_files()
+    fs = [f for f in fs if not os.path.basename(f).startswith(('model_', 'sampler_'))]   # model_files(), sampler fixtures
     fs = [f for f in fs if os.path.basename(f).startswith('linear_') == linear]
     return [f for f in fs if ('2layer' in os.path.basename(f)) == two_layer]
 

@@ -109,3 +109,40 @@ def test_sampler_feeds_the_layer(graph):
         loss = (out.pow(2).mean(dim=1) * b.node_norm).sum()
         loss.backward()
     assert torch.isfinite(layer.multi_head_attention.in_proj_weight.grad).all()
+
+
+def test_replay_of_reference_sampler_fixture():
+    """tests/golden/sampler_rw.npz was produced by the reference's own vendored GraphSAINT classes
+    (visualization/visualize_graphsaint_subgraphs.py:13-203, executed unmodified by oracle/make_golden_sampler.py over
+    stand-ins for torch_sparse / PyG Data).  Replaying its walks through the GPU sampler must give the same node sets,
+    induced edges, subset attributes and -- from the same sampling sequence -- the same node_norm / edge_norm."""
+    import os
+    from conftest import GOLDEN_DIR, load_golden
+    from ampnet_amd.sampler import GraphSAINTRandomWalkSampler
+    g = load_golden(os.path.join(GOLDEN_DIR, 'sampler_rw.npz'))
+    dev = torch.device('cuda:0')
+    ei, N = g['edge_index'], int(g['N'])
+    E = ei.shape[1]
+    data = types.SimpleNamespace(edge_index=torch.from_numpy(ei).to(dev), num_nodes=N,
+                                 x=(torch.arange(N, dtype=torch.float32).view(N, 1) * 2.0).to(dev),
+                                 y=(torch.arange(N) % 7).to(dev),
+                                 edge_attr=(torch.arange(E, dtype=torch.float32) + 0.5).to(dev))
+    s = GraphSAINTRandomWalkSampler(data, batch_size=int(g['batch_size']), walk_length=int(g['walk_length']),
+                                    num_steps=int(g['num_steps']), sample_coverage=0, seed=1, num_nodes=N)
+    s.sample_coverage = int(g['sample_coverage'])
+    s.node_norm, s.edge_norm = s._compute_norm(walks=[torch.from_numpy(w) for w in g['norm_walks']])
+    assert s.num_samples == len(g['norm_walks'])                              # the reference's stopping rule
+    np.testing.assert_allclose(s.node_norm.cpu().numpy(), g['node_norm'], rtol=1e-6)
+    np.testing.assert_allclose(s.edge_norm.cpu().numpy(), g['edge_norm'], rtol=1e-6)
+    for i, w in enumerate(g['epoch_walks']):
+        node_idx, edge_index, edge_id, _ = s.sample(walks=torch.from_numpy(w))
+        b = s._collate(node_idx, edge_index, edge_id)
+        assert b.num_nodes == int(g[f'b{i}_num_nodes'])
+        np.testing.assert_array_equal(b.x.cpu().numpy(), g[f'b{i}_x'])
+        np.testing.assert_array_equal(b.y.cpu().numpy(), g[f'b{i}_y'])
+        np.testing.assert_allclose(b.node_norm.cpu().numpy(), g[f'b{i}_node_norm'], rtol=1e-6)
+        want = sorted(zip(g[f'b{i}_edge_index'][0].tolist(), g[f'b{i}_edge_index'][1].tolist(),
+                          g[f'b{i}_edge_attr'].tolist(), np.round(g[f'b{i}_edge_norm'], 5).tolist()))
+        got = sorted(zip(b.edge_index[0].tolist(), b.edge_index[1].tolist(), b.edge_attr.tolist(),
+                         np.round(b.edge_norm.cpu().numpy(), 5).tolist()))
+        assert got == want

@@ -152,3 +152,36 @@ def test_ampgcn_oracle_matches_reference_model(path):
         assert_close_scaled(v, g['grad.' + k], 'grad ' + k)
     if cfg['average_pooling_flag'] == 'False':
         assert 'param.cls_token' in g and 'grad.cls_token' not in g      # defined, never used (amp_gcn.py:55-57)
+
+
+# ---- sampler fixture generated by the reference's vendored GraphSAINT classes (oracle/make_golden_sampler.py):
+# pins the numpy restatement of the deterministic parts (induced subgraph, attribute subsetting, norms)
+def test_graphsaint_restatement_matches_reference_sampler():
+    from conftest import GOLDEN_DIR, load_golden
+    from oracle import graphsaint_numpy as gs
+    g = load_golden(os.path.join(GOLDEN_DIR, 'sampler_rw.npz'))
+    ei, N = g['edge_index'], int(g['N'])
+    E = ei.shape[1]
+    # norms: replay the samples __compute_norm__ drew
+    node_count, edge_count = np.zeros(N, np.float32), np.zeros(E, np.float32)
+    for w in g['norm_walks']:
+        assert gs.walk_is_valid(ei, N, w)
+        node_idx, _, keep = gs.induced_subgraph(ei, N, w)
+        node_count[node_idx] += 1
+        edge_count[keep] += 1
+    assert node_count.sum() >= N * int(g['sample_coverage'])                 # the reference's stopping rule
+    num_samples = len(g['norm_walks'])
+    node_norm, edge_norm = gs.norms(node_count, edge_count, ei[0], N, num_samples)
+    np.testing.assert_allclose(node_norm, g['node_norm'], rtol=1e-6)
+    np.testing.assert_allclose(edge_norm, g['edge_norm'], rtol=1e-6)
+    # batches: same node sets, same induced edges (as multisets of (row, col, edge id))
+    x = np.arange(N, dtype=np.float32).reshape(N, 1) * 2.0
+    attr = np.arange(E, dtype=np.float32) + 0.5
+    for i, w in enumerate(g['epoch_walks']):
+        node_idx, e_sub, keep = gs.induced_subgraph(ei, N, w)
+        assert node_idx.size == int(g[f'b{i}_num_nodes'])
+        np.testing.assert_array_equal(x[node_idx], g[f'b{i}_x'])
+        np.testing.assert_allclose(node_norm[node_idx], g[f'b{i}_node_norm'], rtol=1e-6)
+        want = sorted(zip(g[f'b{i}_edge_index'][0].tolist(), g[f'b{i}_edge_index'][1].tolist(), g[f'b{i}_edge_attr'].tolist()))
+        got = sorted(zip(e_sub[0].tolist(), e_sub[1].tolist(), attr[keep].tolist()))
+        assert got == want
