@@ -791,3 +791,28 @@ def test_bench_launches_two_ranks(dev):
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     assert out['n_gpus'] == 2 and out['config']['parallelism'] == 'dp2' and out['value'] > 0
+
+
+def test_split_precision_on_hub_graph_uses_hub_plan(dev):
+    """precision='bf16x9' has no long-segment pass of its own: with hubs in the graph the C ABI runs the native fp32
+    kernels with the plan (it used to walk a hub's whole segment on one wave).  Same results as 'exact'."""
+    from ampnet_amd import AMPConv, graph_cache
+    torch.manual_seed(8)
+    N, E, L, D, H = 400, 6000, 20, 256, 8
+    layer = AMPConv(D, H).to(dev)
+    x = torch.randn(N, L * D, device=dev)
+    dy = torch.randn(N, L * D, device=dev)
+    ei = torch.randint(0, N, (2, E), device=dev)
+    ei[1, :1500] = 7                                         # 1500-in-edge hub
+    ei[0, 1500:2600] = 9                                     # 1100-out-edge hub
+    outs = {}
+    for mode in ('exact', 'bf16x9'):
+        graph_cache.clear()
+        layer.precision = mode
+        layer.zero_grad(set_to_none=True)
+        xg = x.clone().requires_grad_(True)
+        y = layer(xg, ei)
+        y.backward(dy)
+        outs[mode] = (y.detach(), xg.grad, layer.multi_head_attention.in_proj_weight.grad.clone())
+    for a, b in zip(outs['exact'], outs['bf16x9']):
+        assert torch.equal(a, b), 'a hub graph in a split-precision mode must take the native long-segment path'
