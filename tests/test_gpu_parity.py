@@ -795,7 +795,8 @@ def test_bench_launches_two_ranks(dev):
 
 def test_split_precision_on_hub_graph_uses_hub_plan(dev):
     """precision='bf16x9' has no long-segment pass of its own: with hubs in the graph the C ABI runs the native fp32
-    kernels with the plan (it used to walk a hub's whole segment on one wave).  Same results as 'exact'."""
+    kernels with the plan (it used to walk a hub's whole segment on one wave).  fp32-grade agreement with 'exact'
+    (the statistics hand-off is off in the split modes, so the summation order differs)."""
     from ampnet_amd import AMPConv, graph_cache
     torch.manual_seed(8)
     N, E, L, D, H = 400, 6000, 20, 256, 8
@@ -814,5 +815,4 @@ def test_split_precision_on_hub_graph_uses_hub_plan(dev):
         y = layer(xg, ei)
         y.backward(dy)
         outs[mode] = (y.detach(), xg.grad, layer.multi_head_attention.in_proj_weight.grad.clone())
-    for a, b in zip(outs['exact'], outs['bf16x9']):
-        assert torch.equal(a, b), 'a hub graph in a split-precision mode must take the native long-segment path'
+XX
