@@ -33,6 +33,17 @@ constexpr int kWavesPerBlock = AMPCONV_WPB;
 #ifndef AMPCONV_PF_SRC
 #define AMPCONV_PF_SRC 1
 #endif
+// addressing of the 4x4x1 phase-2 reads (mfma_tile.h, nt_accumulate): physical channel halves (fewer address registers,
+// 2-way LDS bank conflicts) or logical halves (conflict-free)
+#ifndef AMPCONV_NT_PHYS_FWD
+#define AMPCONV_NT_PHYS_FWD true     // keeps the forward pass at 128 registers = 4 waves per SIMD (1 spill instead of 7)
+#endif
+#ifndef AMPCONV_NT_PHYS_DST
+#define AMPCONV_NT_PHYS_DST false
+#endif
+#ifndef AMPCONV_NT_PHYS_SRC
+#define AMPCONV_NT_PHYS_SRC false
+#endif
 #ifndef AMPCONV_PF_DST_T4
 #define AMPCONV_PF_DST_T4 1      // main tiles in flight per wave in bwd_dst_mfma_t4 (1 or 2; 2 needs AMPCONV_DST_WAVES=2)
 #endif
@@ -555,7 +566,7 @@ __global__ LB_SRC void bwd_src_mfma(BwdArgs a) {
 // stash [4 edges][Q | dO][4 tokens][DH]; stash row rho = 8 e + 4 isG + t, chunk swizzle swz_tail.
 // the stash swizzles like a 16-row image whose row 4 e + t is (edge e, token 16 + t): conflict-free for the row / column /
 // 4x4x1 operand reads (round 1's function had 2-way conflicts on the first two) and the same chunk-bit-2 rule as the main
-// images, which nt_accumulate / nt_fix_halves rely on
+// images, which nt_accumulate relies on
 template <int DH>
 __device__ __forceinline__ int swz_tail(int rho) {
   return swz<DH>(4 * (rho >> 3) + (rho & 3));
@@ -783,8 +794,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? AMPCONV_SRC_WAVES :
         }
       }
       if constexpr (NT4) {
-        nt_accumulate<DH>(dV4, Gt, nt_main, pT);
-        nt_accumulate<DH>(dK4, Qt, nt_main, dsT);
+        nt_accumulate<DH, AMPCONV_NT_PHYS_SRC>(dV4, Gt, nt_main, pT);
+        nt_accumulate<DH, AMPCONV_NT_PHYS_SRC>(dK4, Qt, nt_main, dsT);
       }
       __builtin_amdgcn_wave_barrier();
     }
@@ -857,8 +868,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? AMPCONV_SRC_WAVES :
         }
       }
       if constexpr (NT4) {      // tail-tile row 4 sg + x = (edge sg, token 16 + x): stash row 8 sg + 4 isG + x
-        nt_accumulate<DH>(dV4, stash + 4 * DH, nt_stash, pT);
-        nt_accumulate<DH>(dK4, stash, nt_stash, dsT);
+        nt_accumulate<DH, AMPCONV_NT_PHYS_SRC>(dV4, stash + 4 * DH, nt_stash, pT);
+        nt_accumulate<DH, AMPCONV_NT_PHYS_SRC>(dK4, stash, nt_stash, dsT);
       }
       __builtin_amdgcn_wave_barrier();
     }
@@ -880,8 +891,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? AMPCONV_SRC_WAVES :
     }
   }
   if constexpr (NT4) {          // the four sg partial sums of every block column, then one quad stores
-    nt_fix_halves<DH>(dK4, lane);
-    nt_fix_halves<DH>(dV4, lane);
+    nt_fix_halves<DH, AMPCONV_NT_PHYS_SRC>(dK4, lane);
+    nt_fix_halves<DH, AMPCONV_NT_PHYS_SRC>(dV4, lane);
 #pragma unroll
     for (int hf = 0; hf < C::MC; ++hf) {
       float4 k4, v4;
@@ -1162,7 +1173,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, AMPCONV_FWD_WAVES) void fwd_mf
           for (int nt = 0; nt < NTM; ++nt) OT[mc][nt] = MFMA16(vA, S[nt][q], OT[mc][nt]);
         }
       }
-      if constexpr (NT4) nt_accumulate<DH>(O4, Vt, nt_base, pz);
+      if constexpr (NT4) nt_accumulate<DH, AMPCONV_NT_PHYS_FWD>(O4, Vt, nt_base, pz);
       __builtin_amdgcn_wave_barrier();
     }
 
@@ -1183,7 +1194,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, AMPCONV_FWD_WAVES) void fwd_mf
         for (int nt = 0; nt < NTM; ++nt) OT[mc][nt] = MFMA16(vA, St[nt][q], OT[mc][nt]);
       }
     }
-    if constexpr (NT4) nt_accumulate<DH>(O4, Vtail, nt_base, PtT);   // row 4 sg + x = (edge sg, token 16 + x)
+    if constexpr (NT4) nt_accumulate<DH, AMPCONV_NT_PHYS_FWD>(O4, Vtail, nt_base, PtT);   // row 4 sg + x = (edge sg, token 16 + x)
     __builtin_amdgcn_wave_barrier();
     id0 = nid0; id1 = nid1; id2 = nid2; id3 = nid3;
   }
@@ -1204,7 +1215,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, AMPCONV_FWD_WAVES) void fwd_mf
     }
   }
   if constexpr (NT4) {          // the four sg partial sums of every block column, then one quad stores
-    nt_fix_halves<DH>(O4, lane);
+    nt_fix_halves<DH, AMPCONV_NT_PHYS_FWD>(O4, lane);
 #pragma unroll
     for (int hf = 0; hf < C::MC; ++hf) {
       float4 o;
@@ -1499,7 +1510,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? AMPCONV_DST_WAVES :
           }
         }
         DsT = mineT ? pt * (dzt - delta) : DsT;                 // dS^T of edge e's tail rows
-        nt_accumulate<DH>(dQ4, Kt, nt_base, pz * (dz - delta));
+        nt_accumulate<DH, AMPCONV_NT_PHYS_DST>(dQ4, Kt, nt_base, pz * (dz - delta));
       }
       __builtin_amdgcn_wave_barrier();
     }
@@ -1520,7 +1531,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? AMPCONV_DST_WAVES :
         for (int nt = 0; nt < NTM; ++nt) dQT[mc][nt] = MFMA16(kC, dPt[nt][q], dQT[mc][nt]);
       }
     }
-    if constexpr (NT4) nt_accumulate<DH>(dQ4, Ktail, nt_base, DsT);   // row 4 sg + x = (edge sg, token 16 + x)
+    if constexpr (NT4) nt_accumulate<DH, AMPCONV_NT_PHYS_DST>(dQ4, Ktail, nt_base, DsT);   // row 4 sg + x = (edge sg, token 16 + x)
     __builtin_amdgcn_wave_barrier();
     id0 = nid0; id1 = nid1; id2 = nid2; id3 = nid3;
     sp0 = nsp0; sp1 = nsp1; sp2 = nsp2; sp3 = nsp3;
@@ -1542,7 +1553,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? AMPCONV_DST_WAVES :
     }
   }
   if constexpr (NT4) {          // the four sg partial sums of every block column, then one quad stores
-    nt_fix_halves<DH>(dQ4, lane);
+    nt_fix_halves<DH, AMPCONV_NT_PHYS_DST>(dQ4, lane);
 #pragma unroll
     for (int hf = 0; hf < C::MC; ++hf) {
       float4 o;

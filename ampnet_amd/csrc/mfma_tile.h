@@ -312,34 +312,36 @@ __device__ __forceinline__ float reduce_transpose(const f32x4 &x) {
   return y01 + y23;
 }
 
-// phase 2 over one 16-row image: block (g, sg), reg rr, lane j accumulates image[4 sg + x][channel][...] z[row 4 sg + x][j]
-// for channel = 16 h + 4 g + rr.  `base` = this lane's float index of image[4 sg][4 g + rr] (lds_idx / tail_idx).
-// Address arithmetic kept out of the loop: the row step x is an ADD of x * DH (bits the base leaves zero -> folds into
-// the ds_read offset); the XOR swizzle takes row bit 1 (= x >> 1) into chunk bit 0 -> two variants of the address
-// register; and instruction p reads the PHYSICAL channel half p (another immediate, + 16 floats): because the swizzle
-// flips chunk bit 2 for the rows of quads with nt_flip(sg), such a lane's acc[p] belongs to the LOGICAL half p ^ 1 --
-// nt_fix_halves swaps the two accumulators of those lanes once per unit, before the quads are summed.
-// (DH = 16: one half, chunk bits 0..1 only.)
+// phase 2 over one 16-row image: acc[hf] (block (g, sg), reg rr, lane j) += image[4 sg + x][16 hf + 4 g + rr] z[row 4 sg + x][j].
+// `base` = this lane's float index of image[4 sg][4 g + rr] (lds_idx / tail_idx).  Address arithmetic kept out of the
+// loop: the row step x is an ADD of x * DH (bits the base leaves zero: it folds into the ds_read offset); the XOR
+// swizzle takes row bit 1 (= x >> 1) into chunk bit 0 and the channel half hf flips chunk bit 2.
+//   PHYS = false: four variants of the address register per image, conflict-free reads.
+//   PHYS = true : instruction p reads the PHYSICAL half p (one more immediate, two address variants): because the
+//     swizzle flips chunk bit 2 for the rows of the quads with nt_flip(sg), such a lane's acc[p] belongs to the LOGICAL
+//     half p ^ 1 and nt_fix_halves swaps the two accumulators of those lanes once per unit.  Chunk bit 2 then no longer
+//     differs between the quads: every read is a 2-way bank conflict (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
+//     0.00 -> 0.18) -- worth it only where the saved registers keep a wave per SIMD (the forward pass at 128).
 __device__ __forceinline__ bool nt_flip(int lane) {            // chunk bit 2 of swz<32>(4 sg + x): row bits 2 ^ 3 = sg bits 0 ^ 1
   const int sg = (lane >> 2) & 3;
   return ((sg ^ (sg >> 1)) & 1) != 0;
 }
-template <int DH>
+template <int DH, bool PHYS>
 __device__ __forceinline__ void nt_accumulate(f32x4 (&acc)[TileCfg<DH>::MC], const float *img, int base, float z) {
-  const int b0 = DH == 32 ? (base & ~16) : base;              // physical half 0
-  const int b1 = b0 ^ 4;                                      // rows with bit 1 set (x = 2, 3)
+  const int b0 = (PHYS && DH == 32) ? (base & ~16) : base;
 #pragma unroll
   for (int x = 0; x < 4; ++x) {
 #pragma unroll
-    for (int p = 0; p < TileCfg<DH>::MC; ++p) {
-      const float a = img[((x >> 1) ? b1 : b0) + x * DH + 16 * p];
-      acc[p] = mfma4_rows(a, z, acc[p], x);
+    for (int hf = 0; hf < TileCfg<DH>::MC; ++hf) {
+      const int idx = PHYS ? (b0 ^ ((x >> 1) << 2)) + x * DH + 16 * hf
+                           : (base ^ (((x >> 1) << 2) | (hf << 4))) + x * DH;
+      acc[hf] = mfma4_rows(img[idx], z, acc[hf], x);
     }
   }
 }
-template <int DH>
+template <int DH, bool PHYS>
 __device__ __forceinline__ void nt_fix_halves(f32x4 (&acc)[TileCfg<DH>::MC], int lane) {
-  if constexpr (TileCfg<DH>::MC == 2) {
+  if constexpr (PHYS && TileCfg<DH>::MC == 2) {
     const bool f = nt_flip(lane);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {

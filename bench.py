@@ -393,13 +393,20 @@ def main():
         step()
     fence()
     timer.enabled = True
+    step_events = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
         step()
+        e1.record()
+        step_events.append((e0, e1))
     fence()
     dt = time.perf_counter() - t0
     timer.enabled = False
     _lib.load = orig_load
+    step_ms = sorted(a.elapsed_time(b) for a, b in step_events)
+    median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
@@ -471,7 +478,9 @@ def main():
                             'binding': 'mfma' if t_mfma > t_hbm else 'hbm'},
             'kernels_ms': ms,
             'timing': 'value = wall clock over the K steps between barrier+synchronize fences, max over ranks '
-                      '(the contract); kernels_ms = mean HIP-event duration per launch over the same steps',
+                      '(the contract); kernels_ms = mean HIP-event duration per launch over the same steps; '
+                      'ms_per_step_hip_events_median = median of per-step HIP-event durations on rank 0 (SURVEY 8d protocol)',
+            'ms_per_step_hip_events_median': median_ms,
             'roofline': {'kernel': dom, 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'algorithmic_bytes_per_launch': alg[dom], 'avg_launch_ms': ms[dom]},

@@ -815,4 +815,5 @@ def test_split_precision_on_hub_graph_uses_hub_plan(dev):
         y = layer(xg, ei)
         y.backward(dy)
         outs[mode] = (y.detach(), xg.grad, layer.multi_head_attention.in_proj_weight.grad.clone())
-XX
+    for name, a, b in zip(('y', 'dx', 'g_in_proj_weight'), outs['exact'], outs['bf16x9']):
+        assert_close_scaled(b.cpu().numpy(), a.cpu().numpy(), name + ' (bf16x9 with hubs vs exact)')
