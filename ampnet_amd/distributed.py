@@ -55,10 +55,9 @@ class GradientAllReducer:
             else:
                 flat[off:off + n].copy_(p.grad.reshape(-1))
             off += n
-        if world > 1:
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-            if average:
-                flat.mul_(1.0 / world)
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)      # also as the only rank: the same code path
+        if average and world > 1:
+            flat.mul_(1.0 / world)
         off = 0
         for p in self.params:                       # unpack
             n = p.numel()

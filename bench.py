@@ -204,7 +204,7 @@ def launch_ranks(n):
     sys.exit(0)
 
 
-def run_saint(args, rank, world, dev, layer, reducer, N, E, L, D, H, desc, dt_name, tdt, R):
+def run_saint(args, rank, world, dev, layer, reducer, N, E, L, D, H, desc, dt_name, tdt, R, dist_on):
     """GraphSAINT-batch mode: per rank per step GraphSAINTRandomWalkSampler.sample() -> row gather of the
     resident features -> AMPConv forward + backward on the induced subgraph -> gradient all-reduce.
     `value` = sampled edges processed by all ranks per second; the sampler's share of the step and the
@@ -237,7 +237,7 @@ def run_saint(args, rank, world, dev, layer, reducer, N, E, L, D, H, desc, dt_na
         xs = x.index_select(0, node_idx).requires_grad_(True)
         y = layer(xs, ei_sub)
         y.backward(dy_buf[: xs.size(0)])
-        if world > 1:
+        if dist_on:
             reducer.allreduce()
         if timed:
             ev.append((e0, e1))
@@ -245,7 +245,7 @@ def run_saint(args, rank, world, dev, layer, reducer, N, E, L, D, H, desc, dt_na
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -262,7 +262,7 @@ def run_saint(args, rank, world, dev, layer, reducer, N, E, L, D, H, desc, dt_na
     _lib.load = orig_load
     tot = torch.tensor([dt, float(sum(e for _, e in sizes)), float(sum(n for n, _ in sizes))], dtype=torch.float64,
                        device=dev)
-    if world > 1:
+    if dist_on:
         tmax = tot[:1].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
@@ -334,8 +334,14 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', 0)) % n_dev     # gloo rehearsal: ranks may share a card
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    # AMPCONV_BENCH_FORCE_DIST=1: join a process group even as the only rank, so that a one-GPU box executes the RCCL
+    # code path of the N-rank run (init with device_id, parameter broadcast, gradient all-reduce, barriers)
+    dist_on = world > 1 or os.environ.get('AMPCONV_BENCH_FORCE_DIST') == '1'
+    if dist_on:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group(backend, **({'device_id': dev} if backend == 'nccl' else {}))
 
     from ampnet_amd import AMPConv, graph_cache, _lib
@@ -354,13 +360,13 @@ def main():
         layer.multi_head_attention.in_proj_bias.normal_(0, 0.1)
         layer.multi_head_attention.out_proj.bias.normal_(0, 0.1)
     layer = layer.to(tdt)
-    if world > 1:
+    if dist_on:
         broadcast_parameters(layer, src=0)
     reducer = GradientAllReducer(layer.parameters())
 
     if args.workload in SAINT:
-        run_saint(args, rank, world, dev, layer, reducer, N, E, L, D, H, desc, dt_name, tdt, R)
-        if world > 1:
+        run_saint(args, rank, world, dev, layer, reducer, N, E, L, D, H, desc, dt_name, tdt, R, dist_on)
+        if dist_on:
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -380,12 +386,12 @@ def main():
         x.grad = None
         y = layer(x, ei)
         y.backward(dy)
-        if world > 1:
+        if dist_on:
             reducer.allreduce()
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -409,7 +415,7 @@ def main():
     median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if dist_on:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
@@ -492,7 +498,7 @@ def main():
             torch.cuda.empty_cache()
             out['cpu_baseline'] = cpu_baseline(L, D, H, E / N)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist_on:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -817,3 +817,23 @@ def test_split_precision_on_hub_graph_uses_hub_plan(dev):
         outs[mode] = (y.detach(), xg.grad, layer.multi_head_attention.in_proj_weight.grad.clone())
     for name, a, b in zip(('y', 'dx', 'g_in_proj_weight'), outs['exact'], outs['bf16x9']):
         assert_close_scaled(b.cpu().numpy(), a.cpu().numpy(), name + ' (bf16x9 with hubs vs exact)')
+
+
+def test_bench_rccl_path_single_rank(dev):
+    """The N-rank run's RCCL code path (nccl process group with device_id, parameter broadcast, gradient all-reduce,
+    barriers, MAX reduction of the time) executed by ONE rank on the one GPU of the test box -- two ranks cannot share
+    a card under RCCL, so this is as much of the `--gpus N` path as a single GPU can run."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, AMPCONV_BENCH_FORCE_DIST='1', AMPCONV_DIST_BACKEND='nccl', HSA_ENABLE_IPC_MODE_LEGACY='0',
+               MASTER_ADDR='127.0.0.1', MASTER_PORT='29533')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--workload', 'tiny', '--steps', '2', '--warmup', '1',
+                        '--no-cpu-baseline', '--no-alt-gemm'], env=env, timeout=600, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
+    assert out['n_gpus'] == 1 and out['value'] > 0

@@ -88,3 +88,37 @@ def test_node_partition_bookkeeping():
     assert torch.equal(part.local_edges(ei), ei)
     x = torch.arange(20.).view(10, 2)
     assert torch.equal(part.local_rows(x), x)
+
+
+def test_rccl_collectives_single_rank():
+    """The RCCL calls of the partitioned layer (`all_gather_into_tensor` / `reduce_scatter_tensor`, started with
+    async_op=True as partitioned.py does) executed by one rank on the one GPU of the test box: the same code path
+    as on the 8-GPU node, where only the world size differs."""
+    import subprocess
+    import sys
+    code = '''
+import os, torch, torch.distributed as dist
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29544", RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", device_id=dev)
+t = torch.arange(12, dtype=torch.float32, device=dev).view(4, 3)
+out = torch.empty(4, 3, device=dev)
+w = dist.all_gather_into_tensor(out, t, async_op=True)
+x = t @ t.t()                      # dense work issued between start and wait
+w.wait()
+assert torch.equal(out, t)
+rs = torch.empty(4, 3, device=dev)
+w = dist.reduce_scatter_tensor(rs, t.clone(), op=dist.ReduceOp.SUM, async_op=True)
+w.wait()
+assert torch.equal(rs, t)
+flat = torch.ones(1000, device=dev)
+dist.all_reduce(flat)
+dist.broadcast(flat, src=0)
+dist.barrier()
+assert float(flat.sum()) == 1000.0 and x.shape == (4, 4)
+dist.destroy_process_group()
+print("rccl ok")
+'''
+    r = subprocess.run([sys.executable, '-c', code], timeout=300, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0 and 'rccl ok' in r.stdout, r.stderr[-3000:]
