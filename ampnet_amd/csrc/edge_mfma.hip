@@ -57,10 +57,12 @@ constexpr int kWavesPerBlock = AMPCONV_WPB;
 #define AMPCONV_PF_FWD_T4 1      // main tiles in flight per wave in fwd_mfma_t4 (1 or 2; 2 needs AMPCONV_FWD_WAVES=3)
 #endif
 #ifndef AMPCONV_PF_SRC_T4
-#define AMPCONV_PF_SRC_T4 2      // edges in flight per wave in bwd_src_mfma_t4 (1, 2 or 4); 2 and 4 need AMPCONV_SRC_WAVES=2
+#define AMPCONV_PF_SRC_T4 1      // edges in flight per wave in bwd_src_mfma_t4 (1, 2 or 4); 2 and 4 need AMPCONV_SRC_WAVES=2
 #endif
 #ifndef AMPCONV_SRC_WAVES
-#define AMPCONV_SRC_WAVES 2      // waves per SIMD the source pass is compiled for (register budget 256; 3 = 168)
+#define AMPCONV_SRC_WAVES 3      // waves per SIMD the source pass is compiled for: 3 = 168 registers (own K / V operands
+                                 // re-read from LDS, statistics half an edge ahead), 2 = 256 (everything in registers,
+                                 // prefetch ring of AMPCONV_PF_SRC_T4 edges with their statistics): 115.8 vs 117.5 ms at cfg4
 #endif
 #ifdef AMPCONV_NO_SCHED_FENCE
 #define SCHED_FENCE()
@@ -577,7 +579,7 @@ __device__ __forceinline__ int tail_idx(int rho, int c) {
 }
 
 // registers -> main images (token rows < 16) and the stash slot of edge e (rows 16..19), scaled
-template <int DH, bool FULL>
+template <int DH, bool FULL, int IMG = TileCfg<DH>::TILE_FLOATS>
 __device__ __forceinline__ void pair_to_lds_tail(float *ldsA, float *stash, int e, const PairRegs<DH> &t,
                                                  float mulA, float mulB, int L, int lane) {
   using C = TileCfg<DH>;
@@ -593,7 +595,7 @@ __device__ __forceinline__ void pair_to_lds_tail(float *ldsA, float *stash, int 
       float4 x = t.v[i];
       x.x *= mul; x.y *= mul; x.z *= mul; x.w *= mul;
       if (j < 16) {
-        *reinterpret_cast<float4 *>(ldsA + (isB ? C::TILE_FLOATS : 0) + j * DH + ((q ^ swz<DH>(j)) << 2)) = x;
+        *reinterpret_cast<float4 *>(ldsA + (isB ? IMG : 0) + j * DH + ((q ^ swz<DH>(j)) << 2)) = x;
       } else {
         const int rho = 8 * e + (isB ? 4 : 0) + (j - 16);
         *reinterpret_cast<float4 *>(stash + rho * DH + ((q ^ swz_tail<DH>(rho)) << 2)) = x;
@@ -613,7 +615,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? AMPCONV_SRC_WAVES :
   using C = TileCfg<DH>;
   constexpr int kStash = 4 * 2 * 4 * DH;
   constexpr int NTM = NT4 ? 1 : 2;           // 16-wide column tiles on the 16x16x4 path
-  __shared__ __attribute__((aligned(16))) float lds_all[kWavesPerBlock][2 * C::TILE_FLOATS + kStash];
+  // FIXED_LDS (the 168-register build, AMPCONV_SRC_WAVES=3): the source's own K / V tiles live in LDS and their
+  // operands are re-read per phase (8 ds_read_b128) instead of holding 32 registers for the whole unit; the
+  // streamed images then keep only the 16 rows the main phase reads (tokens 16..19 go to the stash anyway):
+  // 13 312 B per wave = 3 blocks per CU
+  constexpr bool FIXED_LDS = NT4 && DH == 32 && AMPCONV_SRC_WAVES >= 3;
+  constexpr int kMain = FIXED_LDS ? 16 * DH : C::TILE_FLOATS;      // floats per streamed image
+  constexpr int kFix = FIXED_LDS ? 2 * C::TILE_FLOATS : 0;
+  __shared__ __attribute__((aligned(16))) float lds_all[kWavesPerBlock][2 * kMain + kStash + kFix];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t unit = (int64_t)blockIdx.x * kWavesPerBlock + wave;
@@ -622,28 +631,54 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? AMPCONV_SRC_WAVES :
   int h, beg, end, deg;
   if (!map_unit(a.hub, a.ptr, unit, a.H, s, onode, h, beg, end, deg)) return;
   const int L = a.L, n = lane & 15, g = lane >> 4, sg = (lane >> 2) & 3, jt = lane & 3;
-  float *Qt = lds_all[wave], *Gt = Qt + C::TILE_FLOATS, *stash = Qt + 2 * C::TILE_FLOATS;
+  float *Qt = lds_all[wave], *Gt = Qt + kMain, *stash = Qt + 2 * kMain;
+  float *Kfix = stash + kStash, *Vfix = Kfix + C::TILE_FLOATS;
   const float oscale = a.hub.mode == 2 ? 1.f : a.oscale;
 
-  float kB[NTM][C::KK], vB[NTM][C::KK];
-  float kT[NT4 ? C::KK : 1], vT[NT4 ? C::KK : 1];
+  float kB[FIXED_LDS ? 1 : NTM][FIXED_LDS ? 1 : C::KK], vB[FIXED_LDS ? 1 : NTM][FIXED_LDS ? 1 : C::KK];
+  float kT[NT4 && !FIXED_LDS ? C::KK : 1], vT[NT4 && !FIXED_LDS ? C::KK : 1];
   {
     const float *kb = tile_ptr<const float>(a.K, s, h);
     const float *vb = tile_ptr<const float>(a.V, s, h);
+    if constexpr (FIXED_LDS) {
+      if (!FULL) {
+        tile_zero<DH>(Kfix, lane);
+        tile_zero<DH>(Vfix, lane);
+      }
+      TileRegs<DH> tk, tv;
+      tile_load<DH>(tk, kb, a.K.row_stride, L, lane);
+      tile_load<DH>(tv, vb, a.V.row_stride, L, lane);
+      tile_to_lds<DH>(Kfix, tk, 1.f, L, lane);
+      tile_to_lds<DH>(Vfix, tv, 1.f, L, lane);
+    } else {
 #pragma unroll
-    for (int nt = 0; nt < NTM; ++nt) {
-      rowop_from_global<DH>(kB[nt], kb, a.K.row_stride, nt, true, 1.f, L, lane);
-      rowop_from_global<DH>(vB[nt], vb, a.V.row_stride, nt, true, 1.f, L, lane);
-    }
-    if constexpr (NT4) {
-      tailop_from_global<DH>(kT, kb, a.K.row_stride, 1.f, L, lane);
-      tailop_from_global<DH>(vT, vb, a.V.row_stride, 1.f, L, lane);
+      for (int nt = 0; nt < NTM; ++nt) {
+        rowop_from_global<DH>(kB[nt], kb, a.K.row_stride, nt, true, 1.f, L, lane);
+        rowop_from_global<DH>(vB[nt], vb, a.V.row_stride, nt, true, 1.f, L, lane);
+      }
+      if constexpr (NT4) {
+        tailop_from_global<DH>(kT, kb, a.K.row_stride, 1.f, L, lane);
+        tailop_from_global<DH>(vT, vb, a.V.row_stride, 1.f, L, lane);
+      }
     }
   }
   if (!FULL) {
-    tile_zero<DH>(Qt, lane);
-    tile_zero<DH>(Gt, lane);
+    for (int i = lane; i < 2 * kMain; i += AMPCONV_WAVE) Qt[i] = 0.f;
   }
+  // operands of the source's own tile for one phase: columns 0..15 (16x16x4 B operand) and 16..19 (4x4x1 B operand)
+  auto fixed_ops = [&](float (&b0)[C::KK], float (&bt)[C::KK], const float *img, const float (&r0)[FIXED_LDS ? 1 : C::KK],
+                       const float (&rt)[NT4 && !FIXED_LDS ? C::KK : 1]) {
+    if constexpr (FIXED_LDS) {
+      rowop_from_lds<DH>(b0, img, 0, lane);
+      tailop_from_lds<DH>(bt, img, lane);
+    } else {
+#pragma unroll
+      for (int kk = 0; kk < C::KK; ++kk) {
+        b0[kk] = r0[kk];
+        bt[kk] = rt[NT4 ? kk : 0];
+      }
+    }
+  };
   // slots of a last, partial batch and token rows >= L are read by the MFMAs: keep them finite
   for (int i = lane; i < kStash; i += AMPCONV_WAVE) stash[i] = 0.f;
   f32x4 dKT[C::MC][NTM], dVT[C::MC][NTM];
@@ -665,10 +700,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? AMPCONV_SRC_WAVES :
   // of the edge's own phase and the wave waits for them behind the first MFMAs (fewer live registers: what
   // the 168-register build needs; the wait is hidden only while other waves keep the matrix pipe busy)
   constexpr bool STATS_AHEAD = DH == 32 && AMPCONV_SRC_WAVES < 3;
+  // STATS_HALF (the 168-register build): no ring slot to spare, so the statistics of edge p + 1 are requested right
+  // after edge p's own have been consumed (end of phase 1) and arrive behind phase 2, ~60 % of an edge ahead of
+  // their use, in the registers the element-wise step has just freed
+  constexpr bool STATS_HALF = FIXED_LDS;
   struct EdgeStats { f32x4 l4, d4; float lT, dT; };
   EdgeStats ring_st[PF];
   IdxWindow win;
   auto load_stats = [&](EdgeStats &st, int p) {
+    p = p < end ? p : end - 1;                 // STATS_HALF asks one edge past the segment
     const float *sbm = a.stats + ((int64_t)p * a.H + h) * kStatsPerUnit;
     st.l4 = *reinterpret_cast<const f32x4 *>(sbm + 4 * g);
     st.d4 = *reinterpret_cast<const f32x4 *>(sbm + kLmax + 4 * g);
@@ -709,18 +749,23 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? AMPCONV_SRC_WAVES :
       st.dT = sbT[kLmax + 16 + g];
     }
   };
+  EdgeStats next_st;
+  if constexpr (STATS_HALF) {
+    if (beg < end) load_stats(next_st, beg);
+  }
   for (int p0 = beg; p0 < end; p0 += 4) {
     EdgeStats tail_st;
     if constexpr (STATS_AHEAD) load_tail_stats(tail_st, p0);     // used four main phases later
-#pragma unroll(PF == 1 ? 1 : 4)
+#pragma unroll((PF == 1 && !FIXED_LDS) ? 1 : 4)
     for (int e = 0; e < 4; ++e) {
       const int p = p0 + e;
       if (p >= end) break;
       PairRegs<DH> &qg = ring[e % PF];             // batches are 4 edges long: the ring slot of an edge is e % PF
       float &inv_next = ring_inv[e % PF];
-      pair_to_lds_tail<DH, FULL>(Qt, stash, e, qg, a.qscale, inv_next, L, lane);
+      pair_to_lds_tail<DH, FULL, kMain>(Qt, stash, e, qg, a.qscale, inv_next, L, lane);
       EdgeStats st = ring_st[e % PF];
-      if constexpr (!STATS_AHEAD) load_stats(st, p);   // ahead of the tile loads of the next edge
+      if constexpr (STATS_HALF) st = next_st;
+      else if constexpr (!STATS_AHEAD) load_stats(st, p);   // ahead of the tile loads of the next edge
       const f32x4 l4 = st.l4, d4 = st.d4;
       const float lT = st.lT, dT = st.dT;
       if (p + PF < end) fetch(qg, inv_next, ring_st[e % PF], p + PF);
@@ -733,12 +778,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? AMPCONV_SRC_WAVES :
       float pT = 0.f, dsT = 0.f;
       if constexpr (NT4) {
         {
-          float qA[C::KK];
+          float qA[C::KK], b0[C::KK], bt[C::KK];
           rowop_from_lds<DH>(qA, Qt, 0, lane);
+          fixed_ops(b0, bt, Kfix, kB[0], kT);
 #pragma unroll
           for (int kk = 0; kk < C::KK; ++kk) {
-            S0 = MFMA16(qA[kk], kB[0][kk], S0);
-            S1 = MFMA4(qA[kk], kT[kk], S1, 0);          // 4x4x1 partials of the columns 16..19
+            S0 = MFMA16(qA[kk], b0[kk], S0);
+            S1 = MFMA4(qA[kk], bt[kk], S1, 0);          // 4x4x1 partials of the columns 16..19
           }
         }
         pT = (vt && (FULL || 4 * sg + g < L)) ? fast_exp2(reduce_transpose(S1) - lT) : 0.f;
@@ -746,17 +792,21 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? AMPCONV_SRC_WAVES :
         for (int q = 0; q < 4; ++q) S0[q] = v0 ? fast_exp2(S0[q] - l4[q]) : 0.f;
         SCHED_FENCE();
         {
-          float gA[C::KK];
+          float gA[C::KK], b0[C::KK], bt[C::KK];
           rowop_from_lds<DH>(gA, Gt, 0, lane);
+          fixed_ops(b0, bt, Vfix, vB[0], vT);
 #pragma unroll
           for (int kk = 0; kk < C::KK; ++kk) {
-            dP0 = MFMA16(gA[kk], vB[0][kk], dP0);
-            dP1 = MFMA4(gA[kk], vT[kk], dP1, 0);
+            dP0 = MFMA16(gA[kk], b0[kk], dP0);
+            dP1 = MFMA4(gA[kk], bt[kk], dP1, 0);
           }
         }
         dsT = pT * (reduce_transpose(dP1) - dT);
 #pragma unroll
         for (int q = 0; q < 4; ++q) dP0[q] = S0[q] * (dP0[q] - d4[q]);      // dP now holds dS
+        if constexpr (STATS_HALF) {
+          load_stats(next_st, p + 1);
+        }
       } else {
         {
           float qA[C::KK], gA[C::KK];
@@ -823,14 +873,25 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? AMPCONV_SRC_WAVES :
           qA[4 * b + 0] = x.x; qA[4 * b + 1] = x.y; qA[4 * b + 2] = x.z; qA[4 * b + 3] = x.w;
           gA[4 * b + 0] = y.x; gA[4 * b + 1] = y.y; gA[4 * b + 2] = y.z; gA[4 * b + 3] = y.w;
         }
+        if constexpr (NT4) {
+          float b0[C::KK], bt[C::KK];
+          fixed_ops(b0, bt, Kfix, kB[0], kT);
 #pragma unroll
-        for (int kk = 0; kk < C::KK; ++kk) {
-          S0 = MFMA16(qA[kk], kB[0][kk], S0);
-          dP0 = MFMA16(gA[kk], vB[0][kk], dP0);
-          if constexpr (NT4) {
-            S1 = MFMA4(qA[kk], kT[kk], S1, 0);
-            dP1 = MFMA4(gA[kk], vT[kk], dP1, 0);
-          } else {
+          for (int kk = 0; kk < C::KK; ++kk) {
+            S0 = MFMA16(qA[kk], b0[kk], S0);
+            S1 = MFMA4(qA[kk], bt[kk], S1, 0);
+          }
+          fixed_ops(b0, bt, Vfix, vB[0], vT);
+#pragma unroll
+          for (int kk = 0; kk < C::KK; ++kk) {
+            dP0 = MFMA16(gA[kk], b0[kk], dP0);
+            dP1 = MFMA4(gA[kk], bt[kk], dP1, 0);
+          }
+        } else {
+#pragma unroll
+          for (int kk = 0; kk < C::KK; ++kk) {
+            S0 = MFMA16(qA[kk], kB[0][kk], S0);
+            dP0 = MFMA16(gA[kk], vB[0][kk], dP0);
             S1 = MFMA16(qA[kk], kB[NTM - 1][kk], S1);
             dP1 = MFMA16(gA[kk], vB[NTM - 1][kk], dP1);
           }

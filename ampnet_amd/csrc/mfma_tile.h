@@ -301,6 +301,19 @@ __device__ __forceinline__ void tailop_from_global(float (&op)[TileCfg<DH>::KK],
   }
 }
 
+// the same operand from a 20-row LDS image of the fixed tile (rows 16..19; every quad sg reads the same 16 bytes)
+template <int DH>
+__device__ __forceinline__ void tailop_from_lds(float (&op)[TileCfg<DH>::KK], const float *lds, int lane) {
+  using C = TileCfg<DH>;
+  const int j = 16 + (lane & 3), ks = lane >> 4;
+#pragma unroll
+  for (int b = 0; b < C::KK / 4; ++b) {
+    const int chunk = (C::KK / 4) * ks + b;
+    const float4 x = *reinterpret_cast<const float4 *>(lds + j * DH + ((chunk ^ swz<DH>(j)) << 2));
+    op[4 * b + 0] = x.x; op[4 * b + 1] = x.y; op[4 * b + 2] = x.z; op[4 * b + 3] = x.w;
+  }
+}
+
 // phase-1 partials (reg r of lane group ks = partial of row 4 sg + r) -> lane (g, sg, j) = row 4 sg + g
 __device__ __forceinline__ float reduce_transpose(const f32x4 &x) {
   float x0 = x[0], x1 = x[1], x2 = x[2], x3 = x[3];
