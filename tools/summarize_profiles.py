@@ -128,7 +128,9 @@ def main():
                     'SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (duration x clock), clock = GRBM_GUI_ACTIVE / 8 / duration.  '
                     f'`{tag}_final` = the kernels as shipped (fixed-side tail tokens on v_mfma_f32_4x4x1), `{tag}_nt4off` = the '
                     'same build with AMPCONV_FWD_NT4=0 AMPCONV_DST_NT4=0 AMPCONV_SRC_NT4=0 (all products on 16x16x4, the '
-                    'round-1 tiling).  Profiled runs are a few % slower than un-profiled ones.\n\n```\n')
+                    'round-1 tiling; its source pass is compiled under the same 168-register bound as the shipped one and spills 11 '
+                    'registers there -- round 1 measured 12.9-13.1 ms for it without spills, `profiles/r01_sq_counters.md`).  '
+                    'Profiled runs are a few % slower than un-profiled ones.\n\n```\n')
             f.write(open(sq).read())
             f.write('```\n')
 
