@@ -837,3 +837,44 @@ def test_bench_rccl_path_single_rank(dev):
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][0])
     assert out['n_gpus'] == 1 and out['value'] > 0
+
+
+def test_nt4_kernels_match_round1_tiling(dev, tmp_path):
+    """The 4x4x1 tail kernels (default) against the same build with AMPCONV_{FWD,DST,SRC}_NT4=0 (every product on
+    16x16x4, the round-1 tiling): an independent MFMA formulation of the same arithmetic.  The switches are read once
+    per process, so the round-1 tiling runs in a child process."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    script = f'''
+import sys, numpy as np, torch
+sys.path.insert(0, {ROOT!r})
+from ampnet_amd import AMPConv
+torch.manual_seed(12)
+dev = torch.device("cuda:0")
+N, E, L, D, H = 500, 7000, 20, 256, 8
+layer = AMPConv(D, H).to(dev)
+with torch.no_grad():
+    layer.multi_head_attention.in_proj_bias.normal_(0, 0.1)
+    layer.multi_head_attention.out_proj.bias.normal_(0, 0.1)
+g = torch.Generator(device=dev).manual_seed(13)
+x = torch.randn(N, L * D, device=dev, generator=g).requires_grad_(True)
+dy = torch.randn(N, L * D, device=dev, generator=g)
+ei = torch.randint(0, N, (2, E), device=dev, generator=g)
+ei[1, :300] = 3
+ei[0, 300:500] = 4
+y = layer(x, ei)
+y.backward(dy)
+m = layer.multi_head_attention
+np.savez(sys.argv[1], y=y.detach().cpu().numpy(), dx=x.grad.cpu().numpy(), gw=m.in_proj_weight.grad.cpu().numpy(),
+         gb=m.in_proj_bias.grad.cpu().numpy(), gow=m.out_proj.weight.grad.cpu().numpy())
+'''
+    outs = {}
+    for name, extra in (('nt4', {}), ('r1', {'AMPCONV_FWD_NT4': '0', 'AMPCONV_DST_NT4': '0', 'AMPCONV_SRC_NT4': '0'})):
+        path = str(tmp_path / f'{name}.npz')
+        r = subprocess.run([sys.executable, '-c', script, path], env=dict(os.environ, **extra), timeout=600,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs[name] = dict(np.load(path))
+    for k in outs['nt4']:
+        assert_close_scaled(outs['nt4'][k], outs['r1'][k], k + ' (4x4x1 tail vs 16x16x4 tiling)')
