@@ -70,9 +70,14 @@ def main():
         def both():
             cur = torch.cuda.current_stream()
             side.wait_stream(cur)
-            with torch.cuda.stream(side):
-                gemms(k)
-            edges()
+            if '--edges-first' in sys.argv:
+                edges()
+                with torch.cuda.stream(side):
+                    gemms(k)
+            else:
+                with torch.cuda.stream(side):
+                    gemms(k)
+                edges()
             cur.wait_stream(side)
         t_b = timed(both)
         print(f'N={N} E={E}: edge passes {t_e:.2f} ms | {k} GEMMs {t_g:.2f} ms ({k * flop / t_g / 1e9:.0f} TFLOP/s) | '
