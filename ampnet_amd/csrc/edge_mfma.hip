@@ -1001,7 +1001,7 @@ __device__ __forceinline__ void main_load(MainRegs<DH> &t, const float *baseA, i
     const int j = R & 15;
     const unsigned boff = ((unsigned)j * (unsigned)(isB ? strideB : strideA) + 4u * (unsigned)q) * 4u;
     const char *p = reinterpret_cast<const char *>(isB ? baseB : baseA) + boff;
-    if (FULL || j < L) t.v[i] = *reinterpret_cast<const float4 *>(p);
+    if (FULL || j < L) t.v[i] = STREAM_LOAD4(p);
   }
 }
 template <int DH, bool FULL>
@@ -1033,8 +1033,7 @@ __device__ __forceinline__ void tail_load(TailRegs<DH> &t, const ampconv_view_t 
     const int lo = (rho & 4) ? id1 : id0, hi = (rho & 4) ? id3 : id2;     // edge rho >> 2
     const int node = (rho & 8) ? hi : lo;
     if (FULL || tok < L)
-      t.v[i] = *reinterpret_cast<const float4 *>(tile_ptr<const float>(view, node, h) +
-                                                  (int64_t)tok * view.row_stride + 4 * q);
+      t.v[i] = STREAM_LOAD4(tile_ptr<const float>(view, node, h) + (int64_t)tok * view.row_stride + 4 * q);
   }
 }
 template <int DH, bool FULL>

@@ -28,6 +28,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
+// 16-byte load of a streamed (gathered, read-once-per-edge) tile chunk.  AMPCONV_NT_LOADS: non-temporal hint.
+template <typename P>
+__device__ __forceinline__ float4 stream_load4(const P *p) {
+#ifdef AMPCONV_NT_LOADS
+  const f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const f32x4 *>(p));
+  return make_float4(v[0], v[1], v[2], v[3]);
+#else
+  return *reinterpret_cast<const float4 *>(p);
+#endif
+}
+#define STREAM_LOAD4(p) stream_load4(p)
+
 constexpr int kLmax = 20;   // tokens per node handled by the MFMA path
 
 template <int DH>
@@ -117,7 +129,7 @@ __device__ __forceinline__ void pair_load(PairRegs<DH> &t, const float *baseA, i
     // per edge: lets the compiler keep the base in SGPRs (global_load ... v_off, s[base:base+1])
     const unsigned boff = ((unsigned)j * (unsigned)(isB ? strideB : strideA) + 4u * (unsigned)q) * 4u;
     const char *p = reinterpret_cast<const char *>(isB ? baseB : baseA) + boff;
-    if (valid) t.v[i] = *reinterpret_cast<const float4 *>(p);
+    if (valid) t.v[i] = STREAM_LOAD4(p);
   }
 }
 
