@@ -1632,6 +1632,16 @@ inline bool aligned16(const ampconv_view_t &v) {
 
 }  // namespace
 
+// This file is compiled into TWO objects (__graft_entry__.py): AMPCONV_PART=1 = the backward passes and the helpers
+// under the default scheduler, AMPCONV_PART=2 = the forward pass under `-mllvm -amdgpu-sched-strategy=iterative-minreg`
+// (the forward kernel sits exactly at the 128-register line of 4 waves per SIMD: the register-minimising scheduler
+// needs no spill there and runs 4-5 % faster, 76-79 vs 80-82 ms at cfg4; the two backward kernels lose 2-3 % under it).
+// AMPCONV_PART undefined: everything in one object.
+#ifndef AMPCONV_PART
+#define AMPCONV_PART 0
+#endif
+
+#if AMPCONV_PART != 2
 bool ampconv_mfma_supported(int L, int D, int H) {
   const int dh = D / H;
   return L >= 1 && L <= kLmax && (dh == 16 || dh == 32);
@@ -1643,6 +1653,9 @@ bool ampconv_mfma_views_ok(const ampconv_view_t *views, int n) {
   return true;
 }
 
+#endif  // AMPCONV_PART != 2
+
+#if AMPCONV_PART != 1
 int ampconv_fwd_edge_mfma(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
                           const int32_t *rowptr, const int32_t *col, const int32_t *qidx,
                           int64_t n_rows, int L, int D, int H, ampconv_view_t O, HubArgs hub,
@@ -1675,6 +1688,9 @@ int ampconv_fwd_edge_mfma(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
   return ampconv_launch_status();
 }
 
+#endif  // AMPCONV_PART != 1
+
+#if AMPCONV_PART != 2
 int ampconv_bwd_edge_dst_mfma(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
                               ampconv_view_t dO, const int32_t *rowptr, const int32_t *col,
                               int64_t n_rows, int L, int D, int H, ampconv_view_t dQ, HubArgs hub,
@@ -1767,7 +1783,9 @@ int ampconv_bwd_edge_src_mfma(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t
   return ampconv_launch_status();
 }
 
-#ifdef AMPCONV_STAMPS
+#endif  // AMPCONV_PART != 2
+
+#if defined(AMPCONV_STAMPS) && AMPCONV_PART != 2
 extern "C" int ampconv_debug_read_stamps(unsigned long long *host_out, int n) {
   return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamp_sums), sizeof(unsigned long long) * n);
 }
