@@ -6,16 +6,26 @@
 
 namespace {
 
+// Plan layout: header {n_chunks, chunk, n_rows, offset of the list in int32 units}, then max_chunks descriptors, then the list of the first-chunk
+// indices of the long rows (n_rows entries; what the combine pass launches over: one block column per ROW instead of
+// one per chunk with all but the first exiting -- 8 M blocks per call on RMAT scale 21).
+__device__ __host__ inline int64_t hub_max_chunks(int64_t E, int chunk) { return 2 * (E / chunk) + 2; }
+
 __global__ void hub_plan_kernel(const int32_t *__restrict__ ptr, int64_t N, int chunk,
-                                int32_t *__restrict__ header, HubDesc *__restrict__ descs) {
+                                int32_t *__restrict__ header, HubDesc *__restrict__ descs,
+                                int32_t *__restrict__ firsts) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (r == 0) header[1] = chunk;
+  if (r == 0) {
+    header[1] = chunk;
+    header[3] = (int32_t)(firsts - header);
+  }
   if (r >= N) return;
   const int beg = ptr[r], end = ptr[r + 1];
   const int deg = end - beg;
   if (deg <= chunk) return;
   const int nc = (deg + chunk - 1) / chunk;
   const int base = atomicAdd(header, nc);      // slot order is arbitrary, results do not depend on it
+  firsts[atomicAdd(header + 2, 1)] = base;
   for (int k = 0; k < nc; ++k) {
     const int b = beg + k * chunk;
     descs[base + k] = HubDesc{(int32_t)r, b, b + chunk < end ? b + chunk : end, k == 0 ? nc : 0};
@@ -32,10 +42,11 @@ __global__ void hub_plan_kernel(const int32_t *__restrict__ ptr, int64_t N, int 
 template <int VEC>
 __global__ __launch_bounds__(256) void hub_combine_kernel(const HubDesc *__restrict__ descs, const float *__restrict__ P,
                                                           ampconv_view_t out, const int32_t *__restrict__ ptr, int L,
-                                                          int D, int dh, float scale, int out_bf16) {
-  const int64_t c = blockIdx.x;
+                                                          int D, int dh, float scale, int out_bf16,
+                                                          const int32_t *__restrict__ header) {
+  if ((int)blockIdx.x >= header[2]) return;          // the grid is sized for the most rows n_chunks can hold
+  const int64_t c = header[header[3] + blockIdx.x];
   const HubDesc d = descs[c];
-  if (d.nfirst == 0) return;
   __shared__ float part[4][64 * VEC];
   const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int64_t LD = (int64_t)L * D;
@@ -95,7 +106,8 @@ __global__ __launch_bounds__(256) void hub_combine_kernel(const HubDesc *__restr
 
 extern "C" size_t ampconv_hub_plan_bytes(int64_t E, int chunk) {
   if (E < 0 || chunk <= 0) return 0;
-  return 16 + sizeof(HubDesc) * (size_t)(2 * (E / chunk) + 2);
+  const size_t mc = (size_t)hub_max_chunks(E, chunk);
+  return 16 + sizeof(HubDesc) * mc + sizeof(int32_t) * (mc / 2 + 2);
 }
 
 extern "C" int ampconv_hub_plan(const int32_t *ptr, int64_t N, int64_t E, int chunk, void *plan,
@@ -105,8 +117,9 @@ extern "C" int ampconv_hub_plan(const int32_t *ptr, int64_t N, int64_t E, int ch
   int32_t *header = (int32_t *)plan;
   hipError_t e = hipMemsetAsync(header, 0, 16, stream);
   if (e != hipSuccess) return (int)e;
-  hub_plan_kernel<<<(unsigned)((N + 255) / 256), 256, 0, stream>>>(ptr, N, chunk, header,
-                                                                  (HubDesc *)(header + 4));
+  HubDesc *descs = (HubDesc *)(header + 4);
+  int32_t *firsts = (int32_t *)(descs + hub_max_chunks(E, chunk));
+  hub_plan_kernel<<<(unsigned)((N + 255) / 256), 256, 0, stream>>>(ptr, N, chunk, header, descs, firsts);
   return ampconv_launch_status();
 }
 
@@ -126,12 +139,14 @@ int ampconv_hub_combine(const void *plan, int64_t n_chunks, const float *P, ampc
   const bool vec4 = dh % 4 == 0 && out.node_stride % 4 == 0 && out.row_stride % 4 == 0 && out.head_stride % 4 == 0 &&
                     (uintptr_t)P % 16 == 0 && (out_bf16 || (uintptr_t)out.ptr % 16 == 0);
   if (n_chunks > INT32_MAX) return AMPCONV_E_BADARG;
+  const int32_t *header = (const int32_t *)plan;
+  const unsigned max_rows = (unsigned)(n_chunks / 2 + 1);      // a long row has at least two chunks
   if (vec4) {
-    const dim3 grid((unsigned)n_chunks, (unsigned)((LD + 255) / 256));
-    hub_combine_kernel<4><<<grid, 256, 0, stream>>>(descs, P, out, ptr_for_mean, L, D, dh, scale, out_bf16);
+    const dim3 grid(max_rows, (unsigned)((LD + 255) / 256));
+    hub_combine_kernel<4><<<grid, 256, 0, stream>>>(descs, P, out, ptr_for_mean, L, D, dh, scale, out_bf16, header);
   } else {
-    const dim3 grid((unsigned)n_chunks, (unsigned)((LD + 63) / 64));
-    hub_combine_kernel<1><<<grid, 256, 0, stream>>>(descs, P, out, ptr_for_mean, L, D, dh, scale, out_bf16);
+    const dim3 grid(max_rows, (unsigned)((LD + 63) / 64));
+    hub_combine_kernel<1><<<grid, 256, 0, stream>>>(descs, P, out, ptr_for_mean, L, D, dh, scale, out_bf16, header);
   }
   return ampconv_launch_status();
 }
