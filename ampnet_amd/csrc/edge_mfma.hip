@@ -59,6 +59,20 @@ constexpr int kWavesPerBlock = AMPCONV_WPB;
 #ifndef AMPCONV_PF_SRC_T4
 #define AMPCONV_PF_SRC_T4 1      // edges in flight per wave in bwd_src_mfma_t4 (1, 2 or 4); 2 and 4 need AMPCONV_SRC_WAVES=2
 #endif
+// dh = 16 (BASELINE config 3): 4 waves per SIMD with one edge in flight, or 3 with a ring of AMPCONV_PF_SRC16 edges whose
+// statistics travel with the tiles
+#ifndef AMPCONV_DST16_WAVES
+#define AMPCONV_DST16_WAVES 4
+#endif
+#ifndef AMPCONV_PF_DST16
+#define AMPCONV_PF_DST16 1
+#endif
+#ifndef AMPCONV_SRC16_WAVES
+#define AMPCONV_SRC16_WAVES 3     // 6.12 vs 6.37 ms at 100 k / 1 M, D=128, H=8
+#endif
+#ifndef AMPCONV_PF_SRC16
+#define AMPCONV_PF_SRC16 2
+#endif
 #ifndef AMPCONV_SRC_WAVES
 #define AMPCONV_SRC_WAVES 3      // waves per SIMD the source pass is compiled for: 3 = 168 registers (own K / V operands
                                  // re-read from LDS, statistics half an edge ahead), 2 = 256 (everything in registers,
@@ -611,7 +625,7 @@ __device__ __forceinline__ void pair_to_lds_tail(float *ldsA, float *stash, int 
 // phase-1 result (one register: lane (g, sg, j) = destination token 4 sg + g, source token 16 + j)
 // goes straight back in as the B operand of phase 2.
 template <int DH, bool FULL, bool NT4>
-__global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? AMPCONV_SRC_WAVES : 4) void bwd_src_mfma_t4(BwdArgs a) {
+__global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? AMPCONV_SRC_WAVES : AMPCONV_SRC16_WAVES) void bwd_src_mfma_t4(BwdArgs a) {
   using C = TileCfg<DH>;
   constexpr int kStash = 4 * 2 * 4 * DH;
   constexpr int NTM = NT4 ? 1 : 2;           // 16-wide column tiles on the 16x16x4 path
@@ -692,14 +706,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? AMPCONV_SRC_WAVES :
 
   // register ring: the tiles of the next PF edges are in flight while one edge computes (PF = 2 needs
   // the 256-register budget of two waves per SIMD: AMPCONV_SRC_WAVES=2)
-  constexpr int PF = DH == 32 ? AMPCONV_PF_SRC_T4 : 1;      // dh = 16 stays within 128 registers (4 waves per SIMD)
+  constexpr int PF = DH == 32 ? AMPCONV_PF_SRC_T4 : AMPCONV_PF_SRC16;
   PairRegs<DH> ring[PF];
   float ring_inv[PF];
   // statistics of an edge (lse / delta of its destination tokens 4g .. 4g+3 and, NT4, of token 4 sg + g).
   // STATS_AHEAD: they travel with the edge's tiles, PF edges ahead; otherwise they are loaded at the start
   // of the edge's own phase and the wave waits for them behind the first MFMAs (fewer live registers: what
   // the 168-register build needs; the wait is hidden only while other waves keep the matrix pipe busy)
-  constexpr bool STATS_AHEAD = DH == 32 && AMPCONV_SRC_WAVES < 3;
+  constexpr bool STATS_AHEAD = DH == 32 ? AMPCONV_SRC_WAVES < 3 : AMPCONV_SRC16_WAVES < 4;
   // STATS_HALF (the 168-register build): no ring slot to spare, so the statistics of edge p + 1 are requested right
   // after edge p's own have been consumed (end of phase 1) and arrive behind phase 2, ~60 % of an edge ahead of
   // their use, in the registers the element-wise step has just freed
@@ -1328,7 +1342,7 @@ __device__ __forceinline__ void tail_dma(float *img, const ampconv_view_t &view,
 // 4 sg + g, destination token 16 + j); max, sum and delta of a column are all-reduces over the 16 lanes that
 // share j, quad sg == e folding in the batch's tail tile.  Per edge and head 30 16x16x4 + 30 4x4x1 instead of 60.
 template <int DH, bool FULL, bool STATS, bool NT4>
-__global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? AMPCONV_DST_WAVES : 4) void bwd_dst_mfma_t4(BwdArgs a) {
+__global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? AMPCONV_DST_WAVES : AMPCONV_DST16_WAVES) void bwd_dst_mfma_t4(BwdArgs a) {
   using C = TileCfg<DH>;
   constexpr int kImg = 16 * DH;
   // two separate LDS objects: the compiler orders every LDS read behind an LDS-DMA it cannot prove
@@ -1393,7 +1407,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? AMPCONV_DST_WAVES :
   // main tiles of the next PF edges in flight (ring slot = e % PF).  The ordering argument for the LDS-DMA
   // of the tail images below holds for PF = 2 as well: the DMA of batch b + 1 goes out in phase 0 of the FULL
   // batch b ahead of that phase's staged loads, and phase 2 waits for exactly those loads.
-  constexpr int PF = DH == 32 ? AMPCONV_PF_DST_T4 : 1;
+  constexpr int PF = DH == 32 ? AMPCONV_PF_DST_T4 : AMPCONV_PF_DST16;
   MainRegs<DH> ring[PF];
   int cur = 0;
   if (beg < end) {
