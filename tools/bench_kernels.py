@@ -56,10 +56,23 @@ def main():
     print(f'mode={dt} N={N} E={E} L={L} D={D} H={H}  csr build (cold) {1e3 * (time.time() - t0):.1f} ms')
     print(f'csr build {timeit(lambda: EdgeCSR(ei, N, validate=False)):.3f} ms')
     Qv, Kv, Vv = (F_._view(qkv, i * D, L, dh) for i in range(3))
+    dOv = F_._view(dobar, 0, L, dh)
+    # --layout=nhld / hnld: gathered inputs with contiguous per-(node, head) tiles (strided views, no kernel change)
+    layout = next((a.split('=')[1] for a in sys.argv if a.startswith('--layout=')), 'nld')
+    if layout != 'nld':
+        src4 = [qkv[:, i * D:(i + 1) * D].reshape(N, L, H, dh) for i in range(3)] + [dobar.reshape(N, L, H, dh)]
+        es = qkv.element_size()
+        if layout == 'nhld':
+            keep_in = [t.permute(0, 2, 1, 3).contiguous() for t in src4]          # [N, H, L, dh]
+            views = [_lib.View(t.data_ptr(), H * L * dh, dh, L * dh) for t in keep_in]
+        else:
+            keep_in = [t.permute(2, 0, 1, 3).contiguous() for t in src4]          # [H, N, L, dh]
+            views = [_lib.View(t.data_ptr(), L * dh, dh, N * L * dh) for t in keep_in]
+        Qv, Kv, Vv, dOv = views
+    print('input layout', layout)
     obar = torch.empty(N * L, D, device=dev, dtype=tdt)
     dqkv = torch.empty(N * L, 3 * D, device=dev, dtype=tdt)
     dQv, dKv, dVv = (F_._view(dqkv, i * D, L, dh) for i in range(3))
-    dOv = F_._view(dobar, 0, L, dh)
     st = torch.cuda.current_stream().cuda_stream
     R = L * D * qkv.element_size()
 
