@@ -644,6 +644,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? AMPCONV_SRC_WAVES :
   int64_t s, onode;
   int h, beg, end, deg;
   if (!map_unit(a.hub, a.ptr, unit, a.H, s, onode, h, beg, end, deg)) return;
+  STAMP_DECL
   const int L = a.L, n = lane & 15, g = lane >> 4, sg = (lane >> 2) & 3, jt = lane & 3;
   float *Qt = lds_all[wave], *Gt = Qt + kMain, *stash = Qt + 2 * kMain;
   float *Kfix = stash + kStash, *Vfix = Kfix + C::TILE_FLOATS;
@@ -776,7 +777,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? AMPCONV_SRC_WAVES :
       if (p >= end) break;
       PairRegs<DH> &qg = ring[e % PF];             // batches are 4 edges long: the ring slot of an edge is e % PF
       float &inv_next = ring_inv[e % PF];
+      STAMP(0);
       pair_to_lds_tail<DH, FULL, kMain>(Qt, stash, e, qg, a.qscale, inv_next, L, lane);
+      STAMP(1);
       EdgeStats st = ring_st[e % PF];
       if constexpr (STATS_HALF) st = next_st;
       else if constexpr (!STATS_AHEAD) load_stats(st, p);   // ahead of the tile loads of the next edge
@@ -784,6 +787,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? AMPCONV_SRC_WAVES :
       const float lT = st.lT, dT = st.dT;
       if (p + PF < end) fetch(qg, inv_next, ring_st[e % PF], p + PF);
       __builtin_amdgcn_wave_barrier();
+      STAMP(2);
 
       // main tile: destination tokens 0..15 of this edge.  S first, then dP (NT4: one after the other
       // keeps only one row operand and one pair of result tiles live at a time)
@@ -805,6 +809,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? AMPCONV_SRC_WAVES :
 #pragma unroll
         for (int q = 0; q < 4; ++q) S0[q] = v0 ? fast_exp2(S0[q] - l4[q]) : 0.f;
         SCHED_FENCE();
+        STAMP(3);
         {
           float gA[C::KK], b0[C::KK], bt[C::KK];
           rowop_from_lds<DH>(gA, Gt, 0, lane);
@@ -821,6 +826,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? AMPCONV_SRC_WAVES :
         if constexpr (STATS_HALF) {
           load_stats(next_st, p + 1);
         }
+        STAMP(4);
       } else {
         {
           float qA[C::KK], gA[C::KK];
@@ -862,6 +868,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? AMPCONV_SRC_WAVES :
         nt_accumulate<DH, AMPCONV_NT_PHYS_SRC>(dK4, Qt, nt_main, dsT);
       }
       __builtin_amdgcn_wave_barrier();
+      STAMP(5);
     }
 
     // tail tile of the (up to) four edges p0 .. p0+3: lane group g <-> edge p0 + g
@@ -947,8 +954,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? AMPCONV_SRC_WAVES :
         nt_accumulate<DH, AMPCONV_NT_PHYS_SRC>(dK4, stash, nt_stash, dsT);
       }
       __builtin_amdgcn_wave_barrier();
+      STAMP(6);
     }
   }
+  STAMP(7);
 
   float *kb = tile_ptr<float>(a.dK, onode, h), *vb = tile_ptr<float>(a.dV, onode, h);
 #pragma unroll
@@ -981,6 +990,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? AMPCONV_SRC_WAVES :
       }
     }
   }
+  STAMP_FLUSH(unit);
 }
 
 // ---- forward with the tail tokens of four consecutive edges in one MFMA tile.
