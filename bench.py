@@ -446,6 +446,8 @@ def main():
         ms = timer.summary()
         alg = {'ampconv_fwd_edge': (2 * E + 2 * N) * R, 'ampconv_bwd_edge_dst': (2 * E + 3 * N) * R,
                'ampconv_bwd_edge_src': (2 * E + 4 * N) * R}
+        kflops = {'ampconv_fwd_edge': 4 * L * L * D * E, 'ampconv_bwd_edge_dst': 6 * L * L * D * E,
+                  'ampconv_bwd_edge_src': 8 * L * L * D * E}   # multiply-adds x 2 of the products each pass does
         dom = max(ms, key=ms.get)
         achieved = alg[dom] / (ms[dom] * 1e-3) / 1e9
         value = world * E * args.steps / dt
@@ -489,7 +491,11 @@ def main():
             'ms_per_step_hip_events_median': median_ms,
             'roofline': {'kernel': dom, 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
                          'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'algorithmic_bytes_per_launch': alg[dom], 'avg_launch_ms': ms[dom]},
+                         'algorithmic_bytes_per_launch': alg[dom], 'avg_launch_ms': ms[dom],
+                         # the same launch against the arithmetic peak (fp32: MFMA and VALU share the FP32 pipe)
+                         'arithmetic': {'flops_per_launch': kflops[dom], 'achieved_TFLOPs': kflops[dom] / (ms[dom] * 1e-3) / 1e12,
+                                        'peak_TFLOPs': mfma_peak,
+                                        'frac': kflops[dom] / (ms[dom] * 1e-3) / 1e12 / mfma_peak}},
         }
         if alt is not None:
             out['alt_gemm'] = alt
