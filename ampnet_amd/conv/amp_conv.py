@@ -72,8 +72,11 @@ class AMPConv(MessagePassing):
         # how fp32 products run on the matrix cores: 'default' | 'exact' | 'bf16x9' | 'bf16x6'
         # (include/ampconv.h, dtype codes); inputs, outputs and accumulation are fp32 in every mode
         self.precision = 'default'
-        # how the dense fp32 projections run: 'fp32' | 'bf16x3' (functional.gemm_precision)
-        self.gemm_precision = 'fp32'
+        # how the per-node projections run: 'native' (default: libampconv's own kernels, csrc/proj_gemm.hip -- fp32
+        # operands split exactly into three bf16 terms, six partial products on the bf16 matrix cores, fp32
+        # accumulate; fp32 storage with embed_dim % 128 == 0, anything else falls to 'fp32') | 'fp32' (library
+        # GEMMs, rocBLAS) | 'bf16x3' (hipBLASLt's 3-product split, 8x the error) -- functional.gemm_precision
+        self.gemm_precision = os.environ.get('AMPCONV_GEMM', 'native')
         self.num_heads = num_heads
         self.embed_dim = embed_dim
         # parameter container only: same init RNG consumption and state-dict keys as the reference

@@ -35,7 +35,7 @@ def _ptr(t):
     return t.data_ptr() if t is not None else None
 
 
-GEMM_PRECISIONS = ('fp32', 'bf16x3')
+GEMM_PRECISIONS = ('native', 'fp32', 'bf16x3')
 # hand the softmax statistics of the destination pass to the source pass (AMPCONV_SOFTMAX_STATS=0:
 # both passes reduce their own; used by the tests to cross-check the two ways)
 SOFTMAX_STATS = os.environ.get('AMPCONV_SOFTMAX_STATS', '1') != '0'
@@ -60,8 +60,8 @@ def gemm_precision(mode):
     matters (tests/test_gpu_parity.py::test_gemm_precision_is_restored pins the restore)."""
     if mode not in GEMM_PRECISIONS:
         raise ValueError(f'gemm precision must be one of {GEMM_PRECISIONS}, got {mode!r}')
-    if mode == 'fp32':
-        yield
+    if mode in ('fp32', 'native'):      # 'native': libampconv's own projection kernels (proj_* below); what they
+        yield                           # do not serve (bf16 storage, D % 128 != 0) runs as plain library GEMMs
         return
     with _GEMM_SWITCH_LOCK:
         prev_env = os.environ.get('HIPBLASLT_ALLOW_TF32')
@@ -95,6 +95,52 @@ def _tn_matmul(a, b, chunks=128):
     if main < M:
         out += a[main:].t().mm(b[main:])
     return out
+
+
+# ---- the per-node projections in libampconv.so (csrc/proj_gemm.hip): fp32 operands split exactly into
+# three bf16 terms, six partial products on v_mfma_f32_32x32x16_bf16, fp32 accumulate
+def proj_native(gemm, dtype, D):
+    """Does the 'native' mode serve this layer?  fp32 storage, embed_dim a multiple of 128."""
+    return gemm == 'native' and dtype == torch.float32 and bool(_lib.load().ampconv_proj_supported(D, D))
+
+
+def proj_image(W, transpose=False):
+    """MFMA-fragment image of the fp32 weight W [R, C] (rows contiguous): of W itself for out = in @ W^T
+    (the forward direction of nn.Linear), of W^T for out = in @ W (its input gradient)."""
+    lib = _lib.load()
+    assert W.dim() == 2 and W.stride(1) == 1 and W.dtype == torch.float32
+    R, C = W.shape
+    N, K = (C, R) if transpose else (R, C)
+    sn, sk = (1, W.stride(0)) if transpose else (W.stride(0), 1)
+    img = torch.empty(lib.ampconv_proj_weight_image_bytes(N, K), dtype=torch.uint8, device=W.device)
+    _lib.check(lib.ampconv_proj_weight_image(W.data_ptr(), sn, sk, N, K, img.data_ptr(), _stream()),
+               'ampconv_proj_weight_image')
+    return img, N, K
+
+
+def proj_rows(a2, image, bias=None, rowptr=None, L=0):
+    """out[M, N] = (a2[M, K] @ B^T + bias) * [node of the row has an in-edge]  (mask only with rowptr)."""
+    lib = _lib.load()
+    img, N, K = image
+    assert a2.dim() == 2 and a2.size(1) == K and a2.stride(1) == 1 and a2.dtype == torch.float32
+    out = torch.empty(a2.size(0), N, dtype=torch.float32, device=a2.device)
+    _lib.check(lib.ampconv_proj_rows(a2.data_ptr(), a2.stride(0), a2.size(0), K, img.data_ptr(), N, _ptr(bias),
+                                     _ptr(rowptr), L, out.data_ptr(), N, _stream()), 'ampconv_proj_rows')
+    return out
+
+
+def proj_wgrad(a2, b2, dw, colsum=None, rowptr=None, L=0):
+    """dw[Na, Nb] = (mask * a2)^T @ b2 and colsum[Na] = column sums of mask * a2, into caller-owned (views of)
+    contiguous fp32 tensors; reduction over the rows in fixed slices (bitwise reproducible)."""
+    lib = _lib.load()
+    M, Na = a2.shape
+    Nb = b2.size(1)
+    assert b2.size(0) == M and dw.shape == (Na, Nb) and dw.is_contiguous() and a2.stride(1) == 1 and b2.stride(1) == 1
+    nws = lib.ampconv_proj_wgrad_workspace_bytes(M, Na, Nb)
+    ws = torch.empty(max(nws, 16) // 4, dtype=torch.float32, device=a2.device)
+    _lib.check(lib.ampconv_proj_wgrad(a2.data_ptr(), a2.stride(0), b2.data_ptr(), b2.stride(0), M, Na, Nb,
+                                      _ptr(rowptr), L, dw.data_ptr(), _ptr(colsum), ws.data_ptr(), nws, _stream()),
+               'ampconv_proj_wgrad')
 
 
 def edge_forward(Q, K, V, csr, n_rows, L, D, H, out2d, qidx=None, dtype=_lib.AMPCONV_F32):
@@ -132,24 +178,33 @@ class AMPConvFunction(torch.autograd.Function):
                                  'use float32 for this shape')
         Nq, Nk = xq.size(0), xkv.size(0)
         xq2 = xq.contiguous().view(Nq * L, D)
+        native = proj_native(gemm, xq.dtype, D)
         with torch.cuda.device(xq.device), gemm_precision(gemm):
             if shared:
-                qkv = torch.addmm(b_in, xq2, w_in.t())                     # [N*L, 3D]
+                qkv = (proj_rows(xq2, proj_image(w_in), b_in) if native
+                       else torch.addmm(b_in, xq2, w_in.t()))              # [N*L, 3D]
                 Qv, Kv, Vv = (_view(qkv, i * D, L, dh) for i in range(3))
                 xkv2 = xq2
                 kv = None
             else:
                 xkv2 = xkv.contiguous().view(Nk * L, D)
-                qkv = torch.addmm(b_in[:D], xq2, w_in[:D].t())             # [Nq*L, D]
-                kv = torch.addmm(b_in[D:], xkv2, w_in[D:].t())             # [Nk*L, 2D]
+                if native:
+                    qkv = proj_rows(xq2, proj_image(w_in[:D]), b_in[:D])
+                    kv = proj_rows(xkv2, proj_image(w_in[D:]), b_in[D:])
+                else:
+                    qkv = torch.addmm(b_in[:D], xq2, w_in[:D].t())         # [Nq*L, D]
+                    kv = torch.addmm(b_in[D:], xkv2, w_in[D:].t())         # [Nk*L, 2D]
                 Qv = _view(qkv, 0, L, dh)
                 Kv, Vv = _view(kv, 0, L, dh), _view(kv, D, L, dh)
             obar = torch.empty(Nq * L, D, dtype=xq.dtype, device=xq.device)
             edge_forward(Qv, Kv, Vv, csr, Nq, L, D, H, obar, dtype=dtype)
-            y = torch.addmm(b_out, obar, w_out.t())
-            io = _lib.AMPCONV_BF16 if y.dtype == torch.bfloat16 else _lib.AMPCONV_F32
-            rc = lib.ampconv_mask_rows(y.data_ptr(), csr.rowptr.data_ptr(), Nq, L * D, io, _stream())
-            _lib.check(rc, 'ampconv_mask_rows')
+            if native:      # bias and the in-degree mask (rows nobody sends to stay exactly 0) in the epilogue
+                y = proj_rows(obar, proj_image(w_out), b_out, csr.rowptr, L)
+            else:
+                y = torch.addmm(b_out, obar, w_out.t())
+                io = _lib.AMPCONV_BF16 if y.dtype == torch.bfloat16 else _lib.AMPCONV_F32
+                rc = lib.ampconv_mask_rows(y.data_ptr(), csr.rowptr.data_ptr(), Nq, L * D, io, _stream())
+                _lib.check(rc, 'ampconv_mask_rows')
         ctx.set_materialize_grads(False)     # no zero-filled [N*L, 3D] gradient for the qkv side output
         ctx.save_for_backward(xq2, xkv2, w_in, w_out, qkv, kv, obar)
         ctx.csr, ctx.dims, ctx.shared, ctx.dtype, ctx.gemm = csr, (Nq, Nk, L, D, H), shared, dtype, gemm
@@ -171,16 +226,23 @@ class AMPConvFunction(torch.autograd.Function):
         need_xq, need_xkv = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         with torch.cuda.device(dev), gemm_precision(ctx.gemm):
             dy2 = dy.contiguous().view(Nq * L, D)
+            native = proj_native(ctx.gemm, dy2.dtype, D)
             # out-projection: rows with no in-edge contribute nothing (their obar is 0, and
             # the bias gradient masks them explicitly)
-            scratch = torch.empty((1 + _lib.COLSUM_BLOCKS) * D, dtype=torch.float32, device=dev)
-            io = _lib.AMPCONV_BF16 if dy2.dtype == torch.bfloat16 else _lib.AMPCONV_F32
-            rc = lib.ampconv_masked_colsum(dy2.data_ptr(), csr.rowptr.data_ptr(), Nq, L, D,
-                                           scratch.data_ptr(), io, _stream())
-            _lib.check(rc, 'ampconv_masked_colsum')
-            db_out = scratch[:D].to(dy2.dtype)
-            dw_out = _tn_matmul(dy2, obar)
-            dobar = dy2.mm(w_out)                                          # [Nq*L, D]
+            if native:
+                dw_out = torch.empty_like(w_out)
+                db_out = torch.empty(D, dtype=torch.float32, device=dev)
+                proj_wgrad(dy2, obar, dw_out, db_out, csr.rowptr, L)
+                dobar = proj_rows(dy2, proj_image(w_out, transpose=True))
+            else:
+                scratch = torch.empty((1 + _lib.COLSUM_BLOCKS) * D, dtype=torch.float32, device=dev)
+                io = _lib.AMPCONV_BF16 if dy2.dtype == torch.bfloat16 else _lib.AMPCONV_F32
+                rc = lib.ampconv_masked_colsum(dy2.data_ptr(), csr.rowptr.data_ptr(), Nq, L, D,
+                                               scratch.data_ptr(), io, _stream())
+                _lib.check(rc, 'ampconv_masked_colsum')
+                db_out = scratch[:D].to(dy2.dtype)
+                dw_out = _tn_matmul(dy2, obar)
+                dobar = dy2.mm(w_out)                                      # [Nq*L, D]
             dOv = _view(dobar, 0, L, dh)
             if shared:
                 dqkv = torch.empty(Nq * L, 3 * D, dtype=dy2.dtype, device=dev)
@@ -215,10 +277,24 @@ class AMPConvFunction(torch.autograd.Function):
             # dY) Wo = db_out Wo: a [D] x [D, D] product instead of a second 20 GB reduction pass.  The K bias
             # shifts every score of a row equally, i.e. has gradient exactly 0 (torch's autograd returns ~1e-9 noise)
             db_v = None
-            if shared and dy2.dtype == torch.float32:
+            if shared and dy2.dtype == torch.float32 and not native:
                 db_v = scratch[:D] @ w_out
             del dobar, stats
-            if shared:
+            if native:
+                # weight and bias gradients in one pass each (the column sums ride on the rows the product reads
+                # anyway: all three thirds of in_proj_bias.grad are the true sums, as autograd's are)
+                dw_in = torch.empty_like(w_in)
+                db_in = torch.empty(3 * D, dtype=torch.float32, device=dev)
+                if shared:
+                    proj_wgrad(dqkv, xq2, dw_in, db_in)
+                    dxq = proj_rows(dqkv, proj_image(w_in, transpose=True)).view(Nq, L * D) if need_xq else None
+                    dxkv = None
+                else:
+                    proj_wgrad(dqkv, xq2, dw_in[:D], db_in[:D])
+                    proj_wgrad(dkv, xkv2, dw_in[D:], db_in[D:])
+                    dxq = proj_rows(dqkv, proj_image(w_in[:D], transpose=True)).view(Nq, L * D) if need_xq else None
+                    dxkv = proj_rows(dkv, proj_image(w_in[D:], transpose=True)).view(Nk, L * D) if need_xkv else None
+            elif shared:
                 dw_in = _tn_matmul(dqkv, xq2)
                 if db_v is not None:
                     db_in = torch.cat([dqkv[:, :D].sum(dim=0), torch.zeros_like(db_v), db_v])

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define AMPCONV_VERSION 101
+#define AMPCONV_VERSION 102
 
 enum {
   AMPCONV_OK = 0,
@@ -198,6 +198,37 @@ int ampconv_linear_apply(ampconv_view_t A, const float *M, int transpose, int64_
                          int D, int H, float scale, ampconv_view_t Out, void *stream);
 int ampconv_masked_colsum(const void *dY, const int32_t *rowptr, int64_t N,
                           int L, int D, float *out, int dtype, void *stream);
+
+/* ---- node phase: the per-node projections ---------------------------------------------------
+ * Replaces the packed in-projection (torch functional.py:5785-5862 `_in_projection_packed`; the
+ * reference's copy src/ampnet/conv/custom_multihead_attn_forward.py:4070-4077) and the
+ * out-projection (torch functional.py:6600), once per NODE instead of once per edge, and their
+ * autograd backward (dObar = dY Wo, dX = dQKV Win, dW = dOut^T In, db = colsum).
+ * fp32 in, fp32 out, fp32 accumulate; every operand element is split EXACTLY into three bf16 terms
+ * and a product is the sum of the six partial products of order >= 2^-16 on
+ * v_mfma_f32_32x32x16_bf16 (error of the dropped terms <= 3 * 2^-26 per product: fp32 grade).
+ *   proj_supported     : 1 if (N, K) is served (N % 128 == 0, K % 32 == 0), else 0 -- the caller
+ *                        then uses a library GEMM
+ *   proj_weight_image  : B[n][k] = W[n * stride_n + k * stride_k] (N x K) -> `image`
+ *                        (proj_weight_image_bytes(N, K) bytes, 16-byte aligned): the three bf16 planes
+ *                        of the weight as ready MFMA fragments.  (stride_n, stride_k) = (K, 1) uses a
+ *                        row-major [N, K] weight as it stands (forward), (1, N) its transpose (backward).
+ *   proj_rows          : out[m, :N] = (A[m, :K] B^T + bias) * (rowptr ? [node m / L has an in-edge] : 1)
+ *                        A row-major with leading dimension lda (elements), out with ldc
+ *   proj_wgrad         : dW[Na, Nb] = sum_m (mask_m A[m, :Na])^T B[m, :Nb] and colsum[Na] = sum_m mask_m A[m, :Na]
+ *                        (mask as above, rowptr may be NULL); deterministic: fixed row slices, ordered sum.
+ *                        `workspace`: proj_wgrad_workspace_bytes(M, Na, Nb) bytes.  */
+int ampconv_proj_supported(int N, int K);
+size_t ampconv_proj_weight_image_bytes(int N, int K);
+int ampconv_proj_weight_image(const float *W, int64_t stride_n, int64_t stride_k, int N, int K,
+                              void *image, void *stream);
+int ampconv_proj_rows(const float *A, int64_t lda, int64_t M, int K, const void *wimage, int N,
+                      const float *bias, const int32_t *rowptr, int L, float *out, int64_t ldc,
+                      void *stream);
+size_t ampconv_proj_wgrad_workspace_bytes(int64_t M, int Na, int Nb);
+int ampconv_proj_wgrad(const float *A, int64_t lda, const float *B, int64_t ldb, int64_t M, int Na,
+                       int Nb, const int32_t *rowptr, int L, float *dW, float *colsum,
+                       void *workspace, size_t workspace_bytes, void *stream);
 
 /* ---- GraphSAINT random-walk sampler ("next" row: the step before the hot path) -------------
  * In-tree spec: the reference's vendored PyG sampler, visualization/visualize_graphsaint_subgraphs.py

@@ -1,0 +1,164 @@
+"""Node-phase projection kernels (csrc/proj_gemm.hip) through the C ABI against fp64 products.
+
+What they replace: torch functional.py:5785-5862 (`_in_projection_packed`), :6600 (out-projection) and
+their autograd backward.  Tolerance: the kernels are fp32-grade by construction (operands split exactly
+into three bf16 terms, six partial products, fp32 accumulation), so the bar is the error of torch's own
+fp32 GEMM against the same fp64 product -- at most 2x it (plus one ulp of slack) -- not a loose absolute."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available()
+    return torch.device('cuda:0')
+
+
+def _err(x, ref):
+    return float((x.double() - ref).abs().max() / ref.abs().max())
+
+
+def _rowptr(n_nodes, empty, dev):
+    deg = torch.ones(n_nodes, dtype=torch.int32)
+    deg[list(empty)] = 0
+    rp = torch.zeros(n_nodes + 1, dtype=torch.int32)
+    rp[1:] = torch.cumsum(deg, 0)
+    return rp.to(dev), deg.bool()
+
+
+@pytest.mark.parametrize('M,K,N', [(5, 128, 128), (129, 128, 384), (1000, 256, 768), (4096, 768, 256),
+                                   (20 * 333, 256, 256), (777, 384, 128)])
+@pytest.mark.parametrize('transpose', [False, True])
+def test_proj_rows_matches_fp64(M, K, N, transpose):
+    from ampnet_amd.conv import functional as F_
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(M + K + N)
+    a = torch.randn(M, K, device=dev, generator=g)
+    W = torch.randn(*((K, N) if transpose else (N, K)), device=dev, generator=g) * 0.1
+    bias = torch.randn(N, device=dev, generator=g)
+    Wnk = W.t() if transpose else W
+    ref = a.double() @ Wnk.double().t() + bias.double()
+    out = F_.proj_rows(a, F_.proj_image(W, transpose=transpose), bias)
+    lib_err = _err(torch.addmm(bias, a, Wnk.t()), ref)
+    assert _err(out, ref) <= 2 * lib_err + 1e-7, (_err(out, ref), lib_err)
+    # no bias, bitwise reproducible
+    out2 = F_.proj_rows(a, F_.proj_image(W, transpose=transpose))
+    assert torch.equal(out2, F_.proj_rows(a, F_.proj_image(W, transpose=transpose)))
+    assert _err(out2, ref - bias.double()) <= 2 * lib_err + 1e-7
+
+
+def test_proj_rows_strided_input_and_sliced_weight():
+    # the non-shared path: w_in[:D] / w_in[D:] slices, inputs that are column blocks of a wider buffer
+    from ampnet_amd.conv import functional as F_
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(3)
+    D, M = 128, 300
+    w_in = torch.randn(3 * D, D, device=dev, generator=g) * 0.1
+    wide = torch.randn(M, 3 * D, device=dev, generator=g)
+    out = F_.proj_rows(wide[:, D:], F_.proj_image(w_in[D:], transpose=True))      # [M, 2D] @ [2D, D]
+    ref = wide[:, D:].double() @ w_in[D:].double()
+    assert _err(out, ref) < 1e-6
+
+
+@pytest.mark.parametrize('L,empty', [(20, (0, 7, 49)), (1, (3,)), (7, ())])
+def test_proj_rows_mask_gives_exact_zero_rows(L, empty):
+    from ampnet_amd.conv import functional as F_
+    dev = _dev()
+    n_nodes, K, N = 50, 128, 256
+    rp, has = _rowptr(n_nodes, empty, dev)
+    g = torch.Generator(device=dev).manual_seed(L)
+    a = torch.randn(n_nodes * L, K, device=dev, generator=g)
+    W = torch.randn(N, K, device=dev, generator=g) * 0.1
+    bias = torch.randn(N, device=dev, generator=g)
+    out = F_.proj_rows(a, F_.proj_image(W), bias, rp, L).view(n_nodes, L * N)
+    ref = (a.double() @ W.double().t() + bias.double()).view(n_nodes, L * N) * has.to(dev)[:, None]
+    assert _err(out, ref) < 1e-6
+    for n in empty:
+        assert (out[n] == 0).all()
+
+
+@pytest.mark.parametrize('M,Na,Nb', [(37, 128, 128), (20 * 271, 384, 128), (5000, 768, 256), (70001, 256, 256)])
+@pytest.mark.parametrize('masked', [False, True])
+def test_proj_wgrad_matches_fp64(M, Na, Nb, masked):
+    from ampnet_amd.conv import functional as F_
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(M + Na)
+    a = torch.randn(M, Na, device=dev, generator=g)
+    b = torch.randn(M, Nb, device=dev, generator=g)
+    L = 20 if M % 20 == 0 else 1
+    rp = flag = None
+    if masked:
+        rp, has = _rowptr(M // L, (0, 5, M // L - 1), dev)
+        flag = has.to(dev).repeat_interleave(L)[:, None].double()
+    am = a.double() * flag if masked else a.double()
+    ref_dw, ref_cs = am.t() @ b.double(), am.sum(0)
+    dw = torch.empty(Na, Nb, device=dev)
+    cs = torch.empty(Na, device=dev)
+    F_.proj_wgrad(a, b, dw, cs, rp, L)
+    lib_err = _err((a * flag.float() if masked else a).t() @ b, ref_dw)
+    assert _err(dw, ref_dw) <= 2 * lib_err + 1e-7, (_err(dw, ref_dw), lib_err)
+    assert float((cs.double() - ref_cs).abs().max()) <= 1e-6 * float(am.abs().sum(0).max()) + 1e-6
+    dw2 = torch.empty_like(dw)
+    cs2 = torch.empty_like(cs)
+    F_.proj_wgrad(a, b, dw2, cs2, rp, L)
+    assert torch.equal(dw, dw2) and torch.equal(cs, cs2)            # fixed slices, ordered sum
+
+
+def test_proj_wgrad_into_row_block_views():
+    # the non-shared path writes d in_proj_weight in two row blocks of one tensor
+    from ampnet_amd.conv import functional as F_
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(11)
+    D, M = 128, 999
+    dq, dkv = torch.randn(M, D, device=dev, generator=g), torch.randn(M, 2 * D, device=dev, generator=g)
+    x = torch.randn(M, D, device=dev, generator=g)
+    dw, db = torch.empty(3 * D, D, device=dev), torch.empty(3 * D, device=dev)
+    F_.proj_wgrad(dq, x, dw[:D], db[:D])
+    F_.proj_wgrad(dkv, x, dw[D:], db[D:])
+    ref = torch.cat([dq, dkv], 1).double().t() @ x.double()
+    assert _err(dw, ref) < 1e-6
+    assert _err(db, torch.cat([dq, dkv], 1).double().sum(0)) < 1e-6
+
+
+def test_unsupported_shapes_are_refused_not_miscomputed():
+    from ampnet_amd import _lib
+    lib = _lib.load()
+    assert lib.ampconv_proj_supported(256, 256) == 1 and lib.ampconv_proj_supported(768, 256) == 1
+    assert lib.ampconv_proj_supported(100, 100) == 0 and lib.ampconv_proj_supported(64, 64) == 0
+    assert lib.ampconv_proj_rows(None, 100, 10, 100, None, 100, None, None, 0, None, 100, None) == -1
+
+
+def test_layer_native_vs_library_gemm_error_table():
+    """The rule for the headline mode: against the fp64 oracle, 'native' may be at most 2x
+    the plain-fp32 path's error on y, dx and all four parameter gradients."""
+    import numpy as np
+    from ampnet_amd import AMPConv
+    from oracle.ampconv_numpy import AMPConvOracle
+    dev = _dev()
+    torch.manual_seed(5)
+    N, E, L, D, H = 400, 4800, 20, 256, 8
+    layer = AMPConv(D, H).to(dev)
+    with torch.no_grad():
+        layer.multi_head_attention.in_proj_bias.normal_(0, 0.1)
+        layer.multi_head_attention.out_proj.bias.normal_(0, 0.1)
+    g = torch.Generator().manual_seed(6)
+    x, dy = torch.randn(N, L * D, generator=g), torch.randn(N, L * D, generator=g)
+    ei = torch.randint(0, N, (2, E), generator=g)
+    m = layer.multi_head_attention
+    o = AMPConvOracle(*(p.detach().cpu().double().numpy() for p in (m.in_proj_weight, m.in_proj_bias,
+                                                                    m.out_proj.weight, m.out_proj.bias)), H)
+    y_ref, _ = o.forward(x.double().numpy(), ei.numpy())
+    refs = (y_ref,) + tuple(o.backward(dy.double().numpy()))
+    errs = {}
+    for mode in ('native', 'fp32'):
+        layer.gemm_precision = mode
+        layer.zero_grad(set_to_none=True)
+        xg = x.to(dev).requires_grad_(True)
+        y = layer(xg, ei.to(dev))
+        y.backward(dy.to(dev))
+        got = (y, xg.grad, m.in_proj_weight.grad, m.in_proj_bias.grad, m.out_proj.weight.grad, m.out_proj.bias.grad)
+        errs[mode] = [float(np.abs(t.detach().cpu().double().numpy() - r).max() / np.abs(r).max())
+                      for t, r in zip(got, refs)]
+    for en, ef in zip(errs['native'], errs['fp32']):
+        assert en <= 2 * ef + 2e-7, errs

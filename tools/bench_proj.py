@@ -1,0 +1,89 @@
+"""Developer micro-benchmark of the node-phase projection kernels (csrc/proj_gemm.hip) against the
+library GEMMs they replace, at the row count of a workload (default: cfg4, N*L = 2e7 rows, D = 256).
+
+    python tools/bench_proj.py [rows D] [--iters=5]
+
+Prints per GEMM: ms, fp32-equivalent TFLOP/s (2 M N K / t), bf16 MFMA TFLOP/s actually issued (x6),
+and the max error against an fp64 product on a row sample."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+from ampnet_amd.conv import functional as F_  # noqa: E402
+
+
+def timeit(fn, iters=5, warm=2):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    args = [a for a in sys.argv[1:] if not a.startswith('--')]
+    M, D = (int(args[0]), int(args[1])) if len(args) == 2 else (20_000_000, 256)
+    iters = 5
+    for a in sys.argv:
+        if a.startswith('--iters='):
+            iters = int(a.split('=')[1])
+    dev = torch.device('cuda:0')
+    torch.manual_seed(0)
+    x = torch.randn(M, D, device=dev)
+    w_in = torch.randn(3 * D, D, device=dev) * 0.06
+    b_in = torch.randn(3 * D, device=dev) * 0.1
+    w_out = torch.randn(D, D, device=dev) * 0.06
+    qkv = torch.empty(M, 3 * D, device=dev)
+    for r0 in range(0, M, 1 << 20):
+        qkv[r0:r0 + (1 << 20)] = torch.randn(min(1 << 20, M - r0), 3 * D, device=dev)
+    S = min(M, 4096)
+
+    def report(name, t, flops, err=None, terr=None):
+        print(f'{name:34s} {t:8.2f} ms  {flops / t / 1e9:7.1f} TF fp32-equiv  ({6 * flops / t / 1e9:7.0f} TF bf16 issued)'
+              + (f'  err {err:.2e} (library {terr:.2e})' if err is not None else ''), flush=True)
+
+    def err(a, ref):
+        return float((a.double() - ref).abs().max() / ref.abs().max())
+
+    # forward in-projection [M, D] x [D, 3D]
+    img = F_.proj_image(w_in)
+    t = timeit(lambda: F_.proj_rows(x, img, b_in), iters)
+    ref = x[:S].double() @ w_in.double().t() + b_in.double()
+    report('qkv  native', t, 2 * M * D * 3 * D, err(F_.proj_rows(x[:S], img, b_in), ref), err(torch.addmm(b_in, x[:S], w_in.t()), ref))
+    report('qkv  library (addmm)', timeit(lambda: torch.addmm(b_in, x, w_in.t()), iters), 2 * M * D * 3 * D)
+    # out-projection [M, D] x [D, D]
+    img_o = F_.proj_image(w_out)
+    report('out  native', timeit(lambda: F_.proj_rows(x, img_o, b_in[:D]), iters), 2 * M * D * D)
+    report('out  library (addmm)', timeit(lambda: torch.addmm(b_in[:D], x, w_out.t()), iters), 2 * M * D * D)
+    # dX = dQKV Win  [M, 3D] x [3D, D]
+    img_t = F_.proj_image(w_in, transpose=True)
+    t = timeit(lambda: F_.proj_rows(qkv, img_t), iters)
+    ref = qkv[:S].double() @ w_in.double()
+    report('dx   native', t, 2 * M * D * 3 * D, err(F_.proj_rows(qkv[:S], img_t), ref), err(qkv[:S].mm(w_in), ref))
+    report('dx   library (mm)', timeit(lambda: qkv.mm(w_in), iters), 2 * M * D * 3 * D)
+    # dW_in = dQKV^T X  [3D, M] x [M, D]
+    dw, cs = torch.empty(3 * D, D, device=dev), torch.empty(3 * D, device=dev)
+    t = timeit(lambda: F_.proj_wgrad(qkv, x, dw, cs), iters)
+    Mr = min(M, 1 << 18)
+    dwr, csr_ = torch.empty_like(dw), torch.empty_like(cs)
+    F_.proj_wgrad(qkv[:Mr], x[:Mr], dwr, csr_)
+    ref = qkv[:Mr].double().t() @ x[:Mr].double()
+    report('dWin native (+ colsum)', t, 2 * M * D * 3 * D, err(dwr, ref), err(qkv[:Mr].t().mm(x[:Mr]), ref))
+    report('dWin library (128-way bmm + sum)', timeit(lambda: F_._tn_matmul(qkv, x), iters), 2 * M * D * 3 * D)
+    dwo, cso = torch.empty(D, D, device=dev), torch.empty(D, device=dev)
+    report('dWo  native (+ colsum)', timeit(lambda: F_.proj_wgrad(x, x, dwo, cso), iters), 2 * M * D * D)
+    report('dWo  library', timeit(lambda: F_._tn_matmul(x, x), iters), 2 * M * D * D)
+    print('weight image (4 per step):', f'{timeit(lambda: F_.proj_image(w_in), 20):.4f} ms')
+
+
+if __name__ == '__main__':
+    main()
