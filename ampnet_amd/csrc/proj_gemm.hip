@@ -22,6 +22,7 @@
 //   proj_wgrad dW[Na, Nb] = A[M, Na]^T B[M, Nb], colsum(A)         (weight / bias gradients: reduction over
 //              the N*L node-token rows; both operands split on the fly, fragments by the hardware-transposing
 //              ds_read_b64_tr_b16; deterministic two-step reduction over row slices)
+#include <stdlib.h>
 #include <type_traits>
 #include "common.h"
 
@@ -84,11 +85,29 @@ __device__ __forceinline__ void dma16(const void *gsrc, unsigned lds_dst) {
                : "memory");
 }
 
+#ifdef AMPCONV_PROJ_STAMPS
+// diagnostic build (tools/stamp_proj.py): per-phase s_memtime sums of proj_rows_kernel, written to a device
+// buffer that nothing else reads; never part of the product build
+__device__ unsigned long long g_proj_stamps[8 * 4096];
+#define PSTAMP_DECL unsigned long long st_last, st_now, st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; \
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
+#define PSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); \
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_now)::"memory"); \
+  __builtin_amdgcn_sched_barrier(0); st_acc[i] += st_now - st_last; st_last = st_now; } while (0)
+#define PSTAMP_FLUSH(unit) do { if ((unit) < 4096 && threadIdx.x == 0) for (int i_ = 0; i_ < 8; ++i_) \
+  g_proj_stamps[(unit) * 8 + i_] = st_acc[i_]; } while (0)
+#else
+#define PSTAMP_DECL
+#define PSTAMP(i)
+#define PSTAMP_FLUSH(unit)
+#endif
+
 // ---------------------------------------------------------------------------------------------------
-// weight image: for k stage kt (32 deep), 32-column tile n32 of the OUTPUT, k step ks (16 deep), plane p:
-//   fragment ((kt * N/32 + n32) * 2 + ks) * 3 + p,  1 KiB, lane l = (r = l & 31, h = l >> 5) holds plane p of
-//   B[n32 * 32 + r][kt * 32 + ks * 16 + 8 h + 0..7]      with B[n][k] = W[n * stride_n + k * stride_k]
-// i.e. exactly the B operand of v_mfma_f32_32x32x16_bf16, in lane order.
+// weight image: for k step ks (16 deep), 32-column tile n32 of the OUTPUT, plane p:
+//   fragment (ks * N/32 + n32) * 3 + p,  1 KiB, lane l = (r = l & 31, h = l >> 5) holds plane p of
+//   B[n32 * 32 + r][ks * 16 + 8 h + 0..7]      with B[n][k] = W[n * stride_n + k * stride_k]
+// i.e. exactly the B operand of v_mfma_f32_32x32x16_bf16, in lane order; the fragments of one k step and one
+// block of columns are contiguous, so a stage is one linear LDS-DMA copy.
 __global__ void weight_image_kernel(const float *__restrict__ W, int64_t sn, int64_t sk, int N, int K,
                                     char *__restrict__ img) {
   const int k8s = K / 8;
@@ -104,17 +123,25 @@ __global__ void weight_image_kernel(const float *__restrict__ W, int64_t sn, int
     const Pair3 q = split_pair(x[2 * t], x[2 * t + 1]);
     pl[0][t] = q.h1; pl[1][t] = q.h2; pl[2][t] = q.h3;
   }
-  const int kt = k8 >> 2, ks = (k8 >> 1) & 1, h = k8 & 1, n32 = n >> 5, r = n & 31;
-  char *dst = img + ((size_t)((kt * (N / 32) + n32) * 2 + ks) * 3) * kFrag + (32 * h + r) * 16;
+  const int ks = k8 >> 1, h = k8 & 1, n32 = n >> 5, r = n & 31;
+  char *dst = img + ((size_t)(ks * (N / 32) + n32) * 3) * kFrag + (32 * h + r) * 16;
 #pragma unroll
   for (int p = 0; p < 3; ++p) *reinterpret_cast<i32x4 *>(dst + p * kFrag) = pl[p];
 }
 
 // ---------------------------------------------------------------------------------------------------
-// proj_rows: 128 x BN output tile per 256-thread workgroup (4 waves as 2 x 2, each 64 x BN/2), K in stages
-// of 32.  LDS per stage: A planes 24 KiB (one buffer: the next stage's rows wait in registers, split and
-// written between the two barriers), weight fragments BN/32 * 6 KiB (two buffers, filled by LDS-DMA a whole
-// compute phase ahead).  2 workgroups per CU cover each other's barriers, split phases and store tails.
+// proj_rows: BM x BN output tiles per workgroup of WM x WN waves (each (BM / WM) x (BN / WN)), K in steps of 16.
+// LDS: two buffers of {weight fragments BN / 32 * 3 KiB, A planes BM / 32 * 3 KiB}; ONE barrier per step: while a
+// step's fragments are multiplied, the next step's weight fragments arrive by LDS-DMA and the next step's rows
+// (loaded as whole 128-byte lines, 32 deep, one step ahead of their first use) are split and filed into the other
+// buffer, so a wave's vector / LDS / memory instructions sit in the shadow of its own and its SIMD partner's MFMAs.
+// Workgroups are PERSISTENT: one flat step loop over a strided list of tiles, the first fragments of the next tile
+// are on their way before the store tail of the current one.
+// What the shape is chosen by (in-kernel stamps, tools/stamp_proj.py): every vector-memory instruction a wave
+// issues (1-KiB row load, 1-KiB LDS-DMA piece, store) costs it ~100 cycles once all waves of a CU use the address
+// path, against 32 per MFMA: a 128 x 128 tile of four waves needs 0.38 of them per MFMA, 128 x 256 needs 0.19.
+// Output tiles leave through LDS as whole 128-byte row segments (dwordx4 stores: a quarter of the store
+// instructions of the C/D layout).
 struct RowsArgs {
   const float *A;
   int64_t lda;
@@ -126,165 +153,231 @@ struct RowsArgs {
   int L;
   float *out;
   int64_t ldc;
-  int row_tiles;              // ceil(M / 128)
+  int row_tiles;              // ceil(M / BM)
+  int64_t tiles;              // tile slots: row tiles rounded up to 8, times column tiles
 };
 
-constexpr int kBM = 128;
-constexpr int kStageA = (kBM / 32) * 2 * kTile3;     // 24 KiB
+constexpr int kXcd = 8;
 
-template <int BN>
-__global__ __launch_bounds__(256, 2) void proj_rows_kernel(RowsArgs a) {
-  constexpr int NTB = BN / 32;                 // 32-column tiles per workgroup
-  constexpr int NTW = NTB / 2;                 // ... per wave
-  constexpr int kStageB = NTB * 2 * kTile3;
-  constexpr int kPieces = kStageB / kFrag;     // 1-KiB DMA pieces per stage
-  // one LDS object: [B buffer 0][B buffer 1][A planes][row flags]; the DMA targets stay below 64 KiB
-  __shared__ __attribute__((aligned(16))) char smem[2 * kStageB + kStageA + kBM * 4];
-  char *sB = smem, *sA = smem + 2 * kStageB;
-  float *flags = reinterpret_cast<float *>(smem + 2 * kStageB + kStageA);
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 2 : 2) void proj_rows_kernel(RowsArgs a) {
+  constexpr int NW = WM * WN, NTHR = 64 * NW;
+  constexpr int MTB = BM / 32, NTB = BN / 32;          // 32-row / 32-column tiles per workgroup
+  constexpr int MTW = MTB / WM, NTW = NTB / WN;        // ... per wave
+  constexpr int kStepA = MTB * kTile3, kStepB = NTB * kTile3;
+  constexpr int kBuf = kStepB + kStepA;                // one buffer: [weight fragments][A planes]
+  constexpr int kPieces = kStepB / kFrag;              // 1-KiB DMA pieces per step
+  constexpr int NLH = BM * 4 / NTHR;                   // float4 row loads per thread and 16-deep half line
+  constexpr int kRowsPerLoad = NTHR / 4;
+  static_assert(kPieces % NW == 0 && NLH * NTHR == BM * 4 && kRowsPerLoad % 32 == 0, "tile / wave shape");
+  static_assert(NW * 4096 <= kBuf, "store staging lives in the consumed buffer");
+  // one LDS object: [buffer 0][buffer 1][row flags of the even / odd tile]
+  __shared__ __attribute__((aligned(16))) char smem[2 * kBuf + 2 * BM * 4];
+  float *flags = reinterpret_cast<float *>(smem + 2 * kBuf);
 
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wm = w >> 1, wn = w & 1;
-  // XCD-aware order: workgroups b, b + 8, b + 16 ... share an XCD (round-robin dispatch); give them the
-  // column tiles of ONE row tile so that its A rows are fetched into that XCD's L2 once
-  constexpr int kXcd = 8;
+  const int wm = w / WN, wn = w % WN;
   const int nct = a.N / BN;
-  const int b = blockIdx.x, xcd = b % kXcd, i_x = b / kXcd;
-  const int rt = (i_x / nct) * kXcd + xcd, ct = i_x % nct;
-  if (rt >= a.row_tiles) return;
-  const int64_t row0 = (int64_t)rt * kBM;
-  const int col0 = ct * BN;
-  const int KT = a.K / 32;
+  const int KS = a.K / 16;
 
-  if (t < kBM) {
-    float f = 1.f;
-    if (a.rowptr) {
-      const int64_t m = row0 + t < a.M ? row0 + t : a.M - 1;
-      const int64_t node = m / a.L;
-      f = a.rowptr[node + 1] != a.rowptr[node] ? 1.f : 0.f;
-    }
-    flags[t] = f;
-  }
-
-  // A rows of this thread: float4 column c of the 32-deep stage, row r0 of each of the four 32-row tiles
-  const int c = t & 7, r0 = t >> 3;
-  const float *arow[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int64_t m = row0 + 32 * i + r0;
-    m = m < a.M ? m : a.M - 1;
-    arow[i] = a.A + m * a.lda + 4 * c;
-  }
-  // where its split chunks go: fragment (tile i, k step c >> 2), slot 32 h + (r ^ (4 ks + 2 h)), half q
-  const int wks = c >> 2, wh = (c >> 1) & 1, wq = c & 1;
-  char *wdst = sA + wks * kTile3 + ((32 * wh + (r0 ^ (4 * wks + 2 * wh))) << 4) + 8 * wq;
+  // rows of this thread: float4 column c of a 16-deep half line, rows r0 + kRowsPerLoad * i
+  const int c = t & 3, r0 = t >> 2;
+  // where its split chunks go: fragment (32-row tile, plane), slot 32 h + (r ^ 4 h), half q  (conflict-free
+  // 8-byte stores and 16-byte fragment reads: tools/lds_layout_check.py, entry proj)
+  const int wh = c >> 1, wq = c & 1;
+  const int wdst = kStepB + (r0 >> 5) * kTile3 + ((32 * wh + ((r0 & 31) ^ (4 * wh))) << 4) + 8 * wq;
+  constexpr int kWStep = (kRowsPerLoad / 32) * kTile3;         // LDS bytes between the tiles of loads i, i + 1
   // fragment reads: lane (r = lane & 31, h = lane >> 5)
   const int fr = lane & 31, fh = lane >> 5;
-  const char *ardp[2];
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks)
-    ardp[ks] = sA + (2 * wm) * 2 * kTile3 + ks * kTile3 + ((32 * fh + (fr ^ (4 * ks + 2 * fh))) << 4);
-  const char *brdp = sB + (NTW * wn) * 2 * kTile3 + lane * 16;
+  const int ard = kStepB + (MTW * wm) * kTile3 + ((32 * fh + (fr ^ (4 * fh))) << 4);
+  const int brd = (NTW * wn) * kTile3 + lane * 16;
+  const size_t wstep = (size_t)(a.N / 32) * kTile3;            // bytes of one k step of the whole image
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_char *)smem;
 
-  // weight image of this column block: stage kt = kPieces KiB at ((kt * N/32 + col0/32) * 6) KiB
-  const char *wsrc = a.wimg + (size_t)(col0 / 32) * 2 * kTile3 + lane * 16;
-  const size_t wstage = (size_t)(a.N / 32) * 2 * kTile3;
-  const unsigned sB_lds = (unsigned)(uintptr_t)(lds_char *)sB;
-
-  auto dma_stage = [&](int kt) {
-    const unsigned dst = sB_lds + (kt & 1) * kStageB;
+  // tile slot u -> (row tile, column tile).  Workgroups b, b + 8, ... share an XCD (round-robin dispatch, speed
+  // only): consecutive slots of one XCD are the column tiles of ONE row tile, whose rows then come from its L2
+  struct Tile {
+    int64_t row0;
+    int col0;
+    bool valid;
+  };
+  auto tile_of = [&](int64_t u) {
+    Tile tl;
+    const int64_t i_x = u / kXcd;
+    const int64_t rt = (i_x / nct) * kXcd + u % kXcd;
+    tl.row0 = rt * BM;
+    tl.col0 = (int)(i_x % nct) * BN;
+    tl.valid = u < a.tiles && rt < a.row_tiles;
+    return tl;
+  };
+  auto dma_step = [&](const Tile &tl, int ks, int buf) {
+    const char *src = a.wimg + (size_t)(tl.col0 / 32) * kTile3 + (size_t)ks * wstep + lane * 16;
+    const unsigned dst = lds0 + buf * kBuf;
 #pragma unroll
-    for (int j = 0; j < kPieces / 4; ++j) {
-      const int piece = w + 4 * j;
-      dma16(wsrc + (size_t)kt * wstage + piece * kFrag, dst + piece * kFrag);
+    for (int j = 0; j < kPieces / NW; ++j) {
+      const int piece = w + NW * j;
+      dma16(src + piece * kFrag, dst + piece * kFrag);
     }
   };
-
-  f32x16 acc[2][NTW];
+  // rows of the thread in the NEXT line block to request (advanced 32 floats per block, re-based at a tile seam)
+  const float *rp[NLH];
+  auto rebase = [&](const Tile &tl) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NLH; ++i) {
+      int64_t m = tl.row0 + kRowsPerLoad * i + r0;
+      m = m < a.M ? m : a.M - 1;
+      rp[i] = a.A + m * a.lda + 4 * c;
+    }
+  };
+  float4 x[2][NLH];                     // one 32-deep line block of the thread's rows: [half][row]
+  auto load_rows = [&]() {
 #pragma unroll
-    for (int j = 0; j < NTW; ++j)
+    for (int i = 0; i < NLH; ++i) {
+      x[0][i] = *reinterpret_cast<const float4 *>(rp[i]);
+      x[1][i] = *reinterpret_cast<const float4 *>(rp[i] + 16);
+      rp[i] += 32;
+    }
+  };
+  auto split_rows = [&](auto half, int buf) {       // `half` is a compile-time constant: x stays in registers
+    char *base = smem + buf * kBuf + wdst;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  float4 x[4];
-  dma_stage(0);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) x[i] = *reinterpret_cast<const float4 *>(arow[i]);
-
-  for (int kt = 0; kt < KT; ++kt) {
-    // split this stage's rows and file them as MFMA fragments
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const Pair3 p0 = split_pair(x[i].x, x[i].y), p1 = split_pair(x[i].z, x[i].w);
-      char *d = wdst + i * 2 * kTile3;
+    for (int i = 0; i < NLH; ++i) {
+      const float4 v = x[decltype(half)::value][i];
+      const Pair3 p0 = split_pair(v.x, v.y), p1 = split_pair(v.z, v.w);
+      char *d = base + i * kWStep;
       *reinterpret_cast<i32x2 *>(d) = i32x2{p0.h1, p1.h1};
       *reinterpret_cast<i32x2 *>(d + kFrag) = i32x2{p0.h2, p1.h2};
       *reinterpret_cast<i32x2 *>(d + 2 * kFrag) = i32x2{p0.h3, p1.h3};
     }
-    // this stage's weight fragments were requested one compute phase ago
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (kt + 1 < KT) {
-      dma_stage(kt + 1);
+  };
+  f32x16 acc[MTW][NTW];
+  auto compute = [&](int buf) {
+    const char *bb = smem + buf * kBuf;
+    i32x4 bf[NTW][3];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) x[i] = *reinterpret_cast<const float4 *>(arow[i] + 32 * (kt + 1));
+    for (int j = 0; j < NTW; ++j)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) bf[j][p] = *reinterpret_cast<const i32x4 *>(bb + brd + j * kTile3 + p * kFrag);
+#pragma unroll
+    for (int i = 0; i < MTW; ++i) {
+      i32x4 af[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) af[p] = *reinterpret_cast<const i32x4 *>(bb + ard + i * kTile3 + p * kFrag);
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) acc[i][j] = mfma6(af, bf[j], acc[i][j]);
     }
-    const char *bcur = brdp + (kt & 1) * kStageB;
+  };
+
+  PSTAMP_DECL
+  int64_t u = blockIdx.x;
+  Tile cur = tile_of(u);
+  if (!cur.valid) return;        // slots are ordered: nothing further for this workgroup either
+  Tile nxt = tile_of(u + gridDim.x);
+  int par = 0;                   // parity of the tile (row flags)
+  const int KB = a.K / 32;       // line blocks per tile; a tile is 2 KB steps, so step parity = buffer, statically
+  rebase(cur);
+  dma_step(cur, 0, 0);
+  load_rows();
+  split_rows(std::integral_constant<int, 0>{}, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  for (;;) {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      i32x4 af[2][3], bf[NTW][3];
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-          af[i][p] = *reinterpret_cast<const i32x4 *>(ardp[ks] + i * 2 * kTile3 + p * kFrag);
+    for (int i = 0; i < MTW; ++i)
 #pragma unroll
       for (int j = 0; j < NTW; ++j)
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
-          bf[j][p] = *reinterpret_cast<const i32x4 *>(bcur + (2 * j + ks) * kTile3 + p * kFrag);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < NTW; ++j) acc[i][j] = mfma6(af[i], bf[j], acc[i][j]);
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    if (t < BM) {
+      float f = 1.f;
+      if (a.rowptr) {
+        const int64_t m = cur.row0 + t < a.M ? cur.row0 + t : a.M - 1;
+        const int64_t node = m / a.L;
+        f = a.rowptr[node + 1] != a.rowptr[node] ? 1.f : 0.f;
+      }
+      flags[par * BM + t] = f;
     }
-    // every wave is done with the A planes (and with weight buffer kt & 1) before they are overwritten
+    for (int kb = 0; kb < KB; ++kb) {
+      // ---- even step (fragments in buffer 0): the odd step's weight fragments by DMA, its rows = the second half
+      // of the line block in registers; then the block is used up and the next one is requested
+      PSTAMP(0);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // buffer 0 complete, buffer 1 free
+      PSTAMP(1);
+      dma_step(cur, 2 * kb + 1, 1);
+      compute(0);
+      split_rows(std::integral_constant<int, 1>{}, 1);
+      const bool last = kb + 1 == KB;
+      if (last) rebase(nxt);
+      const bool request = !last || nxt.valid;      // workgroup-uniform
+      if (request) {
+        load_rows();
+        // the DMA pieces have had the compute phase to land; the row loads requested after them stay in flight
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLH) : "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      PSTAMP(2);
+      // ---- odd step (buffer 1): next even step's fragments (this tile's, or step 0 of the next tile; past the
+      // end of the work list the refill is harmless and keeps the step free of branches)
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      PSTAMP(3);
+      dma_step(last ? (nxt.valid ? nxt : cur) : cur, last ? 0 : 2 * kb + 2, 0);
+      compute(1);
+      split_rows(std::integral_constant<int, 0>{}, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      PSTAMP(4);
+    }
+    // store tail.  C/D register e of lane (col = lane & 31, hi = lane >> 5) is row (e & 3) + 8 (e >> 2) + 4 hi of a
+    // 32 x 32 tile: bias and row mask applied in that layout, then the tile goes through a wave-private 4 KiB of
+    // LDS -- inside buffer 1, which the last step consumed: free once every wave has passed the barrier below, and
+    // not refilled before the next even step's barrier -- and leaves as 8 rows x 128 bytes per store instruction.
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  }
-
-  // epilogue: C/D register e of lane (col = lane & 31, hi = lane >> 5) is row (e & 3) + 8 (e >> 2) + 4 hi
-  auto store_tile = [&](auto ragged) {
+    {
+      const float *fl_t = flags + par * BM;
+      float *stage = reinterpret_cast<float *>(smem + kBuf + w * 4096);
+      const int sr = lane >> 3, sc4 = lane & 7;
+      auto store_tile = [&](auto ragged) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int rl0 = (2 * wm + i) * 32 + 4 * fh;
-      float fl[16];
+        for (int i = 0; i < MTW; ++i) {
+          const int rl0 = (MTW * wm + i) * 32;
+          float fl[16];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4 f4 = *reinterpret_cast<const float4 *>(flags + rl0 + 8 * g);
-        fl[4 * g] = f4.x; fl[4 * g + 1] = f4.y; fl[4 * g + 2] = f4.z; fl[4 * g + 3] = f4.w;
-      }
+          for (int g = 0; g < 4; ++g) {
+            const float4 f4 = *reinterpret_cast<const float4 *>(fl_t + rl0 + 4 * fh + 8 * g);
+            fl[4 * g] = f4.x; fl[4 * g + 1] = f4.y; fl[4 * g + 2] = f4.z; fl[4 * g + 3] = f4.w;
+          }
 #pragma unroll
-      for (int j = 0; j < NTW; ++j) {
-        const int col = col0 + (NTW * wn + j) * 32 + fr;
-        const float bj = a.bias ? a.bias[col] : 0.f;
-        float *o = a.out + (row0 + rl0) * a.ldc + col;
+          for (int j = 0; j < NTW; ++j) {
+            const int colt = cur.col0 + (NTW * wn + j) * 32;
+            const float bj = a.bias ? a.bias[colt + fr] : 0.f;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int dr = (e & 3) + 8 * (e >> 2);
-          const float v = (acc[i][j][e] + bj) * fl[e];
-          if (!decltype(ragged)::value || row0 + rl0 + dr < a.M) o[(int64_t)dr * a.ldc] = v;
+            for (int e = 0; e < 16; ++e)
+              stage[((e & 3) + 8 * (e >> 2) + 4 * fh) * 32 + fr] = (acc[i][j][e] + bj) * fl[e];
+            float *o = a.out + (cur.row0 + rl0 + sr) * a.ldc + colt + 4 * sc4;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const float4 v = *reinterpret_cast<const float4 *>(stage + (sr + 8 * g) * 32 + 4 * sc4);
+              if (!decltype(ragged)::value || cur.row0 + rl0 + sr + 8 * g < a.M)
+                *reinterpret_cast<float4 *>(o + (int64_t)(8 * g) * a.ldc) = v;
+            }
+          }
         }
-      }
+      };
+      if (cur.row0 + BM <= a.M)            // workgroup-uniform: only the last row tile is ragged
+        store_tile(std::false_type{});
+      else
+        store_tile(std::true_type{});
     }
-  };
-  if (row0 + kBM <= a.M)            // workgroup-uniform: only the last row tile is ragged
-    store_tile(std::false_type{});
-  else
-    store_tile(std::true_type{});
+    PSTAMP(6);
+    if (!nxt.valid) break;
+    cur = nxt;
+    u += gridDim.x;
+    nxt = tile_of(u + gridDim.x);
+    par ^= 1;
+  }
+  PSTAMP_FLUSH(blockIdx.x);
 }
-
 
 // ---------------------------------------------------------------------------------------------------
 // proj_wgrad: dW[Na, Nb] = sum over the rows m of A[m, :]^T B[m, :] (+ column sums of A).  The contraction
@@ -318,21 +411,23 @@ __device__ __forceinline__ i32x4 tr_frag(const char *p0, const char *p1) {
   return i32x4{ai[0], ai[1], bi[0], bi[1]};
 }
 
-template <int TJ, bool MASK>
-__global__ __launch_bounds__(256, 2) void proj_wgrad_kernel(WgradArgs a) {
-  constexpr int TI = 128;
+template <int TI, int TJ, int WI, int WJ, bool MASK>
+__global__ __launch_bounds__(64 * WI * WJ, 2) void proj_wgrad_kernel(WgradArgs a) {
+  constexpr int NW = WI * WJ, NTHR = 64 * NW;
   constexpr int kRowA = TI * 2, kRowB = TJ * 2;             // bytes per image row
   constexpr int kPlaneA = kRS * kRowA, kPlaneB = kRS * kRowB;
   constexpr int kStage = 3 * (kPlaneA + kPlaneB);
-  constexpr int NJW = TJ / 64;                              // 32-column tiles of B per wave (2 x 2 waves)
-  constexpr int NLB = TJ / 64;                              // float4 loads of B per thread and stage
+  constexpr int NIW = TI / 32 / WI, NJW = TJ / 32 / WJ;     // 32-column tiles of A / B per wave
+  constexpr int kColsA4 = TI / 4, kColsB4 = TJ / 4;         // float4 per tile row
+  constexpr int kRowsA = NTHR / kColsA4, kRowsB = NTHR / kColsB4;   // rows covered by one load of the workgroup
+  constexpr int NLA = kRS / kRowsA, NLB = kRS / kRowsB;     // float4 loads per thread and stage
+  static_assert(NLA * kRowsA == kRS && NLB * kRowsB == kRS && kRowsA * kColsA4 * 16 <= 2 * kStage, "tile shape");
   __shared__ __attribute__((aligned(16))) char smem[2 * kStage];
 
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int wi = w >> 1, wj = w & 1;
+  const int wi = w / WJ, wj = w % WJ;
   const int ntj = a.Nb / TJ, ntiles = (a.Na / TI) * ntj;
-  constexpr int kXcd = 8;
   const int b = blockIdx.x, xcd = b % kXcd, i_x = b / kXcd;
   const int slice = (i_x / ntiles) * kXcd + xcd, tile = i_x % ntiles;
   if (slice >= a.S) return;
@@ -341,18 +436,16 @@ __global__ __launch_bounds__(256, 2) void proj_wgrad_kernel(WgradArgs a) {
   const int64_t m1 = m0 + a.rows_per_slice < a.M ? m0 + a.rows_per_slice : a.M;
   const int ns = (int)((m1 - m0 + kRS - 1) / kRS);
 
-  // loads: A rows ra, ra + 8 (float4 column ca of 32), B rows rb + 4 i (float4 column cb of TJ / 4)
-  const int ca = t & 31, ra = t >> 5;
-  constexpr int kColsB4 = TJ / 4;
+  // loads: A rows ra + kRowsA i (float4 column ca), B rows rb + kRowsB i (float4 column cb)
+  const int ca = t % kColsA4, ra = t / kColsA4;
   const int cb = t % kColsB4, rb = t / kColsB4;
-  constexpr int kRowsB = 256 / kColsB4;                     // rows of B covered by one load of the workgroup
   const float *pa = a.A + (int64_t)ti * TI + 4 * ca;
   const float *pb = a.B + (int64_t)tj * TJ + 4 * cb;
   // plane stores: 8 bytes at row r, byte (8 c) ^ ((r & 3) << 6)
-  int wa[2], wb[NLB];
+  int wa[NLA], wb[NLB];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int r = ra + 8 * i;
+  for (int i = 0; i < NLA; ++i) {
+    const int r = ra + kRowsA * i;
     wa[i] = r * kRowA + ((8 * ca) ^ ((r & 3) << 6));
   }
 #pragma unroll
@@ -363,24 +456,24 @@ __global__ __launch_bounds__(256, 2) void proj_wgrad_kernel(WgradArgs a) {
   // transposed reads: lane = (h = lane >> 5, gi = (lane >> 4) & 1, q = (lane >> 2) & 3, p = lane & 3) addresses
   // row 8 h + 4 u + q, columns 32 tile + 16 gi + 4 p .. + 3 (u = 0, 1: the two halves of the 8-deep k group)
   const int fh = lane >> 5, gi = (lane >> 4) & 1, q = (lane >> 2) & 3, pp = lane & 3, fr = lane & 31;
-  const int rdA = (8 * fh + q) * kRowA + (q << 6) + 32 * gi + 8 * pp;       // ^ (tile << 6), + 4 * kRowA for u = 1
+  const int rdA = (8 * fh + q) * kRowA + (q << 6) + 32 * gi + 8 * pp;       // ^ (tile & 3) << 6, + (tile >> 2) << 8
   const int rdB = 3 * kPlaneA + (8 * fh + q) * kRowB + (q << 6) + 32 * gi + 8 * pp;
 
-  f32x16 acc[2][NJW];
+  f32x16 acc[NIW][NJW];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NIW; ++i)
 #pragma unroll
     for (int j = 0; j < NJW; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
   float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  float4 xa[2], xb[NLB];
+  float4 xa[NLA], xb[NLB];
   auto load_stage = [&](int s) {
     const int64_t mb = m0 + (int64_t)s * kRS;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int64_t m = mb + ra + 8 * i;
+    for (int i = 0; i < NLA; ++i) {
+      const int64_t m = mb + ra + kRowsA * i;
       const int64_t mc = m < m1 ? m : m1 - 1;
       xa[i] = *reinterpret_cast<const float4 *>(pa + mc * a.lda);
       float f = m < m1 ? 1.f : 0.f;
@@ -402,7 +495,7 @@ __global__ __launch_bounds__(256, 2) void proj_wgrad_kernel(WgradArgs a) {
   for (int s = 0; s < ns; ++s) {
     char *buf = smem + (s & 1) * kStage;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NLA; ++i) {
       cs.x += xa[i].x; cs.y += xa[i].y; cs.z += xa[i].z; cs.w += xa[i].w;
       const Pair3 p0 = split_pair(xa[i].x, xa[i].y), p1 = split_pair(xa[i].z, xa[i].w);
       char *d = buf + wa[i];
@@ -420,13 +513,7 @@ __global__ __launch_bounds__(256, 2) void proj_wgrad_kernel(WgradArgs a) {
     }
     if (s + 1 < ns) load_stage(s + 1);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    i32x4 af[2][3], bf[NJW][3];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const char *r0 = buf + (rdA ^ ((2 * wi + i) << 6));
-#pragma unroll
-      for (int p = 0; p < 3; ++p) af[i][p] = tr_frag(r0 + p * kPlaneA, r0 + p * kPlaneA + 4 * kRowA);
-    }
+    i32x4 bf[NJW][3];
 #pragma unroll
     for (int j = 0; j < NJW; ++j) {
       const int jt = NJW * wj + j;
@@ -435,32 +522,38 @@ __global__ __launch_bounds__(256, 2) void proj_wgrad_kernel(WgradArgs a) {
       for (int p = 0; p < 3; ++p) bf[j][p] = tr_frag(r0 + p * kPlaneB, r0 + p * kPlaneB + 4 * kRowB);
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NIW; ++i) {
+      const int it = NIW * wi + i;
+      const char *r0 = buf + ((rdA + ((it >> 2) << 8)) ^ ((it & 3) << 6));
+      i32x4 af[3];
 #pragma unroll
-      for (int j = 0; j < NJW; ++j) acc[i][j] = mfma6(af[i], bf[j], acc[i][j]);
+      for (int p = 0; p < 3; ++p) af[p] = tr_frag(r0 + p * kPlaneA, r0 + p * kPlaneA + 4 * kRowA);
+#pragma unroll
+      for (int j = 0; j < NJW; ++j) acc[i][j] = mfma6(af, bf[j], acc[i][j]);
+    }
   }
 
   // partial tile of this slice
   float *part = a.part + (size_t)slice * ((size_t)a.Na * a.Nb + a.Na);
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NIW; ++i)
 #pragma unroll
     for (int j = 0; j < NJW; ++j) {
-      float *o = part + (size_t)(ti * TI + (2 * wi + i) * 32 + 4 * fh) * a.Nb + tj * TJ + (NJW * wj + j) * 32 + fr;
+      float *o = part + (size_t)(ti * TI + (NIW * wi + i) * 32 + 4 * fh) * a.Nb + tj * TJ + (NJW * wj + j) * 32 + fr;
 #pragma unroll
       for (int e = 0; e < 16; ++e) o[(size_t)((e & 3) + 8 * (e >> 2)) * a.Nb] = acc[i][j][e];
     }
   if (tj == 0) {
-    // column sums of the A tile: 8 row-threads per float4 column, added through LDS in a fixed order
+    // column sums of the A tile: kRowsA row-threads per float4 column, added through LDS in a fixed order
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     float4 *red = reinterpret_cast<float4 *>(smem);
-    red[ra * 32 + ca] = cs;
+    red[ra * kColsA4 + ca] = cs;
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    if (t < 32) {
+    if (t < kColsA4) {
       float4 sum = red[t];
 #pragma unroll
-      for (int r = 1; r < 8; ++r) {
-        const float4 v = red[r * 32 + t];
+      for (int r = 1; r < kRowsA; ++r) {
+        const float4 v = red[r * kColsA4 + t];
         sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
       }
       *reinterpret_cast<float4 *>(part + (size_t)a.Na * a.Nb + ti * TI + 4 * t) = sum;
@@ -487,14 +580,19 @@ __global__ void wgrad_reduce_kernel(const float *__restrict__ part, int S, int64
 struct WgradPlan {
   int S;
   int64_t rows_per_slice;
-  int tj;
+  int ti, tj;
 };
 inline WgradPlan wgrad_plan(int64_t M, int Na, int Nb) {
   WgradPlan p;
   p.tj = Nb % 256 == 0 ? 256 : 128;
-  const int64_t ntiles = (int64_t)(Na / 128) * (Nb / p.tj);
+  p.ti = (Na % 256 == 0 && p.tj == 256) ? 256 : 128;       // 256 x 256: eight waves, one workgroup per CU
+  const int64_t ntiles = (int64_t)(Na / p.ti) * (Nb / p.tj);
   const int64_t nstages = (M + kRS - 1) / kRS;
-  int64_t S = 512 / ntiles;                    // about two workgroups per CU in one round
+  // one round of workgroups: slices are dealt to the 8 XCDs in turn (round-robin dispatch) and every slice brings
+  // `ntiles` workgroups, so an XCD's 32 CUs (x 2 for the 4-wave shapes) hold floor(32 / ntiles) slices each --
+  // one slice more on some XCDs would run as a second round and double the time
+  const int per_xcd = (p.ti == 256 ? 1 : 2) * 32;
+  int64_t S = (int64_t)kXcd * (per_xcd / ntiles > 0 ? per_xcd / ntiles : 1);
   if (S < 1) S = 1;
   if (S > nstages) S = nstages > 0 ? nstages : 1;
   p.rows_per_slice = ((nstages + S - 1) / S) * kRS;
@@ -531,12 +629,29 @@ extern "C" int ampconv_proj_rows(const float *A, int64_t lda, int64_t M, int K, 
   if (M == 0) return AMPCONV_OK;
   if (!A || !wimage || !out || (uintptr_t)A % 16 || (uintptr_t)wimage % 16) return AMPCONV_E_BADARG;
   if (rowptr && L <= 0) return AMPCONV_E_BADARG;
-  const int64_t rts = (M + kBM - 1) / kBM;
+  if (ldc % 4 || (uintptr_t)out % 16) return AMPCONV_E_BADARG;
+  // tile shape (developer switch AMPCONV_PROJ_ROWS: 0 = 256 x 256 tile of 8 waves where N allows, 1 = 128 x 128 of 4)
+  static const int variant = [] {
+    const char *e = getenv("AMPCONV_PROJ_ROWS");
+    return e ? atoi(e) : 0;
+  }();
+  const int shape = N % 256 ? 2 : variant;             // 0: 128 x 256 / 4 waves, 1: 256 x 256 / 8 waves, 2: 128 x 128 / 4 waves
+  const int bm = shape == 1 ? 256 : 128, bn = shape == 2 ? 128 : 256;
+  const int64_t rts = (M + bm - 1) / bm;
   if (rts > (int64_t)INT32_MAX / 64) return AMPCONV_E_BADARG;
-  RowsArgs a{A, lda, M, K, N, (const char *)wimage, bias, rowptr, L, out, ldc, (int)rts};
   const int64_t rtp = (rts + 7) / 8 * 8;
-  const int nct = N / 128;
-  proj_rows_kernel<128><<<(unsigned)(rtp * nct), 256, 0, (hipStream_t)stream>>>(a);
+  RowsArgs a{A, lda, M, K, N, (const char *)wimage, bias, rowptr, L, out, ldc, (int)rts, rtp * (N / bn)};
+  static const int n_cu = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n;
+  }();
+  int64_t grid = (int64_t)n_cu * (shape == 1 ? 1 : 2);
+  if (grid > a.tiles) grid = a.tiles;
+  hipStream_t st = (hipStream_t)stream;
+  if (shape == 0) proj_rows_kernel<128, 256, 2, 2><<<(unsigned)grid, 256, 0, st>>>(a);
+  else if (shape == 1) proj_rows_kernel<256, 256, 2, 4><<<(unsigned)grid, 512, 0, st>>>(a);
+  else proj_rows_kernel<128, 128, 2, 2><<<(unsigned)grid, 256, 0, st>>>(a);
   return ampconv_launch_status();
 }
 
@@ -565,16 +680,25 @@ extern "C" int ampconv_proj_wgrad(const float *A, int64_t lda, const float *B, i
   const size_t n_all = (size_t)Na * Nb + Na;
   if (workspace_bytes < (size_t)p.S * n_all * sizeof(float)) return AMPCONV_E_WORKSPACE;
   WgradArgs a{A, lda, B, ldb, M, Na, Nb, rowptr, L, (float *)workspace, p.S, p.rows_per_slice};
-  const int ntiles = (Na / 128) * (Nb / p.tj);
+  const int ntiles = (Na / p.ti) * (Nb / p.tj);
   const unsigned grid = (unsigned)(((p.S + 7) / 8 * 8) * ntiles);
-  if (p.tj == 256) {
-    if (rowptr) proj_wgrad_kernel<256, true><<<grid, 256, 0, st>>>(a);
-    else proj_wgrad_kernel<256, false><<<grid, 256, 0, st>>>(a);
+  if (p.ti == 256) {
+    if (rowptr) proj_wgrad_kernel<256, 256, 2, 4, true><<<grid, 512, 0, st>>>(a);
+    else proj_wgrad_kernel<256, 256, 2, 4, false><<<grid, 512, 0, st>>>(a);
+  } else if (p.tj == 256) {
+    if (rowptr) proj_wgrad_kernel<128, 256, 2, 2, true><<<grid, 256, 0, st>>>(a);
+    else proj_wgrad_kernel<128, 256, 2, 2, false><<<grid, 256, 0, st>>>(a);
   } else {
-    if (rowptr) proj_wgrad_kernel<128, true><<<grid, 256, 0, st>>>(a);
-    else proj_wgrad_kernel<128, false><<<grid, 256, 0, st>>>(a);
+    if (rowptr) proj_wgrad_kernel<128, 128, 2, 2, true><<<grid, 256, 0, st>>>(a);
+    else proj_wgrad_kernel<128, 128, 2, 2, false><<<grid, 256, 0, st>>>(a);
   }
   wgrad_reduce_kernel<<<(unsigned)((n_all / 4 + 255) / 256), 256, 0, st>>>((const float *)workspace, p.S,
                                                                           (int64_t)Na * Nb, (int64_t)n_all, dW, colsum);
   return ampconv_launch_status();
 }
+
+#ifdef AMPCONV_PROJ_STAMPS
+extern "C" int ampconv_debug_read_proj_stamps(unsigned long long *host_out, int n) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_proj_stamps), sizeof(unsigned long long) * n);
+}
+#endif

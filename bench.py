@@ -10,7 +10,7 @@ shape (one-subgraph-per-GPU data parallelism, weak scaling) and the parameter
 gradients are averaged with one RCCL all-reduce per step inside the timed
 region (experiments/cora_benchmark_graphsaint_distributed.py:63-94 as intended).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg4|cfg3|cfg5|cora|tiny] [--dtype f32|bf16] [--gemm fp32|bf16x3]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg4|cfg3|cfg5|cora|tiny] [--dtype f32|bf16] [--gemm native|fp32|bf16x3]
 
 Prints ONE JSON line on rank 0.  `roofline` prices the dominant kernel against
 the 8 TB/s HBM3E spec peak with durations measured live by HIP events on the
@@ -167,14 +167,17 @@ def parse_args():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--workload', default=os.environ.get('AMPCONV_BENCH_WORKLOAD', 'cfg4'))
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-alt-gemm', action='store_true', help='skip the extra bf16x3-GEMM pass (profiling runs)')
+    ap.add_argument('--no-alt-gemm', action='store_true',
+                    help='skip the extra pass with the projections on the library GEMMs (profiling runs)')
     ap.add_argument('--softmax-free', action='store_true',
                     help="the reference's softmax-free attention variant (AMPConv(..., softmax=False)); not the headline")
     ap.add_argument('--dtype', default=None, choices=['f32', 'bf16'],
                     help='storage dtype (default: f32; bf16 for cfg5)')
-    ap.add_argument('--gemm', default='fp32', choices=['fp32', 'bf16x3'],
-                    help='dense fp32 projections: plain fp32 GEMMs (default, the headline number) or '
-                         "hipBLASLt's 3-product bf16 split (ampnet_amd.conv.functional.gemm_precision)")
+    ap.add_argument('--gemm', default='native', choices=['native', 'fp32', 'bf16x3'],
+                    help="per-node projections: 'native' (default, the headline: libampconv's own kernels, fp32 operands "
+                         "split exactly into three bf16 terms, six partial products on the bf16 matrix cores, fp32-grade "
+                         "error -- csrc/proj_gemm.hip), 'fp32' (library GEMMs, rocBLAS) or 'bf16x3' (hipBLASLt's "
+                         "3-product split, 8x the error; ampnet_amd.conv.functional.gemm_precision)")
     return ap.parse_args()
 
 
@@ -420,9 +423,9 @@ def main():
     dt = float(tmax.item())
 
     alt = None
-    if world == 1 and dt_name == 'f32' and args.gemm == 'fp32' and not args.no_alt_gemm and not args.softmax_free:
-        # same step with the projections on hipBLASLt's bf16x3 path -- reported beside, never as `value`
-        layer.gemm_precision = 'bf16x3'
+    if world == 1 and dt_name == 'f32' and args.gemm == 'native' and not args.no_alt_gemm and not args.softmax_free:
+        # same step with the projections on the library's fp32 GEMMs (rocBLAS) -- what round 2 measured; reported beside
+        layer.gemm_precision = 'fp32'
         step()
         fence()
         t0 = time.perf_counter()
@@ -430,8 +433,8 @@ def main():
             step()
         fence()
         dta = time.perf_counter() - t0
-        layer.gemm_precision = 'fp32'
-        alt = {'gemm': 'bf16x3', 'value': E * args.steps / dta, 'unit': 'edges/s',
+        layer.gemm_precision = args.gemm
+        alt = {'gemm': 'fp32 (rocBLAS library GEMMs)', 'value': E * args.steps / dta, 'unit': 'edges/s',
                'ms_per_step': 1e3 * dta / args.steps}
 
     if rank == 0 and args.softmax_free:

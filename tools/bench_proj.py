@@ -33,9 +33,13 @@ def main():
     args = [a for a in sys.argv[1:] if not a.startswith('--')]
     M, D = (int(args[0]), int(args[1])) if len(args) == 2 else (20_000_000, 256)
     iters = 5
+    only = None
+    lib = '--no-lib' not in sys.argv
     for a in sys.argv:
         if a.startswith('--iters='):
             iters = int(a.split('=')[1])
+        if a.startswith('--only='):
+            only = a.split('=')[1]
     dev = torch.device('cuda:0')
     torch.manual_seed(0)
     x = torch.randn(M, D, device=dev)
@@ -48,8 +52,15 @@ def main():
     S = min(M, 4096)
 
     def report(name, t, flops, err=None, terr=None):
+        if t is None:
+            return
         print(f'{name:34s} {t:8.2f} ms  {flops / t / 1e9:7.1f} TF fp32-equiv  ({6 * flops / t / 1e9:7.0f} TF bf16 issued)'
               + (f'  err {err:.2e} (library {terr:.2e})' if err is not None else ''), flush=True)
+
+    _timeit = timeit
+
+    def timeit_lib(fn, n):
+        return _timeit(fn, n) if lib else None
 
     def err(a, ref):
         return float((a.double() - ref).abs().max() / ref.abs().max())
@@ -59,17 +70,19 @@ def main():
     t = timeit(lambda: F_.proj_rows(x, img, b_in), iters)
     ref = x[:S].double() @ w_in.double().t() + b_in.double()
     report('qkv  native', t, 2 * M * D * 3 * D, err(F_.proj_rows(x[:S], img, b_in), ref), err(torch.addmm(b_in, x[:S], w_in.t()), ref))
-    report('qkv  library (addmm)', timeit(lambda: torch.addmm(b_in, x, w_in.t()), iters), 2 * M * D * 3 * D)
+    report('qkv  library (addmm)', timeit_lib(lambda: torch.addmm(b_in, x, w_in.t()), iters), 2 * M * D * 3 * D)
     # out-projection [M, D] x [D, D]
     img_o = F_.proj_image(w_out)
     report('out  native', timeit(lambda: F_.proj_rows(x, img_o, b_in[:D]), iters), 2 * M * D * D)
-    report('out  library (addmm)', timeit(lambda: torch.addmm(b_in[:D], x, w_out.t()), iters), 2 * M * D * D)
+    report('out  library (addmm)', timeit_lib(lambda: torch.addmm(b_in[:D], x, w_out.t()), iters), 2 * M * D * D)
     # dX = dQKV Win  [M, 3D] x [3D, D]
     img_t = F_.proj_image(w_in, transpose=True)
     t = timeit(lambda: F_.proj_rows(qkv, img_t), iters)
     ref = qkv[:S].double() @ w_in.double()
     report('dx   native', t, 2 * M * D * 3 * D, err(F_.proj_rows(qkv[:S], img_t), ref), err(qkv[:S].mm(w_in), ref))
-    report('dx   library (mm)', timeit(lambda: qkv.mm(w_in), iters), 2 * M * D * 3 * D)
+    report('dx   library (mm)', timeit_lib(lambda: qkv.mm(w_in), iters), 2 * M * D * 3 * D)
+    if only == 'rows':
+        return
     # dW_in = dQKV^T X  [3D, M] x [M, D]
     dw, cs = torch.empty(3 * D, D, device=dev), torch.empty(3 * D, device=dev)
     t = timeit(lambda: F_.proj_wgrad(qkv, x, dw, cs), iters)
@@ -78,10 +91,10 @@ def main():
     F_.proj_wgrad(qkv[:Mr], x[:Mr], dwr, csr_)
     ref = qkv[:Mr].double().t() @ x[:Mr].double()
     report('dWin native (+ colsum)', t, 2 * M * D * 3 * D, err(dwr, ref), err(qkv[:Mr].t().mm(x[:Mr]), ref))
-    report('dWin library (128-way bmm + sum)', timeit(lambda: F_._tn_matmul(qkv, x), iters), 2 * M * D * 3 * D)
+    report('dWin library (128-way bmm + sum)', timeit_lib(lambda: F_._tn_matmul(qkv, x), iters), 2 * M * D * 3 * D)
     dwo, cso = torch.empty(D, D, device=dev), torch.empty(D, device=dev)
     report('dWo  native (+ colsum)', timeit(lambda: F_.proj_wgrad(x, x, dwo, cso), iters), 2 * M * D * D)
-    report('dWo  library', timeit(lambda: F_._tn_matmul(x, x), iters), 2 * M * D * D)
+    report('dWo  library', timeit_lib(lambda: F_._tn_matmul(x, x), iters), 2 * M * D * D)
     print('weight image (4 per step):', f'{timeit(lambda: F_.proj_image(w_in), 20):.4f} ms')
 
 
