@@ -24,6 +24,8 @@ Backend "nccl" (= RCCL) uses all_gather_into_tensor / reduce_scatter_tensor; any
 gloo test, two processes on one GPU) emulates both with all_reduce, which gloo supports on device
 tensors.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -44,6 +46,9 @@ class NodePartition:
         self.n_padded = self.n_local * self.world
         self.begin = self.rank * self.n_local
         self.native = dist.is_initialized() and dist.get_backend(group) == 'nccl'
+        # test switch: take the asynchronous RCCL branch of the two collectives even as the only rank, so that a
+        # one-GPU box runs the start / wait ordering and buffer lifetimes of _PartitionedFunction for real
+        self.force_async = self.native and os.environ.get('AMPCONV_PARTITION_FORCE_ASYNC') == '1'
 
     def local_rows(self, x_full):
         """This rank's rows of a full [N, F] tensor, zero-padded to n_local rows."""
@@ -84,14 +89,14 @@ class NodePartition:
 
     def all_gather_rows_start(self, t):
         t = t.contiguous()
-        if self.world == 1 or not self.native:
+        if (self.world == 1 and not self.force_async) or not self.native:
             return self.all_gather_rows(t), self._Done()
         out = torch.empty(self.world * t.size(0), t.size(1), dtype=t.dtype, device=t.device)
         return out, dist.all_gather_into_tensor(out, t, group=self.group, async_op=True)
 
     def reduce_scatter_rows_start(self, t):
         t = t.contiguous()
-        if self.world == 1 or not self.native:
+        if (self.world == 1 and not self.force_async) or not self.native:
             return self.reduce_scatter_rows(t), self._Done()
         out = torch.empty(t.size(0) // self.world, t.size(1), dtype=t.dtype, device=t.device)
         return out, dist.reduce_scatter_tensor(out, t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
@@ -112,7 +117,7 @@ class NodePartition:
 
 class _PartitionedFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x_local, w_in, b_in, w_out, b_out, csr, num_heads, part, dtype):
+    def forward(ctx, x_local, w_in, b_in, w_out, b_out, csr, num_heads, part, dtype, gemm='native'):
         lib = _lib.load()
         D = w_out.size(0)
         H = int(num_heads)
@@ -121,22 +126,28 @@ class _PartitionedFunction(torch.autograd.Function):
         nl, NP = part.n_local, part.n_padded
         dev = x_local.device
         x2 = x_local.contiguous().view(nl * L, D)
+        native = F_.proj_native(gemm, x_local.dtype, D)                 # libampconv's own projection kernels
         with torch.cuda.device(dev):
             # K|V of the local rows first, their all-gather in flight while the Q projection runs
-            kv_loc = torch.addmm(b_in[D:], x2, w_in[D:].t())            # [nl*L, 2D]
+            kv_loc = (F_.proj_rows(x2, F_.proj_image(w_in[D:]), b_in[D:]) if native
+                      else torch.addmm(b_in[D:], x2, w_in[D:].t()))      # [nl*L, 2D]
             kv_all, work = part.all_gather_rows_start(kv_loc)           # every node's K|V, [NP*L, 2D]
-            qkv = torch.addmm(b_in[:D], x2, w_in[:D].t())               # Q of the local rows, [nl*L, D]
+            qkv = (F_.proj_rows(x2, F_.proj_image(w_in[:D]), b_in[:D]) if native
+                   else torch.addmm(b_in[:D], x2, w_in[:D].t()))         # Q of the local rows, [nl*L, D]
             work.wait()
             del kv_loc
             Qv = F_._view(qkv, 0, L, dh)
             Kv, Vv = F_._view(kv_all, 0, L, dh), F_._view(kv_all, D, L, dh)
             obar = torch.empty(nl * L, D, dtype=x_local.dtype, device=dev)
             F_.edge_forward(Qv, Kv, Vv, csr, nl, L, D, H, obar, dtype=dtype)
-            y = torch.addmm(b_out, obar, w_out.t())
-            rc = lib.ampconv_mask_rows(y.data_ptr(), csr.rowptr.data_ptr(), nl, L * D, _lib.AMPCONV_F32, _stream())
-            _lib.check(rc, 'ampconv_mask_rows')
+            if native:
+                y = F_.proj_rows(obar, F_.proj_image(w_out), b_out, csr.rowptr, L)
+            else:
+                y = torch.addmm(b_out, obar, w_out.t())
+                rc = lib.ampconv_mask_rows(y.data_ptr(), csr.rowptr.data_ptr(), nl, L * D, _lib.AMPCONV_F32, _stream())
+                _lib.check(rc, 'ampconv_mask_rows')
         ctx.save_for_backward(x2, w_in, w_out, qkv, kv_all, obar)
-        ctx.csr, ctx.dims, ctx.part, ctx.dtype = csr, (nl, NP, L, D, H), part, dtype
+        ctx.csr, ctx.dims, ctx.part, ctx.dtype, ctx.native = csr, (nl, NP, L, D, H), part, dtype, native
         return y.view(nl, L * D)
 
     @staticmethod
@@ -149,13 +160,19 @@ class _PartitionedFunction(torch.autograd.Function):
         dev = dy.device
         with torch.cuda.device(dev):
             dy2 = dy.contiguous().view(nl * L, D)
-            scratch = torch.empty((1 + _lib.COLSUM_BLOCKS) * D, dtype=torch.float32, device=dev)
-            rc = lib.ampconv_masked_colsum(dy2.data_ptr(), csr.rowptr.data_ptr(), nl, L, D, scratch.data_ptr(),
-                                           _lib.AMPCONV_F32, _stream())
-            _lib.check(rc, 'ampconv_masked_colsum')
-            db_out = scratch[:D].clone()
-            dw_out = F_._tn_matmul(dy2, obar)
-            dobar = dy2.mm(w_out)
+            native = ctx.native
+            if native:
+                dw_out, db_out = torch.empty_like(w_out), torch.empty(D, dtype=torch.float32, device=dev)
+                F_.proj_wgrad(dy2, obar, dw_out, db_out, csr.rowptr, L)
+                dobar = F_.proj_rows(dy2, F_.proj_image(w_out, transpose=True))
+            else:
+                scratch = torch.empty((1 + _lib.COLSUM_BLOCKS) * D, dtype=torch.float32, device=dev)
+                rc = lib.ampconv_masked_colsum(dy2.data_ptr(), csr.rowptr.data_ptr(), nl, L, D, scratch.data_ptr(),
+                                               _lib.AMPCONV_F32, _stream())
+                _lib.check(rc, 'ampconv_masked_colsum')
+                db_out = scratch[:D].clone()
+                dw_out = F_._tn_matmul(dy2, obar)
+                dobar = dy2.mm(w_out)
             Qv, dOv = F_._view(qkv, 0, L, dh), F_._view(dobar, 0, L, dh)
             Kv, Vv = F_._view(kv_all, 0, L, dh), F_._view(kv_all, D, L, dh)
             dq = torch.empty(nl * L, D, dtype=torch.float32, device=dev)
@@ -180,16 +197,26 @@ class _PartitionedFunction(torch.autograd.Function):
             del dobar, stats
             # this rank's rows of dK|dV, summed over ranks: in flight while the Q-side products run
             dkv, work = part.reduce_scatter_rows_start(dkv_all)
-            dw_q = F_._tn_matmul(dq, x2)
-            db_q = dq.sum(dim=0)
-            dx = dq.mm(w_in[:D]) if ctx.needs_input_grad[0] else None
-            work.wait()
-            del dkv_all
-            dw_in = torch.cat([dw_q, F_._tn_matmul(dkv, x2)], dim=0)
-            db_in = torch.cat([db_q, dkv.sum(dim=0)])
-            if dx is not None:
-                dx = dx.addmm_(dkv, w_in[D:]).view(nl, L * D)
-        return dx, dw_in, db_in, dw_out, db_out, None, None, None, None
+            if native:
+                dw_in, db_in = torch.empty_like(w_in), torch.empty(3 * D, dtype=torch.float32, device=dev)
+                F_.proj_wgrad(dq, x2, dw_in[:D], db_in[:D])
+                dx = F_.proj_rows(dq, F_.proj_image(w_in[:D], transpose=True)) if ctx.needs_input_grad[0] else None
+                work.wait()
+                del dkv_all
+                F_.proj_wgrad(dkv, x2, dw_in[D:], db_in[D:])
+                if dx is not None:
+                    dx = dx.add_(F_.proj_rows(dkv, F_.proj_image(w_in[D:], transpose=True))).view(nl, L * D)
+            else:
+                dw_q = F_._tn_matmul(dq, x2)
+                db_q = dq.sum(dim=0)
+                dx = dq.mm(w_in[:D]) if ctx.needs_input_grad[0] else None
+                work.wait()
+                del dkv_all
+                dw_in = torch.cat([dw_q, F_._tn_matmul(dkv, x2)], dim=0)
+                db_in = torch.cat([db_q, dkv.sum(dim=0)])
+                if dx is not None:
+                    dx = dx.addmm_(dkv, w_in[D:]).view(nl, L * D)
+        return dx, dw_in, db_in, dw_out, db_out, None, None, None, None, None
 
 
 class PartitionedAMPConv(torch.nn.Module):
@@ -219,4 +246,4 @@ class PartitionedAMPConv(torch.nn.Module):
         if x_local.dtype != torch.float32 or not conv.softmax:
             raise ValueError('the partitioned layer runs the float32 softmax path')
         return _PartitionedFunction.apply(x_local, *conv._params(), graph, conv.num_heads, part,
-                                          _lib.PRECISIONS[conv.precision])
+                                          _lib.PRECISIONS[conv.precision], conv.gemm_precision)

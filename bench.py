@@ -16,7 +16,12 @@ Prints ONE JSON line on rank 0.  `roofline` prices the dominant kernel against
 the 8 TB/s HBM3E spec peak with durations measured live by HIP events on the
 launch stream over the timed region; `cpu_baseline` is the reference-shaped CPU
 restatement (oracle/ampconv_torch.py) timed on the host cores on a bounded
-sub-sample of the same workload (rank 0, N=1 only).
+sub-sample of the same workload (rank 0, N=1 only).  Beside the headline the line
+carries: `saint` (N > 1: BASELINE config 4 as written -- the resident graph, one
+GraphSAINT subgraph per rank per step -- measured on the same ranks right after
+the full-graph pass), `extra_workloads` (N = 1: configs 3 and 5, a few steps each),
+`alt_gemm` (the same step on the library's fp32 GEMMs) and per-rank kernel and
+all-reduce times, so that one line diagnoses a scaling run.
 """
 import argparse
 import json
@@ -128,36 +133,61 @@ def host_cores():
     return max(1, min(n, int(os.environ.get('AMPCONV_CPU_THREADS', n))))
 
 
-def cpu_baseline(L, D, H, ratio):
-    """Reference-shaped CPU path (gather -> nn.MultiheadAttention -> scatter-mean), fwd+bwd,
-    on a bounded sub-sample with the workload's L, D, H and E/N."""
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(L, D, H, ratio, budget_s=20.0):
+    """Reference-shaped CPU path (gather -> nn.MultiheadAttention -> scatter-mean), fwd+bwd, on a bounded
+    sub-sample with the workload's L, D, H and E/N (1 warm-up + 3 timed, best; about 100 k edges when
+    the host allows).  The sample is sized from a small timed probe so that the three timed passes take about
+    `budget_s` seconds, and capped at 100 k edges and a quarter of the host RAM (~1 KB per edge and channel)."""
     from oracle.ampconv_torch import RefShapedAMPConv
     cores = host_cores()
     torch.set_num_threads(cores)
-    n_cpu = 3000
-    e_cpu = int(n_cpu * ratio)
     torch.manual_seed(1)
     layer = RefShapedAMPConv(D, H)
     g = torch.Generator().manual_seed(2)
-    x = torch.randn(n_cpu, L * D, generator=g, requires_grad=True)
-    ei = torch.randint(0, n_cpu, (2, e_cpu), generator=g)
-    dy = torch.randn(n_cpu, L * D, generator=g)
 
-    def step(edges):
+    def sample(n_cpu):
+        e_cpu = int(n_cpu * ratio)
+        x = torch.randn(n_cpu, L * D, generator=g, requires_grad=True)
+        return x, torch.randint(0, n_cpu, (2, e_cpu), generator=g), torch.randn(n_cpu, L * D, generator=g), e_cpu
+
+    def step(x, edges, dy):
         layer.zero_grad(set_to_none=True)
         x.grad = None
         y = layer(x, edges)
         (y * dy).sum().backward()
 
-    step(ei[:, : e_cpu // 8])                 # warm-up on an eighth of the sample
+    x, ei, dy, e_probe = sample(400)                       # probe (also warms the thread pool and the allocator)
+    step(x, ei, dy)
+    t0 = time.perf_counter()
+    step(x, ei, dy)
+    rate = e_probe / (time.perf_counter() - t0)
+    try:
+        ram = os.sysconf('SC_PAGE_SIZE') * os.sysconf('SC_PHYS_PAGES')
+    except (ValueError, OSError):
+        ram = 64 << 30
+    e_cpu = int(min(100_000, rate * budget_s / 3, 0.25 * ram / (1000.0 * D)))
+    n_cpu = max(400, int(e_cpu / ratio))
+    x, ei, dy, e_cpu = sample(n_cpu)
+    step(x, ei[:, : max(1, e_cpu // 8)], dy)               # warm-up on an eighth of the sample
     best = float('inf')
-    for _ in range(2):
+    for _ in range(3):
         t0 = time.perf_counter()
-        step(ei)
+        step(x, ei, dy)
         best = min(best, time.perf_counter() - t0)
-    return {'value': e_cpu / best, 'unit': 'edges/s', 'cores': cores, 'kind': 'port',
-            'sample': f'{n_cpu} nodes / {e_cpu} edges, L={L} D={D} H={H} fp32, fwd+bwd, best of 2, '
-                      f'torch {torch.__version__} CPU, {cores} threads'}
+    return {'value': e_cpu / best, 'unit': 'edges/s', 'cores': cores, 'kind': 'port', 'cpu_model': cpu_model(),
+            'sample': f'{n_cpu} nodes / {e_cpu} edges, L={L} D={D} H={H} fp32, fwd+bwd, 1 warm-up + 3 timed (best), '
+                      f'torch {torch.__version__} CPU, {cores} threads; sample sized for ~{budget_s:.0f} s of CPU work '
+                      f'(the reference materialises ~{D} KB per edge)'}
 
 
 def parse_args():
@@ -169,6 +199,8 @@ def parse_args():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-alt-gemm', action='store_true',
                     help='skip the extra pass with the projections on the library GEMMs (profiling runs)')
+    ap.add_argument('--no-extra', action='store_true',
+                    help='skip the side measurements of the default run (N = 1: configs 3 and 5; N > 1: GraphSAINT batches)')
     ap.add_argument('--softmax-free', action='store_true',
                     help="the reference's softmax-free attention variant (AMPConv(..., softmax=False)); not the headline")
     ap.add_argument('--dtype', default=None, choices=['f32', 'bf16'],
@@ -184,9 +216,10 @@ def parse_args():
 def launch_ranks(n):
     """`python bench.py --gpus N` without a launcher around it: start N fresh worker processes of this
     script (one per GPU, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment) BEFORE this
-    process touches the GPU, wait for them, and exit non-zero if any of them failed.  Mirrors the
-    reference's own mp.spawn of one process per rank
-    (experiments/cora_benchmark_graphsaint_distributed.py:130-142).  Rank 0 prints the JSON line."""
+    process touches the GPU and watch them: the first rank that exits non-zero ends the run -- the others
+    (blocked in a collective that will never complete) are terminated, then killed after a grace period --
+    and (rank, exit code) of every failed rank is reported.  Mirrors the reference's own mp.spawn of one
+    process per rank (experiments/cora_benchmark_graphsaint_distributed.py:130-142).  Rank 0 prints the JSON line."""
     import socket
     import subprocess
     port = os.environ.get('MASTER_PORT')
@@ -199,22 +232,93 @@ def launch_ranks(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR='127.0.0.1', MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY='0')
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    rcs = [p.wait() for p in procs]
-    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
-    if bad:
-        print(f'bench.py: ranks failed (rank, exit code): {bad}', file=sys.stderr)
+    rcs = [None] * n
+    first_bad = None
+    while any(rc is None for rc in rcs):
+        for r, p in enumerate(procs):
+            if rcs[r] is None:
+                rcs[r] = p.poll()
+                if rcs[r] not in (None, 0) and first_bad is None:
+                    first_bad = r
+        if first_bad is not None:
+            break
+        time.sleep(0.05)
+    if first_bad is not None:
+        survivors = [r for r in range(n) if rcs[r] is None]
+        for r in survivors:
+            procs[r].terminate()
+        deadline = time.time() + 10.0
+        for r in survivors:
+            try:
+                rcs[r] = procs[r].wait(timeout=max(0.1, deadline - time.time()))
+            except subprocess.TimeoutExpired:
+                procs[r].kill()
+                rcs[r] = procs[r].wait()
+        bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0 and r not in survivors]
+        print(f'bench.py: ranks failed (rank, exit code): {bad}; first: rank {first_bad}; '
+              f'stopped the {len(survivors)} rank(s) still running: {survivors}', file=sys.stderr)
         sys.exit(1)
     sys.exit(0)
 
 
-def run_saint(args, rank, world, dev, layer, reducer, N, E, L, D, H, desc, dt_name, tdt, R, dist_on):
-    """GraphSAINT-batch mode: per rank per step GraphSAINTRandomWalkSampler.sample() -> row gather of the
-    resident features -> AMPConv forward + backward on the induced subgraph -> gradient all-reduce.
-    `value` = sampled edges processed by all ranks per second; the sampler's share of the step and the
-    host read-backs it costs (sub-graph sizes, needed to size the batch's tensors) are reported."""
+def _fence(dist_on):
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def _gather_ranks(values, dev, dist_on):
+    """[len(values)] floats of every rank -> list (by rank) of lists, on every rank."""
+    if not dist_on:
+        return [list(values)]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, [float(v) for v in values])
+    return out
+
+
+EDGE_CALLS = ('ampconv_fwd_edge', 'ampconv_bwd_edge_dst', 'ampconv_bwd_edge_src')
+
+
+def _edge_alg_bytes(N, E, R):
+    return {'ampconv_fwd_edge': (2 * E + 2 * N) * R, 'ampconv_bwd_edge_dst': (2 * E + 3 * N) * R,
+            'ampconv_bwd_edge_src': (2 * E + 4 * N) * R}
+
+
+def _per_rank(ms_by_rank, dist_on):
+    return [{'rank': r, **{k.replace('ampconv_', ''): v[i] for i, k in enumerate(EDGE_CALLS)},
+             **({'allreduce': v[3]} if dist_on else {})} for r, v in enumerate(ms_by_rank)]
+
+
+def make_layer(D, H, tdt, dev, args, dist_on, softmax=True):
+    from ampnet_amd import AMPConv
+    from ampnet_amd.distributed import GradientAllReducer, broadcast_parameters
+    torch.manual_seed(1)
+    layer = AMPConv(D, H, softmax=softmax).to(dev)
+    layer.retain_attention = False                            # no [E, L, L] side output kept alive
+    layer.gemm_precision = args.gemm
+    with torch.no_grad():
+        layer.multi_head_attention.in_proj_bias.normal_(0, 0.1)
+        layer.multi_head_attention.out_proj.bias.normal_(0, 0.1)
+    layer = layer.to(tdt)
+    if dist_on:
+        broadcast_parameters(layer, src=0)
+    return layer, GradientAllReducer(layer.parameters())
+
+
+def measure_saint(workload, steps, warmup, args, rank, world, dev, dist_on, dt_name):
+    """GraphSAINT-batch mode (BASELINE config 4 as written; experiments/cora_benchmark_graphsaint_distributed.py:64-94):
+    per rank per step GraphSAINTRandomWalkSampler.sample() -> row gather of the resident features -> AMPConv forward +
+    backward on the induced subgraph -> gradient all-reduce.  Returns (on every rank) the measurement as a dict:
+    `value` = sampled edges processed by all ranks per second; the sampler's and the all-reduce's share of the step,
+    the host read-backs, per-rank kernel times."""
     import types
     from ampnet_amd import GraphSAINTRandomWalkSampler, graph_cache, _lib
-    roots, walk = SAINT[args.workload]
+    N, E, L, D, H, desc = WORKLOADS[workload]
+    tdt = torch.bfloat16 if dt_name == 'bf16' else torch.float32
+    R = L * D * (2 if dt_name == 'bf16' else 4)
+    layer, reducer = make_layer(D, H, tdt, dev, args, dist_on)
+    roots, walk = SAINT[workload]
     x, ei, _ = make_batch(N, E, L, D, 13, dev, tdt)           # the same resident graph on every rank (seed 13)
     del _
     sampler = GraphSAINTRandomWalkSampler(types.SimpleNamespace(edge_index=ei, num_nodes=N), batch_size=roots,
@@ -227,8 +331,7 @@ def run_saint(args, rank, world, dev, layer, reducer, N, E, L, D, H, desc, dt_na
     timed_lib = TimedLib(_lib.load(), timer)
     orig_load = _lib.load
     _lib.load = lambda: timed_lib
-    ev = []
-    sizes = []
+    ev, ar_ev, sizes = [], [], []
 
     def step(timed):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -241,28 +344,29 @@ def run_saint(args, rank, world, dev, layer, reducer, N, E, L, D, H, desc, dt_na
         y = layer(xs, ei_sub)
         y.backward(dy_buf[: xs.size(0)])
         if dist_on:
+            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a0.record()
             reducer.allreduce()
+            a1.record()
+            if timed:
+                ar_ev.append((a0, a1))
         if timed:
             ev.append((e0, e1))
             sizes.append((int(node_idx.numel()), int(ei_sub.size(1))))
 
-    def fence():
-        torch.cuda.synchronize()
-        if dist_on:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step(False)
-    fence()
-    timer.enabled = True
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
-    fence()
-    dt = time.perf_counter() - t0
-    timer.enabled = False
-    _lib.load = orig_load
+    try:
+        for _ in range(warmup):
+            step(False)
+        _fence(dist_on)
+        timer.enabled = True
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(True)
+        _fence(dist_on)
+        dt = time.perf_counter() - t0
+    finally:
+        timer.enabled = False
+        _lib.load = orig_load
     tot = torch.tensor([dt, float(sum(e for _, e in sizes)), float(sum(n for n, _ in sizes))], dtype=torch.float64,
                        device=dev)
     if dist_on:
@@ -271,39 +375,200 @@ def run_saint(args, rank, world, dev, layer, reducer, N, E, L, D, H, desc, dt_na
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         tot[0] = tmax[0]
     dt, edges_all, nodes_all = (float(v) for v in tot.tolist())
-    if rank != 0:
-        return
     ms = timer.summary()
-    n_avg = sum(n for n, _ in sizes) / len(sizes)
-    e_avg = sum(e for _, e in sizes) / len(sizes)
-    alg = {'ampconv_fwd_edge': (2 * e_avg + 2 * n_avg) * R, 'ampconv_bwd_edge_dst': (2 * e_avg + 3 * n_avg) * R,
-           'ampconv_bwd_edge_src': (2 * e_avg + 4 * n_avg) * R}
+    ar_ms = sum(a.elapsed_time(b) for a, b in ar_ev) / len(ar_ev) if ar_ev else 0.0
+    by_rank = _gather_ranks([ms.get(k, 0.0) for k in EDGE_CALLS] + [ar_ms], dev, dist_on)
+    n_avg = nodes_all / (steps * world)
+    e_avg = edges_all / (steps * world)
+    alg = _edge_alg_bytes(sum(n for n, _ in sizes) / len(sizes), sum(e for _, e in sizes) / len(sizes), R)
     dom = max(ms, key=ms.get)
     achieved = alg[dom] / (ms[dom] * 1e-3) / 1e9
     sampler_ms = sum(a.elapsed_time(b) for a, b in ev) / len(ev)
     flops = 14 * L * L * D * e_avg + 24 * L * D * D * n_avg
-    t_step = dt / args.steps
-    out = {
+    t_step = dt / steps
+    del x, ei, dy_buf, sampler
+    graph_cache.clear()
+    torch.cuda.empty_cache()
+    return {
         'metric': 'AMPConv edges/sec (fwd+bwd), GraphSAINT subgraph batches', 'value': edges_all / dt, 'unit': 'edges/s',
-        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * t_step,
+        'n_gpus': world, 'steps': steps, 'warmup': warmup, 'ms_per_step': 1e3 * t_step,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': dt_name, 'data': 'synthetic',
-        'config': {'workload': f'{args.workload}: {desc}; sampler + feature-row gather + one AMPConv layer fwd+bwd incl. CSR '
+        'config': {'workload': f'{workload}: {desc}; sampler + feature-row gather + one AMPConv layer fwd+bwd incl. CSR '
                                f'build of the subgraph' + (' + RCCL grad all-reduce' if world > 1 else ''),
                    'N': N, 'E': E, 'L': L, 'D': D, 'H': H, 'roots': roots, 'walk_length': walk,
                    'parallelism': f'dp{world}', 'gemm': args.gemm if dt_name == 'f32' else 'bf16'},
+        'nodes_avg': n_avg, 'edges_avg': e_avg, 'sampler_ms': sampler_ms, 'allreduce_ms': ar_ms,
         'batch': {'nodes_avg': n_avg, 'edges_avg': e_avg, 'sampler_ms': sampler_ms,
                   'sampler_share_of_step': sampler_ms / (1e3 * t_step),
+                  'allreduce_share_of_step': ar_ms / (1e3 * t_step),
                   'host_readbacks_per_batch': 'sampler: sub-graph node and edge counts (2), CSR build: bounds flag + '
                                               'long-segment chunk counts (1); all inside the timed step'},
         'layer_flops': {'per_step': flops, 'achieved_TFLOPs_per_gpu': flops / t_step / 1e12,
                         'peak_TFLOPs': MFMA_PEAK_TFLOPS[dt_name],
                         'frac_of_peak': flops / t_step / 1e12 / MFMA_PEAK_TFLOPS[dt_name]},
-        'kernels_ms': ms,
+        'kernels_ms': ms, 'per_rank_ms': _per_rank(by_rank, dist_on),
         'roofline': {'kernel': dom, 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                     'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'algorithmic_bytes_per_launch': alg[dom],
-                     'avg_launch_ms': ms[dom]},
+                     'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'traffic_source': None,
+                     'algorithmic_bytes_per_launch': alg[dom], 'avg_launch_ms': ms[dom]},
     }
-    print(json.dumps(out), flush=True)
+
+
+def measure_full(workload, steps, warmup, args, rank, world, dev, dist_on, dt_name, alt=False):
+    """One graph of the workload's shape per rank; a step = CSR/CSC build + one AMPConv layer forward + backward
+    (+ the gradient all-reduce when a process group is up).  Returns the measurement as a dict (on every rank)."""
+    from ampnet_amd import graph_cache, _lib
+    N, E, L, D, H, desc = WORKLOADS[workload]
+    tdt = torch.bfloat16 if dt_name == 'bf16' else torch.float32
+    R = L * D * (2 if dt_name == 'bf16' else 4)
+    layer, reducer = make_layer(D, H, tdt, dev, args, dist_on, softmax=not args.softmax_free)
+    x, ei, dy = make_batch(N, E, L, D, 1234 + rank, dev, tdt, rmat=workload == 'cfg5')   # own graph per rank
+    x.requires_grad_(True)
+
+    timer = KernelTimer()
+    timed_lib = TimedLib(_lib.load(), timer)
+    orig_load = _lib.load
+    _lib.load = lambda: timed_lib                             # functional.py resolves the lib per call
+    ar_ev = []
+
+    def step(timed=False):
+        graph_cache.clear()                                   # a new batch -> CSR build is in the step
+        layer.zero_grad(set_to_none=True)
+        x.grad = None
+        y = layer(x, ei)
+        y.backward(dy)
+        if dist_on:
+            a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a0.record()
+            reducer.allreduce()
+            a1.record()
+            if timed:
+                ar_ev.append((a0, a1))
+
+    try:
+        for _ in range(warmup):
+            step()
+        _fence(dist_on)
+        timer.enabled = True
+        step_events = []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            step(True)
+            e1.record()
+            step_events.append((e0, e1))
+        _fence(dist_on)
+        dt = time.perf_counter() - t0
+        timer.enabled = False
+        step_ms = sorted(a.elapsed_time(b) for a, b in step_events)
+        median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if dist_on:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+        alt_out = None
+        if alt:
+            # same step with the projections on the library's fp32 GEMMs (rocBLAS) -- what round 2 measured; reported beside
+            layer.gemm_precision = 'fp32'
+            step()
+            _fence(dist_on)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            _fence(dist_on)
+            dta = time.perf_counter() - t0
+            layer.gemm_precision = args.gemm
+            alt_out = {'gemm': 'fp32 (rocBLAS library GEMMs)', 'value': E * steps / dta, 'unit': 'edges/s',
+                       'ms_per_step': 1e3 * dta / steps}
+    finally:
+        timer.enabled = False
+        _lib.load = orig_load
+    ms = timer.summary()
+    ar_ms = sum(a.elapsed_time(b) for a, b in ar_ev) / len(ar_ev) if ar_ev else 0.0
+    by_rank = _gather_ranks([ms.get(k, 0.0) for k in EDGE_CALLS] + [ar_ms], dev, dist_on)
+    del x, dy, ei
+    graph_cache.clear()
+    torch.cuda.empty_cache()
+    out = {'metric': 'AMPConv edges/sec (fwd+bwd)', 'value': world * E * steps / dt, 'unit': 'edges/s',
+           'n_gpus': world, 'steps': steps, 'warmup': warmup, 'ms_per_step': 1e3 * dt / steps, 'higher_is_better': True,
+           'scaling': 'weak', 'vs_baseline': None, 'dtype': dt_name, 'data': 'synthetic',
+           'config': {'workload': f'{workload}: {desc}, one AMPConv layer fwd+bwd incl. CSR build, '
+                                  f'one graph per GPU' + (' + RCCL grad all-reduce' if world > 1 else ''),
+                      'N': N, 'E': E, 'L': L, 'D': D, 'H': H, 'parallelism': f'dp{world}',
+                      'gemm': args.gemm if dt_name == 'f32' else 'bf16'}}
+    if args.softmax_free:
+        # the edge phase of this variant is one segment reduction (conv/linear.py): no edge-kernel roofline
+        out['metric'] += ', softmax-free variant'
+        return out
+    alg = _edge_alg_bytes(N, E, R)
+    kflops = {'ampconv_fwd_edge': 4 * L * L * D * E, 'ampconv_bwd_edge_dst': 6 * L * L * D * E,
+              'ampconv_bwd_edge_src': 8 * L * L * D * E}   # multiply-adds x 2 of the products each pass does
+    dom = max(ms, key=ms.get)
+    achieved = alg[dom] / (ms[dom] * 1e-3) / 1e9
+    b_alg = (6 * E + 15 * N) * R + 16 * E                 # whole layer, SURVEY.md 8d
+    # SURVEY.md 8d names two rooflines: HBM for the edge phase, the matrix pipe for the per-node
+    # projections.  FLOPs per step: attention 14 L^2 D per edge, projections 24 L D^2 per node.
+    flops_attn, flops_proj = 14 * L * L * D * E, 24 * L * D * D * N
+    mfma_peak = MFMA_PEAK_TFLOPS[dt_name]
+    t_step = dt / steps
+    t_hbm, t_mfma = b_alg / (HBM_PEAK_GBS * 1e9), (flops_attn + flops_proj) / (mfma_peak * 1e12)
+    traffic = traffic_source = None                        # PMC-measured HBM bytes per launch
+    try:                                                   # (profiles/pmc_traffic.json, same workload)
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
+        if pmc.get('workload') == workload and dt_name == 'f32':
+            traffic = pmc['kernels'][dom]['traffic_bytes']
+            traffic_source = ('profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload '
+                              '(committed profile, gfx950 corrections applied); not measured in this run')
+    except (OSError, KeyError, ValueError):
+        pass
+    edge_ms = sum(ms[k] for k in EDGE_CALLS if k in ms)
+    edge_bytes = (6 * E + 9 * N) * R
+    out.update({
+        'layer_hbm': {'algorithmic_bytes_per_step': b_alg,
+                      'achieved_GBps_per_gpu': b_alg * steps / dt / 1e9,
+                      'frac_of_8TBps': b_alg * steps / dt / 1e9 / HBM_PEAK_GBS},
+        # the three edge kernels together, SURVEY.md 8d's edge-phase figure (6E + 9N) R against their summed time
+        'edge_phase_hbm': {'algorithmic_bytes_per_step': edge_bytes, 'kernels_ms_sum': edge_ms,
+                           'achieved_GBps': edge_bytes / (edge_ms * 1e-3) / 1e9,
+                           'frac_of_8TBps': edge_bytes / (edge_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+        'layer_flops': {'attention_per_step': flops_attn, 'projections_per_step': flops_proj,
+                        'achieved_TFLOPs_per_gpu': (flops_attn + flops_proj) / t_step / 1e12,
+                        'peak_TFLOPs': mfma_peak, 'frac_of_peak': (flops_attn + flops_proj) / t_step / 1e12 / mfma_peak,
+                        'peak_note': ('fp32-input MFMA = fp32 vector rate (157.3 TF): the peak of the edge kernels; the '
+                                      "'native' projections run as 6 bf16 MFMA products per fp32 product (2.5 PF / 6 = 417 TF "
+                                      'fp32-equivalent at the dense bf16 peak)') if dt_name == 'f32' else 'dense bf16 MFMA',
+                        'floor_ms': {'hbm_at_8TBps': 1e3 * t_hbm, 'mfma_at_peak': 1e3 * t_mfma},
+                        'binding': 'mfma' if t_mfma > t_hbm else 'hbm'},
+        'node_phase_ms': 1e3 * t_step - edge_ms,             # projections + glue + CSR build (+ all-reduce)
+        'kernels_ms': ms, 'per_rank_ms': _per_rank(by_rank, dist_on),
+        'allreduce_ms': ar_ms,
+        'timing': 'value = wall clock over the K steps between barrier+synchronize fences, max over ranks '
+                  '(the contract); kernels_ms = mean HIP-event duration per launch over the same steps (rank 0; every '
+                  'rank: per_rank_ms); ms_per_step_hip_events_median = median of per-step HIP-event durations on rank 0 '
+                  '(SURVEY 8d protocol)',
+        'ms_per_step_hip_events_median': median_ms,
+        'roofline': {'kernel': dom, 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
+                     'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                     'traffic_source': traffic_source,
+                     'algorithmic_bytes_per_launch': alg[dom], 'avg_launch_ms': ms[dom],
+                     # the same launch against the arithmetic peak (fp32: MFMA and VALU share the FP32 pipe, DESIGN 4)
+                     'arithmetic': {'flops_per_launch': kflops[dom], 'achieved_TFLOPs': kflops[dom] / (ms[dom] * 1e-3) / 1e12,
+                                    'peak_TFLOPs': mfma_peak,
+                                    'frac': kflops[dom] / (ms[dom] * 1e-3) / 1e12 / mfma_peak}},
+    })
+    if alt_out is not None:
+        out['alt_gemm'] = alt_out
+    return out
+
+
+def _brief(m):
+    """What an extra workload contributes to the headline's line."""
+    r = m['roofline']
+    return {'workload': m['config']['workload'], 'dtype': m['dtype'], 'value': m['value'], 'unit': m['unit'],
+            'steps': m['steps'], 'ms_per_step': m['ms_per_step'], 'kernels_ms': m['kernels_ms'],
+            'edge_phase_frac_of_8TBps': m['edge_phase_hbm']['frac_of_8TBps'],
+            'dominant_kernel': {'kernel': r['kernel'], 'frac': r['frac'], 'avg_launch_ms': r['avg_launch_ms']}}
 
 
 def main():
@@ -319,9 +584,13 @@ def main():
     backend = os.environ.get('AMPCONV_DIST_BACKEND', 'nccl')       # nccl == RCCL on ROCm (gloo: CPU-side tests)
     if os.environ.get('AMPCONV_BENCH_LAUNCH_ONLY') == '1':
         # rehearsal of the launch path on a machine without a GPU (tests/test_bench_launch.py): the
-        # ranks rendezvous, all-reduce one CPU tensor over gloo and rank 0 reports; nothing is measured
+        # ranks rendezvous, all-reduce one CPU tensor over gloo and rank 0 reports; nothing is measured.
+        # AMPCONV_BENCH_FAIL_RANK=r: that rank dies right after the rendezvous (the others then sit in a
+        # collective that never completes -- what the launcher has to clean up)
         if world > 1:
             dist.init_process_group('gloo')
+        if os.environ.get('AMPCONV_BENCH_FAIL_RANK') == str(rank):
+            os._exit(3)
         t = torch.ones(1)
         if world > 1:
             dist.all_reduce(t)
@@ -342,170 +611,41 @@ def main():
     dist_on = world > 1 or os.environ.get('AMPCONV_BENCH_FORCE_DIST') == '1'
     if dist_on:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29511')
+        if 'MASTER_PORT' not in os.environ:                   # single forced rank: any free port
+            import socket
+            with socket.socket() as s:
+                s.bind(('127.0.0.1', 0))
+                os.environ['MASTER_PORT'] = str(s.getsockname()[1])
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group(backend, **({'device_id': dev} if backend == 'nccl' else {}))
 
-    from ampnet_amd import AMPConv, graph_cache, _lib
-    from ampnet_amd.conv import functional as F_
-    from ampnet_amd.distributed import GradientAllReducer, broadcast_parameters
-
-    N, E, L, D, H, desc = WORKLOADS[args.workload]
     dt_name = args.dtype or ('bf16' if args.workload == 'cfg5' else 'f32')
-    tdt = torch.bfloat16 if dt_name == 'bf16' else torch.float32
-    R = L * D * (2 if dt_name == 'bf16' else 4)
-    torch.manual_seed(1)
-    layer = AMPConv(D, H, softmax=not args.softmax_free).to(dev)
-    layer.retain_attention = False                            # no [E, L, L] side output kept alive
-    layer.gemm_precision = args.gemm
-    with torch.no_grad():
-        layer.multi_head_attention.in_proj_bias.normal_(0, 0.1)
-        layer.multi_head_attention.out_proj.bias.normal_(0, 0.1)
-    layer = layer.to(tdt)
-    if dist_on:
-        broadcast_parameters(layer, src=0)
-    reducer = GradientAllReducer(layer.parameters())
-
     if args.workload in SAINT:
-        run_saint(args, rank, world, dev, layer, reducer, N, E, L, D, H, desc, dt_name, tdt, R, dist_on)
-        if dist_on:
-            dist.barrier()
-            dist.destroy_process_group()
-        return
-
-    x, ei, dy = make_batch(N, E, L, D, 1234 + rank, dev, tdt, rmat=args.workload == 'cfg5')   # own graph per rank
-    x.requires_grad_(True)
-
-    timer = KernelTimer()
-    real_lib = _lib.load()
-    timed_lib = TimedLib(real_lib, timer)
-    orig_load = _lib.load
-    _lib.load = lambda: timed_lib                             # functional.py resolves the lib per call
-
-    def step():
-        graph_cache.clear()                                   # a new batch -> CSR build is in the step
-        layer.zero_grad(set_to_none=True)
-        x.grad = None
-        y = layer(x, ei)
-        y.backward(dy)
-        if dist_on:
-            reducer.allreduce()
-
-    def fence():
-        torch.cuda.synchronize()
-        if dist_on:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    fence()
-    timer.enabled = True
-    step_events = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        step()
-        e1.record()
-        step_events.append((e0, e1))
-    fence()
-    dt = time.perf_counter() - t0
-    timer.enabled = False
-    _lib.load = orig_load
-    step_ms = sorted(a.elapsed_time(b) for a, b in step_events)
-    median_ms = step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2])
-
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if dist_on:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
-
-    alt = None
-    if world == 1 and dt_name == 'f32' and args.gemm == 'native' and not args.no_alt_gemm and not args.softmax_free:
-        # same step with the projections on the library's fp32 GEMMs (rocBLAS) -- what round 2 measured; reported beside
-        layer.gemm_precision = 'fp32'
-        step()
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        fence()
-        dta = time.perf_counter() - t0
-        layer.gemm_precision = args.gemm
-        alt = {'gemm': 'fp32 (rocBLAS library GEMMs)', 'value': E * args.steps / dta, 'unit': 'edges/s',
-               'ms_per_step': 1e3 * dta / args.steps}
-
-    if rank == 0 and args.softmax_free:
-        # the edge phase of this variant is one segment reduction (conv/linear.py): no edge-kernel roofline
-        print(json.dumps({'metric': 'AMPConv edges/sec (fwd+bwd), softmax-free variant', 'value': world * E * args.steps / dt,
-                          'unit': 'edges/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-                          'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak',
-                          'vs_baseline': None, 'dtype': dt_name, 'data': 'synthetic',
-                          'config': {'workload': f'{args.workload}: {desc}, softmax-free AMPConv layer fwd+bwd',
-                                     'N': N, 'E': E, 'L': L, 'D': D, 'H': H, 'parallelism': f'dp{world}'}}), flush=True)
-    elif rank == 0:
-        ms = timer.summary()
-        alg = {'ampconv_fwd_edge': (2 * E + 2 * N) * R, 'ampconv_bwd_edge_dst': (2 * E + 3 * N) * R,
-               'ampconv_bwd_edge_src': (2 * E + 4 * N) * R}
-        kflops = {'ampconv_fwd_edge': 4 * L * L * D * E, 'ampconv_bwd_edge_dst': 6 * L * L * D * E,
-                  'ampconv_bwd_edge_src': 8 * L * L * D * E}   # multiply-adds x 2 of the products each pass does
-        dom = max(ms, key=ms.get)
-        achieved = alg[dom] / (ms[dom] * 1e-3) / 1e9
-        value = world * E * args.steps / dt
-        b_alg = (6 * E + 15 * N) * R + 16 * E                 # whole layer, SURVEY.md 8d
-        # SURVEY.md 8d names two rooflines: HBM for the edge phase, the matrix pipe for the per-node
-        # projections.  FLOPs per step: attention 14 L^2 D per edge, projections 24 L D^2 per node.
-        flops_attn, flops_proj = 14 * L * L * D * E, 24 * L * D * D * N
-        mfma_peak = MFMA_PEAK_TFLOPS[dt_name]
-        t_step = dt / args.steps
-        t_hbm, t_mfma = b_alg / (HBM_PEAK_GBS * 1e9), (flops_attn + flops_proj) / (mfma_peak * 1e12)
-        traffic = None                                         # PMC-measured HBM bytes per launch
-        try:                                                   # (profiles/pmc_traffic.json, same workload)
-            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')))
-            if pmc.get('workload') == args.workload and dt_name == 'f32':
-                traffic = pmc['kernels'][dom]['traffic_bytes']
-        except (OSError, KeyError, ValueError):
-            pass
-        out = {
-            'metric': 'AMPConv edges/sec (fwd+bwd)', 'value': value, 'unit': 'edges/s',
-            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': 1e3 * dt / args.steps, 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': dt_name, 'data': 'synthetic',
-            'config': {'workload': f'{args.workload}: {desc}, one AMPConv layer fwd+bwd incl. CSR build, '
-                                   f'one graph per GPU' + (' + RCCL grad all-reduce' if world > 1 else ''),
-                       'N': N, 'E': E, 'L': L, 'D': D, 'H': H, 'parallelism': f'dp{world}',
-                       'gemm': args.gemm if dt_name == 'f32' else 'bf16'},
-            'layer_hbm': {'algorithmic_bytes_per_step': b_alg,
-                          'achieved_GBps_per_gpu': b_alg * args.steps / dt / 1e9,
-                          'frac_of_8TBps': b_alg * args.steps / dt / 1e9 / HBM_PEAK_GBS},
-            'layer_flops': {'attention_per_step': flops_attn, 'projections_per_step': flops_proj,
-                            'achieved_TFLOPs_per_gpu': (flops_attn + flops_proj) / t_step / 1e12,
-                            'peak_TFLOPs': mfma_peak, 'frac_of_peak': (flops_attn + flops_proj) / t_step / 1e12 / mfma_peak,
-                            'peak_note': 'fp32-input MFMA = fp32 vector rate (157.3 TF)' if dt_name == 'f32'
-                                         else 'dense bf16 MFMA',
-                            'floor_ms': {'hbm_at_8TBps': 1e3 * t_hbm, 'mfma_at_peak': 1e3 * t_mfma},
-                            'binding': 'mfma' if t_mfma > t_hbm else 'hbm'},
-            'kernels_ms': ms,
-            'timing': 'value = wall clock over the K steps between barrier+synchronize fences, max over ranks '
-                      '(the contract); kernels_ms = mean HIP-event duration per launch over the same steps; '
-                      'ms_per_step_hip_events_median = median of per-step HIP-event durations on rank 0 (SURVEY 8d protocol)',
-            'ms_per_step_hip_events_median': median_ms,
-            'roofline': {'kernel': dom, 'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS,
-                         'unit': 'GB/s', 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'algorithmic_bytes_per_launch': alg[dom], 'avg_launch_ms': ms[dom],
-                         # the same launch against the arithmetic peak (fp32: MFMA and VALU share the FP32 pipe)
-                         'arithmetic': {'flops_per_launch': kflops[dom], 'achieved_TFLOPs': kflops[dom] / (ms[dom] * 1e-3) / 1e12,
-                                        'peak_TFLOPs': mfma_peak,
-                                        'frac': kflops[dom] / (ms[dom] * 1e-3) / 1e12 / mfma_peak}},
-        }
-        if alt is not None:
-            out['alt_gemm'] = alt
-        if world == 1 and not args.no_cpu_baseline:
-            del x, dy
-            torch.cuda.empty_cache()
+        out = measure_saint(args.workload, args.steps, args.warmup, args, rank, world, dev, dist_on, dt_name)
+    else:
+        alt = (world == 1 and dt_name == 'f32' and args.gemm == 'native' and not args.no_alt_gemm
+               and not args.softmax_free)
+        out = measure_full(args.workload, args.steps, args.warmup, args, rank, world, dev, dist_on, dt_name, alt=alt)
+        side = not args.no_extra and not args.softmax_free and args.dtype is None
+        saint_of = {'cfg4': 'cfg4-saint', 'tiny': 'tiny-saint'}
+        if side and dist_on and args.workload in saint_of:
+            # BASELINE config 4 as written, on the same ranks: the mode whose scaling curve can bend
+            # (34 ms steps, sampler read-backs, a 1 MB all-reduce)
+            s = measure_saint(saint_of[args.workload], max(20, args.steps), max(2, args.warmup), args, rank, world, dev,
+                              dist_on, 'f32')
+            out['saint'] = {k: s[k] for k in ('value', 'unit', 'ms_per_step', 'steps', 'nodes_avg', 'edges_avg',
+                                              'sampler_ms', 'allreduce_ms', 'kernels_ms', 'per_rank_ms')}
+            out['saint']['workload'] = s['config']['workload']
+        if side and world == 1 and args.workload == 'cfg4':
+            # the other full-size configurations, driver-observed: a few steps each
+            out['extra_workloads'] = {
+                w: _brief(measure_full(w, 3, 1, args, rank, world, dev, dist_on, 'bf16' if w == 'cfg5' else 'f32'))
+                for w in ('cfg3', 'cfg5')}
+        if world == 1 and not args.no_cpu_baseline and not args.softmax_free and rank == 0:
+            N, E, L, D, H, _ = WORKLOADS[args.workload]
             out['cpu_baseline'] = cpu_baseline(L, D, H, E / N)
+    if rank == 0:
         print(json.dumps(out), flush=True)
     if dist_on:
         dist.barrier()

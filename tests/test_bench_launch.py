@@ -45,3 +45,14 @@ def test_failed_rank_fails_the_launch():
     r = _run(['--gpus', '2', '--workload', 'tiny'], {})
     assert r.returncode != 0
     assert 'ranks failed' in r.stderr
+
+
+def test_one_rank_dying_after_the_rendezvous_stops_the_others():
+    # rank 1 exits right after init_process_group; rank 0 then sits in an all-reduce that can never
+    # complete.  The launcher must notice the first failure, stop the survivor and name the failed rank -- fast.
+    import time
+    t0 = time.time()
+    r = _run(['--gpus', '2', '--workload', 'tiny'], {'AMPCONV_BENCH_LAUNCH_ONLY': '1', 'AMPCONV_BENCH_FAIL_RANK': '1'})
+    assert r.returncode != 0
+    assert 'ranks failed' in r.stderr and '(1, 3)' in r.stderr and 'first: rank 1' in r.stderr, r.stderr[-2000:]
+    assert time.time() - t0 < 120

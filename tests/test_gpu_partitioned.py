@@ -78,6 +78,18 @@ def test_partitioned_layer_matches_single_process(tmp_path):
     for g0, g1, p in zip(r[0]['grads'], r[1]['grads'], layer.parameters()):
         assert torch.equal(g0, g1)                                     # summed over ranks, identical everywhere
         assert_close_scaled(g0.numpy(), p.grad.cpu().numpy(), 'parameter gradient')
+    # ... and against the ORACLE on the whole graph (SURVEY.md 8f row 4 has no reference counterpart: the oracle of
+    # the un-partitioned layer, pinned to the reference's fixtures by tests/test_oracle.py, is the checker)
+    from oracle.ampconv_numpy import AMPConvOracle
+    m = layer.multi_head_attention
+    o = AMPConvOracle(*(t.detach().cpu().numpy() for t in (m.in_proj_weight, m.in_proj_bias, m.out_proj.weight,
+                                                          m.out_proj.bias)), H)
+    y_ref, _ = o.forward(x.numpy(), ei.numpy())
+    dx_ref, dwin, dbin, dwo, dbo = o.backward(dy.numpy())
+    assert_close_scaled(y_part, y_ref, 'y vs oracle')
+    assert_close_scaled(dx_part, dx_ref, 'dx vs oracle')
+    for got, ref, name in zip(r[0]['grads'], (dwin, dbin, dwo, dbo), ('dW_in', 'db_in', 'dW_out', 'db_out')):
+        assert_close_scaled(got.numpy(), ref, name + ' vs oracle')
 
 
 def test_node_partition_bookkeeping():
@@ -97,8 +109,9 @@ def test_rccl_collectives_single_rank():
     import subprocess
     import sys
     code = '''
-import os, torch, torch.distributed as dist
-os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29544", RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+import os, socket, torch, torch.distributed as dist
+s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()      # any free port
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
 dist.init_process_group("nccl", device_id=dev)
@@ -122,3 +135,42 @@ print("rccl ok")
 '''
     r = subprocess.run([sys.executable, '-c', code], timeout=300, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     assert r.returncode == 0 and 'rccl ok' in r.stdout, r.stderr[-3000:]
+
+
+def test_partitioned_layer_async_rccl_branch_single_rank():
+    """the overlapped path of _PartitionedFunction (all_gather_into_tensor / reduce_scatter_tensor with
+    async_op=True, wait() between the Q-side and KV-side products, `del` of the in-flight source buffers) taken for
+    real: one rank under an nccl group with AMPCONV_PARTITION_FORCE_ASYNC=1, against the single-process layer."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    code = f'''
+import os, socket, sys, torch, torch.distributed as dist
+sys.path.insert(0, {ROOT!r}); sys.path.insert(0, os.path.join({ROOT!r}, "tests"))
+s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0",
+                  AMPCONV_PARTITION_FORCE_ASYNC="1")
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", device_id=dev)
+from conftest import assert_close_scaled
+from test_gpu_partitioned import _problem, _layer, N
+from ampnet_amd import NodePartition, PartitionedAMPConv
+x, dy, ei = _problem()
+part = NodePartition(N)
+assert part.native and part.force_async and part.world == 1
+ref = _layer(dev)
+xg = x.to(dev).requires_grad_(True)
+y = ref(xg, ei.to(dev)); y.backward(dy.to(dev))
+layer = PartitionedAMPConv(_layer(dev), part)
+xl = part.local_rows(x.to(dev)).requires_grad_(True)
+yp = layer(xl, layer.prepare(ei.to(dev))); yp.backward(part.local_rows(dy.to(dev)))
+assert_close_scaled(yp.detach().cpu().numpy(), y.detach().cpu().numpy(), "y")
+assert_close_scaled(xl.grad.cpu().numpy(), xg.grad.cpu().numpy(), "dx")
+for p, q in zip(layer.parameters(), ref.parameters()):
+    assert_close_scaled(p.grad.cpu().numpy(), q.grad.cpu().numpy(), "parameter gradient")
+dist.destroy_process_group()
+print("async partitioned ok")
+'''
+    r = subprocess.run([sys.executable, '-c', code], timeout=600, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0 and 'async partitioned ok' in r.stdout, r.stderr[-3000:]
