@@ -30,12 +30,20 @@ class View(ctypes.Structure):
 
 _vp, _i64, _i32, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_size_t
 
+
+class WeightImage(ctypes.Structure):
+    """ampconv_weight_image_t: one job of ampconv_proj_weight_images."""
+    _fields_ = [('W', ctypes.c_void_p), ('stride_n', ctypes.c_int64), ('stride_k', ctypes.c_int64),
+                ('N', ctypes.c_int), ('K', ctypes.c_int), ('image', ctypes.c_void_p)]
+
 # name -> (restype, argtypes); mirrors include/ampconv.h one to one
 SIGNATURES = {
     'ampconv_version': (_i32, []),
     'ampconv_error_string': (ctypes.c_char_p, [_i32]),
     'ampconv_csr_workspace_bytes': (_sz, [_i64, _i64]),
     'ampconv_csr_build': (_i32, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'ampconv_graph_build': (_i32, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'ampconv_csc_positions_from': (_i32, [_vp, _vp, _i64, _vp, _vp]),
     'ampconv_hub_plan_bytes': (_sz, [_i64, _i32]),
     'ampconv_hub_plan': (_i32, [_vp, _i64, _i64, _i32, _vp, _vp]),
     'ampconv_hub_workspace_bytes': (_sz, [_i64, _i32, _i32, _i32]),
@@ -65,6 +73,7 @@ SIGNATURES = {
     'ampconv_proj_supported': (_i32, [_i32, _i32]),
     'ampconv_proj_weight_image_bytes': (_sz, [_i32, _i32]),
     'ampconv_proj_weight_image': (_i32, [_vp, _i64, _i64, _i32, _i32, _vp, _vp]),
+    'ampconv_proj_weight_images': (_i32, [_i32, _vp, _vp]),
     'ampconv_proj_rows': (_i32, [_vp, _i64, _i64, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i64, _vp]),
     'ampconv_proj_wgrad_workspace_bytes': (_sz, [_i64, _i32, _i32]),
     'ampconv_proj_wgrad': (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _sz, _vp]),

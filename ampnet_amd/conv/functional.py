@@ -104,18 +104,32 @@ def proj_native(gemm, dtype, D):
     return gemm == 'native' and dtype == torch.float32 and bool(_lib.load().ampconv_proj_supported(D, D))
 
 
-def proj_image(W, transpose=False):
-    """MFMA-fragment image of the fp32 weight W [R, C] (rows contiguous): of W itself for out = in @ W^T
-    (the forward direction of nn.Linear), of W^T for out = in @ W (its input gradient)."""
+def proj_images(jobs):
+    """MFMA-fragment images of fp32 weights, ALL in one launch: `jobs` = [(W, transpose), ...] (at most 8), W [R, C]
+    with contiguous rows; an image of W itself serves out = in @ W^T (the forward direction of nn.Linear), of W^T
+    serves out = in @ W (its input gradient).  Returns [(image bytes, N, K), ...]."""
     lib = _lib.load()
-    assert W.dim() == 2 and W.stride(1) == 1 and W.dtype == torch.float32
-    R, C = W.shape
-    N, K = (C, R) if transpose else (R, C)
-    sn, sk = (1, W.stride(0)) if transpose else (W.stride(0), 1)
-    img = torch.empty(lib.ampconv_proj_weight_image_bytes(N, K), dtype=torch.uint8, device=W.device)
-    _lib.check(lib.ampconv_proj_weight_image(W.data_ptr(), sn, sk, N, K, img.data_ptr(), _stream()),
-               'ampconv_proj_weight_image')
-    return img, N, K
+    descs, outs, off = (_lib.WeightImage * len(jobs))(), [], 0
+    dims = []
+    for W, transpose in jobs:
+        assert W.dim() == 2 and W.stride(1) == 1 and W.dtype == torch.float32
+        R, C = W.shape
+        N, K = (C, R) if transpose else (R, C)
+        dims.append((N, K, lib.ampconv_proj_weight_image_bytes(N, K)))
+    buf = torch.empty(sum(d[2] for d in dims), dtype=torch.uint8, device=jobs[0][0].device)
+    for i, ((W, transpose), (N, K, nb)) in enumerate(zip(jobs, dims)):
+        sn, sk = (1, W.stride(0)) if transpose else (W.stride(0), 1)
+        img = buf[off:off + nb]
+        descs[i] = _lib.WeightImage(W.data_ptr(), sn, sk, N, K, img.data_ptr())
+        outs.append((img, N, K))
+        off += nb
+    _lib.check(lib.ampconv_proj_weight_images(len(jobs), ctypes.cast(descs, ctypes.c_void_p), _stream()),
+               'ampconv_proj_weight_images')
+    return outs
+
+
+def proj_image(W, transpose=False):
+    return proj_images([(W, transpose)])[0]
 
 
 def proj_rows(a2, image, bias=None, rowptr=None, L=0):
@@ -179,9 +193,13 @@ class AMPConvFunction(torch.autograd.Function):
         Nq, Nk = xq.size(0), xkv.size(0)
         xq2 = xq.contiguous().view(Nq * L, D)
         native = proj_native(gemm, xq.dtype, D)
+        imgs = None
         with torch.cuda.device(xq.device), gemm_precision(gemm):
+            if native:      # every weight image this call and its backward need, in one launch
+                ws = [w_in, w_out] if shared else [w_in[:D], w_in[D:], w_out]
+                imgs = proj_images([(w, False) for w in ws] + [(w, True) for w in ws])
             if shared:
-                qkv = (proj_rows(xq2, proj_image(w_in), b_in) if native
+                qkv = (proj_rows(xq2, imgs[0], b_in) if native
                        else torch.addmm(b_in, xq2, w_in.t()))              # [N*L, 3D]
                 Qv, Kv, Vv = (_view(qkv, i * D, L, dh) for i in range(3))
                 xkv2 = xq2
@@ -189,8 +207,8 @@ class AMPConvFunction(torch.autograd.Function):
             else:
                 xkv2 = xkv.contiguous().view(Nk * L, D)
                 if native:
-                    qkv = proj_rows(xq2, proj_image(w_in[:D]), b_in[:D])
-                    kv = proj_rows(xkv2, proj_image(w_in[D:]), b_in[D:])
+                    qkv = proj_rows(xq2, imgs[0], b_in[:D])
+                    kv = proj_rows(xkv2, imgs[1], b_in[D:])
                 else:
                     qkv = torch.addmm(b_in[:D], xq2, w_in[:D].t())         # [Nq*L, D]
                     kv = torch.addmm(b_in[D:], xkv2, w_in[D:].t())         # [Nk*L, 2D]
@@ -199,7 +217,7 @@ class AMPConvFunction(torch.autograd.Function):
             obar = torch.empty(Nq * L, D, dtype=xq.dtype, device=xq.device)
             edge_forward(Qv, Kv, Vv, csr, Nq, L, D, H, obar, dtype=dtype)
             if native:      # bias and the in-degree mask (rows nobody sends to stay exactly 0) in the epilogue
-                y = proj_rows(obar, proj_image(w_out), b_out, csr.rowptr, L)
+                y = proj_rows(obar, imgs[1 if shared else 2], b_out, csr.rowptr, L)
             else:
                 y = torch.addmm(b_out, obar, w_out.t())
                 io = _lib.AMPCONV_BF16 if y.dtype == torch.bfloat16 else _lib.AMPCONV_F32
@@ -208,6 +226,7 @@ class AMPConvFunction(torch.autograd.Function):
         ctx.set_materialize_grads(False)     # no zero-filled [N*L, 3D] gradient for the qkv side output
         ctx.save_for_backward(xq2, xkv2, w_in, w_out, qkv, kv, obar)
         ctx.csr, ctx.dims, ctx.shared, ctx.dtype, ctx.gemm = csr, (Nq, Nk, L, D, H), shared, dtype, gemm
+        ctx.images_t = imgs[len(imgs) // 2:] if imgs else None     # the transposed images, for the input gradients
         ctx.mark_non_differentiable(qkv)
         if kv is not None:
             ctx.mark_non_differentiable(kv)
@@ -233,7 +252,7 @@ class AMPConvFunction(torch.autograd.Function):
                 dw_out = torch.empty_like(w_out)
                 db_out = torch.empty(D, dtype=torch.float32, device=dev)
                 proj_wgrad(dy2, obar, dw_out, db_out, csr.rowptr, L)
-                dobar = proj_rows(dy2, proj_image(w_out, transpose=True))
+                dobar = proj_rows(dy2, ctx.images_t[-1])
             else:
                 scratch = torch.empty((1 + _lib.COLSUM_BLOCKS) * D, dtype=torch.float32, device=dev)
                 io = _lib.AMPCONV_BF16 if dy2.dtype == torch.bfloat16 else _lib.AMPCONV_F32
@@ -287,13 +306,13 @@ class AMPConvFunction(torch.autograd.Function):
                 db_in = torch.empty(3 * D, dtype=torch.float32, device=dev)
                 if shared:
                     proj_wgrad(dqkv, xq2, dw_in, db_in)
-                    dxq = proj_rows(dqkv, proj_image(w_in, transpose=True)).view(Nq, L * D) if need_xq else None
+                    dxq = proj_rows(dqkv, ctx.images_t[0]).view(Nq, L * D) if need_xq else None
                     dxkv = None
                 else:
                     proj_wgrad(dqkv, xq2, dw_in[:D], db_in[:D])
                     proj_wgrad(dkv, xkv2, dw_in[D:], db_in[D:])
-                    dxq = proj_rows(dqkv, proj_image(w_in[:D], transpose=True)).view(Nq, L * D) if need_xq else None
-                    dxkv = proj_rows(dkv, proj_image(w_in[D:], transpose=True)).view(Nk, L * D) if need_xkv else None
+                    dxq = proj_rows(dqkv, ctx.images_t[0]).view(Nq, L * D) if need_xq else None
+                    dxkv = proj_rows(dkv, ctx.images_t[1]).view(Nk, L * D) if need_xkv else None
             elif shared:
                 dw_in = _tn_matmul(dqkv, xq2)
                 if db_v is not None:

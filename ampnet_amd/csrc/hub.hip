@@ -104,6 +104,8 @@ __global__ __launch_bounds__(256) void hub_combine_kernel(const HubDesc *__restr
 
 }  // namespace
 
+int64_t ampconv_hub_max_chunks(int64_t E, int chunk) { return hub_max_chunks(E, chunk); }
+
 extern "C" size_t ampconv_hub_plan_bytes(int64_t E, int chunk) {
   if (E < 0 || chunk <= 0) return 0;
   const size_t mc = (size_t)hub_max_chunks(E, chunk);

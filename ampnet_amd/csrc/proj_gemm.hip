@@ -108,15 +108,24 @@ __device__ unsigned long long g_proj_stamps[8 * 4096];
 //   B[n32 * 32 + r][ks * 16 + 8 h + 0..7]      with B[n][k] = W[n * stride_n + k * stride_k]
 // i.e. exactly the B operand of v_mfma_f32_32x32x16_bf16, in lane order; the fragments of one k step and one
 // block of columns are contiguous, so a stage is one linear LDS-DMA copy.
-__global__ void weight_image_kernel(const float *__restrict__ W, int64_t sn, int64_t sk, int N, int K,
-                                    char *__restrict__ img) {
-  const int k8s = K / 8;
+struct ImageJob {
+  const float *W;
+  int64_t sn, sk;
+  int N, K;
+  char *img;
+};
+struct ImageJobs {
+  ImageJob j[8];
+};
+__global__ void weight_image_kernel(ImageJobs jobs) {
+  const ImageJob jb = jobs.j[blockIdx.y];
+  const int k8s = jb.K / 8;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= N * k8s) return;
+  if (idx >= jb.N * k8s) return;
   const int n = idx / k8s, k8 = idx - n * k8s;
   float x[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) x[j] = W[(int64_t)n * sn + (int64_t)(8 * k8 + j) * sk];
+  for (int j = 0; j < 8; ++j) x[j] = jb.W[(int64_t)n * jb.sn + (int64_t)(8 * k8 + j) * jb.sk];
   i32x4 pl[3];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
@@ -124,7 +133,7 @@ __global__ void weight_image_kernel(const float *__restrict__ W, int64_t sn, int
     pl[0][t] = q.h1; pl[1][t] = q.h2; pl[2][t] = q.h3;
   }
   const int ks = k8 >> 1, h = k8 & 1, n32 = n >> 5, r = n & 31;
-  char *dst = img + ((size_t)(ks * (N / 32) + n32) * 3) * kFrag + (32 * h + r) * 16;
+  char *dst = jb.img + ((size_t)(ks * (jb.N / 32) + n32) * 3) * kFrag + (32 * h + r) * 16;
 #pragma unroll
   for (int p = 0; p < 3; ++p) *reinterpret_cast<i32x4 *>(dst + p * kFrag) = pl[p];
 }
@@ -561,20 +570,44 @@ __global__ __launch_bounds__(64 * WI * WJ, 2) void proj_wgrad_kernel(WgradArgs a
   }
 }
 
-// out[e] = sum over the slices, in slice order, of part[s][e]; e < n_dw goes to dW, the rest to colsum
-__global__ void wgrad_reduce_kernel(const float *__restrict__ part, int S, int64_t n_dw, int64_t n_all,
-                                    float *__restrict__ dW, float *__restrict__ colsum) {
-  const int64_t e = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  if (e >= n_all) return;
-  float4 acc = *reinterpret_cast<const float4 *>(part + e);
-  for (int s = 1; s < S; ++s) {
-    const float4 v = *reinterpret_cast<const float4 *>(part + (size_t)s * n_all + e);
-    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+// out[e] = sum over the slices of part[s][e]; e < n_dw goes to dW, the rest to colsum.  256 threads = 32 float4
+// elements x 8 slice phases: phase g adds slices g, g + 8, ... in order (four loads in flight), the eight phase sums
+// meet in LDS and are added in a fixed order -- bitwise reproducible, and S / 8 dependent load rounds instead of S
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ part, int S, int64_t n_dw,
+                                                           int64_t n_all, float *__restrict__ dW,
+                                                           float *__restrict__ colsum) {
+  __shared__ float4 red[8][32];
+  const int el = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int64_t e = ((int64_t)blockIdx.x * 32 + el) * 4;
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (e < n_all) {
+    float4 a1 = acc;
+    int s = g;
+    for (; s + 8 < S; s += 16) {
+      const float4 v0 = *reinterpret_cast<const float4 *>(part + (size_t)s * n_all + e);
+      const float4 v1 = *reinterpret_cast<const float4 *>(part + (size_t)(s + 8) * n_all + e);
+      acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
+      a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+    }
+    if (s < S) {
+      const float4 v0 = *reinterpret_cast<const float4 *>(part + (size_t)s * n_all + e);
+      acc.x += v0.x; acc.y += v0.y; acc.z += v0.z; acc.w += v0.w;
+    }
+    acc.x += a1.x; acc.y += a1.y; acc.z += a1.z; acc.w += a1.w;
   }
-  if (e < n_dw)
-    *reinterpret_cast<float4 *>(dW + e) = acc;
-  else if (colsum)
-    *reinterpret_cast<float4 *>(colsum + (e - n_dw)) = acc;
+  red[g][el] = acc;
+  __syncthreads();
+  if (g == 0 && e < n_all) {
+#pragma unroll
+    for (int k = 1; k < 8; ++k) {
+      const float4 v = red[k][el];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    if (e < n_dw)
+      *reinterpret_cast<float4 *>(dW + e) = acc;
+    else if (colsum)
+      *reinterpret_cast<float4 *>(colsum + (e - n_dw)) = acc;
+  }
 }
 
 struct WgradPlan {
@@ -612,14 +645,26 @@ extern "C" int ampconv_proj_supported(int N, int K) {
   return N > 0 && K > 0 && N % 128 == 0 && K % 32 == 0;
 }
 
+extern "C" int ampconv_proj_weight_images(int count, const ampconv_weight_image_t *jobs, void *stream) {
+  if (count < 0 || count > 8 || (count && !jobs)) return AMPCONV_E_BADARG;
+  if (count == 0) return AMPCONV_OK;
+  ImageJobs js;
+  int most = 0;
+  for (int i = 0; i < count; ++i) {
+    const ampconv_weight_image_t &w = jobs[i];
+    if (!ampconv_proj_supported(w.N, w.K) || !w.W || !w.image || (uintptr_t)w.image % 16) return AMPCONV_E_BADARG;
+    js.j[i] = ImageJob{w.W, w.stride_n, w.stride_k, w.N, w.K, (char *)w.image};
+    const int total = w.N * (w.K / 8);
+    most = total > most ? total : most;
+  }
+  weight_image_kernel<<<dim3((most + 255) / 256, count), 256, 0, (hipStream_t)stream>>>(js);
+  return ampconv_launch_status();
+}
+
 extern "C" int ampconv_proj_weight_image(const float *W, int64_t stride_n, int64_t stride_k, int N, int K,
                                          void *image, void *stream) {
-  if (!ampconv_proj_supported(N, K)) return AMPCONV_E_BADARG;
-  if (!W || !image || (uintptr_t)image % 16) return AMPCONV_E_BADARG;
-  const int total = N * (K / 8);
-  weight_image_kernel<<<(total + 255) / 256, 256, 0, (hipStream_t)stream>>>(W, stride_n, stride_k, N, K,
-                                                                            (char *)image);
-  return ampconv_launch_status();
+  const ampconv_weight_image_t job{W, stride_n, stride_k, N, K, image};
+  return ampconv_proj_weight_images(1, &job, stream);
 }
 
 extern "C" int ampconv_proj_rows(const float *A, int64_t lda, int64_t M, int K, const void *wimage, int N,
@@ -692,7 +737,7 @@ extern "C" int ampconv_proj_wgrad(const float *A, int64_t lda, const float *B, i
     if (rowptr) proj_wgrad_kernel<128, 128, 2, 2, true><<<grid, 256, 0, st>>>(a);
     else proj_wgrad_kernel<128, 128, 2, 2, false><<<grid, 256, 0, st>>>(a);
   }
-  wgrad_reduce_kernel<<<(unsigned)((n_all / 4 + 255) / 256), 256, 0, st>>>((const float *)workspace, p.S,
+  wgrad_reduce_kernel<<<(unsigned)((n_all / 4 + 31) / 32), 256, 0, st>>>((const float *)workspace, p.S,
                                                                           (int64_t)Na * Nb, (int64_t)n_all, dW, colsum);
   return ampconv_launch_status();
 }

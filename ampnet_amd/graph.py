@@ -40,34 +40,33 @@ class EdgeCSR:
         self.crow = torch.empty(max(E, 1), **i32)
         self.cperm = torch.empty(max(E, 1), **i32)
         self.cinv = torch.empty(max(E, 1), dtype=torch.float32, device=dev)
-        oob = torch.zeros(1, **i32)
+        status = torch.empty(4, **i32)                   # {bounds flag, dst chunks, src chunks, -}: ONE read-back
+        self._by_edge = torch.empty(max(E, 1), **i32)     # CSC position of every original edge id
         with torch.cuda.device(dev):
             ws_bytes = lib.ampconv_csr_workspace_bytes(N, E) if E > 0 else 0
             ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
-            rc = lib.ampconv_csr_build(ei.data_ptr(), E, N, self.rowptr.data_ptr(), self.col.data_ptr(),
-                                       self.eperm.data_ptr(), self.cscptr.data_ptr(), self.crow.data_ptr(),
-                                       self.cperm.data_ptr(), self.cinv.data_ptr(), oob.data_ptr(), ws.data_ptr(),
-                                       ws_bytes,
-                                       _stream())
-            _lib.check(rc, 'ampconv_csr_build')
             # long-segment plans (hubs of power-law graphs): one for the dst-sorted CSR, one for the
-            # src-sorted CSC; their chunk counts come back with the bounds flag in ONE read-back
+            # src-sorted CSC, made by the same call
             self.hub_dst = self.hub_src = None
             self.hub_dst_chunks = self.hub_src_chunks = 0
+            plans = [None, None]
             if E > _lib.HUB_CHUNK:
                 nb = lib.ampconv_hub_plan_bytes(E, _lib.HUB_CHUNK)
                 plans = [torch.empty(nb // 4, **i32), torch.empty(nb // 4, **i32)]
-                for plan, ptr in zip(plans, (self.rowptr, self.cscptr)):
-                    _lib.check(lib.ampconv_hub_plan(ptr.data_ptr(), N, E, _lib.HUB_CHUNK, plan.data_ptr(),
-                                                    _stream()), 'ampconv_hub_plan')
-                bad, self.hub_dst_chunks, self.hub_src_chunks = torch.stack(
-                    [oob[0], plans[0][0], plans[1][0]]).tolist()
+            rc = lib.ampconv_graph_build(ei.data_ptr(), E, N, self.rowptr.data_ptr(), self.col.data_ptr(),
+                                         self.eperm.data_ptr(), self.cscptr.data_ptr(), self.crow.data_ptr(),
+                                         self.cperm.data_ptr(), self.cinv.data_ptr(), status.data_ptr(), _lib.HUB_CHUNK,
+                                         plans[0].data_ptr() if plans[0] is not None else None,
+                                         plans[1].data_ptr() if plans[1] is not None else None,
+                                         self._by_edge.data_ptr(), ws.data_ptr(), ws_bytes, _stream())
+            _lib.check(rc, 'ampconv_graph_build')
+            bad = 0
+            if plans[0] is not None or (validate and E > 0):
+                bad, self.hub_dst_chunks, self.hub_src_chunks, _ = status.tolist()
                 if self.hub_dst_chunks:
                     self.hub_dst = plans[0][: 4 + 4 * self.hub_dst_chunks]
                 if self.hub_src_chunks:
                     self.hub_src = plans[1][: 4 + 4 * self.hub_src_chunks]
-            else:
-                bad = int(oob.item()) if (validate and E > 0) else 0
         if validate and E > 0 and bad != 0:
             raise ValueError(f'edge_index contains node ids outside [0, {N})')
 
@@ -94,11 +93,10 @@ class EdgeCSR:
                 self._spos = self.eperm
             else:
                 self._spos = torch.empty(max(E, 1), dtype=torch.int32, device=self.device)
-                scratch = torch.empty(max(E, 1), dtype=torch.int32, device=self.device)
                 with torch.cuda.device(self.device):
-                    rc = lib.ampconv_csc_positions(self.eperm.data_ptr(), self.cperm.data_ptr(), E,
-                                                   scratch.data_ptr(), self._spos.data_ptr(), _stream())
-                _lib.check(rc, 'ampconv_csc_positions')
+                    rc = lib.ampconv_csc_positions_from(self.eperm.data_ptr(), self._by_edge.data_ptr(), E,
+                                                        self._spos.data_ptr(), _stream())
+                _lib.check(rc, 'ampconv_csc_positions_from')
         return self._spos
 
     def hub_args(self, side, L, D, n_tiles):

@@ -261,6 +261,22 @@ def launch_ranks(n):
     sys.exit(0)
 
 
+class _stdout_to_stderr:
+    """RCCL prints a version banner on STDOUT when its first communicator comes up; the contract is ONE JSON line there.
+    File-descriptor level redirect (the banner comes from C code) for the duration of the block."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def _fence(dist_on):
     torch.cuda.synchronize()
     if dist_on:
@@ -618,7 +634,12 @@ def main():
                 os.environ['MASTER_PORT'] = str(s.getsockname()[1])
         os.environ.setdefault('RANK', '0')
         os.environ.setdefault('WORLD_SIZE', '1')
-        dist.init_process_group(backend, **({'device_id': dev} if backend == 'nccl' else {}))
+        with _stdout_to_stderr():
+            dist.init_process_group(backend, **({'device_id': dev} if backend == 'nccl' else {}))
+            warm = torch.zeros(1, device=dev)
+            dist.all_reduce(warm)                             # communicator (and its banner) up before anything is timed
+            dist.barrier()
+            torch.cuda.synchronize()
 
     dt_name = args.dtype or ('bf16' if args.workload == 'cfg5' else 'f32')
     if args.workload in SAINT:

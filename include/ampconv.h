@@ -91,6 +91,20 @@ int ampconv_csr_build(const int64_t *edge_index, int64_t E, int64_t N,
                       int32_t *oob, void *workspace, size_t workspace_bytes,
                       void *stream);
 
+/* csr_build and both long-segment plans (below; chunk <= 0 or a NULL plan: none) in one call.  Graphs of at most
+ * 12 288 edges and 16 384 nodes -- GraphSAINT batches, Cora: the reference's own regime -- are prepared by ONE launch
+ * (two workgroups, the stable sorts in LDS); larger ones by the calls above.  Same outputs either way.
+ * `status` (device int32[4]) = {bounds flag as `oob` above, chunks of plan_dst, chunks of plan_src, 0}: everything the
+ * host needs back, in one 16-byte read.  `by_edge` (E int32, may be NULL): CSC position of every ORIGINAL edge id,
+ * from which ampconv_csc_positions_from derives `spos` (below) in one launch.  */
+int ampconv_graph_build(const int64_t *edge_index, int64_t E, int64_t N,
+                        int32_t *rowptr, int32_t *col, int32_t *eperm,
+                        int32_t *cscptr, int32_t *crow, int32_t *cperm, float *cinv,
+                        int32_t *status, int chunk, void *plan_dst, void *plan_src,
+                        int32_t *by_edge, void *workspace, size_t workspace_bytes, void *stream);
+int ampconv_csc_positions_from(const int32_t *eperm, const int32_t *by_edge, int64_t E,
+                               int32_t *spos, void *stream);
+
 /* spos[p] = position in the src-sorted CSC of the edge at position p of the dst-sorted CSR
  * (eperm, cperm of ampconv_csr_build; `scratch` = E int32).  Needed only to hand softmax
  * statistics from the destination pass to the source pass (below).  */
@@ -213,6 +227,7 @@ int ampconv_masked_colsum(const void *dY, const int32_t *rowptr, int64_t N,
  *                        (proj_weight_image_bytes(N, K) bytes, 16-byte aligned): the three bf16 planes
  *                        of the weight as ready MFMA fragments.  (stride_n, stride_k) = (K, 1) uses a
  *                        row-major [N, K] weight as it stands (forward), (1, N) its transpose (backward).
+ *   proj_weight_images : up to 8 of them in ONE launch (forward and transposed images of both weights of a layer)
  *   proj_rows          : out[m, :N] = (A[m, :K] B^T + bias) * (rowptr ? [node m / L has an in-edge] : 1)
  *                        A row-major with leading dimension lda (elements), out with ldc
  *   proj_wgrad         : dW[Na, Nb] = sum_m (mask_m A[m, :Na])^T B[m, :Nb] and colsum[Na] = sum_m mask_m A[m, :Na]
@@ -222,6 +237,13 @@ int ampconv_proj_supported(int N, int K);
 size_t ampconv_proj_weight_image_bytes(int N, int K);
 int ampconv_proj_weight_image(const float *W, int64_t stride_n, int64_t stride_k, int N, int K,
                               void *image, void *stream);
+typedef struct {
+  const float *W;
+  int64_t stride_n, stride_k;
+  int N, K;
+  void *image;
+} ampconv_weight_image_t;
+int ampconv_proj_weight_images(int count, const ampconv_weight_image_t *jobs, void *stream);
 int ampconv_proj_rows(const float *A, int64_t lda, int64_t M, int K, const void *wimage, int N,
                       const float *bias, const int32_t *rowptr, int L, float *out, int64_t ldc,
                       void *stream);

@@ -158,23 +158,50 @@ def test_aggregate_known_answer(dev):
         assert (out[[0, 1, 3, 4]] == 0).all()
 
 
-def test_csr_build_is_a_stable_sort(dev):
-    from ampnet_amd import EdgeCSR
+@pytest.mark.parametrize('N,E,hub', [(1000, 20000, 4000), (2708, 10556, 300), (16384, 12288, 0), (37, 65, 0), (500, 12289, 70)],
+                         ids=['large-path', 'cora-small-path', 'small-path-limits', 'tiny', 'just-over-the-limit'])
+def test_csr_build_is_a_stable_sort(N, E, hub, dev):
+    """Both preparation paths of ampconv_graph_build -- one launch for graphs of at most 12 288 edges / 16 384 nodes
+    (the stable sorts in LDS), device-wide radix sorts above -- against numpy's stable argsort: positions, pointers,
+    1 / in-degree, and the long-segment plans as SETS of descriptors (their slot order is arbitrary by design)."""
+    from ampnet_amd import EdgeCSR, _lib
     rng = np.random.default_rng(3)
-    N, E = 1000, 20000
     ei = rng.integers(0, N, size=(2, E)).astype(np.int64)
-    ei[1, :4000] = 7                                  # a hub
+    ei[1, :hub] = 7                                   # a hub destination ...
+    ei[0, hub:hub + hub // 2] = 11                    # ... and a hub source
     csr = EdgeCSR(torch.from_numpy(ei).to(dev), N)
     perm = np.argsort(ei[1], kind='stable')
     np.testing.assert_array_equal(csr.eperm.cpu().numpy(), perm)
     np.testing.assert_array_equal(csr.col.cpu().numpy(), ei[0][perm])
-    np.testing.assert_array_equal(csr.rowptr.cpu().numpy(),
-                                  np.concatenate([[0], np.cumsum(np.bincount(ei[1], minlength=N))]))
+    rowptr = np.concatenate([[0], np.cumsum(np.bincount(ei[1], minlength=N))])
+    np.testing.assert_array_equal(csr.rowptr.cpu().numpy(), rowptr)
     cperm = np.argsort(ei[0], kind='stable')
     np.testing.assert_array_equal(csr.cperm.cpu().numpy(), cperm)
     np.testing.assert_array_equal(csr.crow.cpu().numpy(), ei[1][cperm])
-    np.testing.assert_array_equal(csr.cscptr.cpu().numpy(),
-                                  np.concatenate([[0], np.cumsum(np.bincount(ei[0], minlength=N))]))
+    cscptr = np.concatenate([[0], np.cumsum(np.bincount(ei[0], minlength=N))])
+    np.testing.assert_array_equal(csr.cscptr.cpu().numpy(), cscptr)
+    np.testing.assert_array_equal(csr.cinv.cpu().numpy(), (1.0 / np.bincount(ei[1], minlength=N)[ei[1][cperm]]).astype(np.float32))
+    chunk = _lib.HUB_CHUNK
+    for plan, n, ptr in ((csr.hub_dst, csr.hub_dst_chunks, rowptr), (csr.hub_src, csr.hub_src_chunks, cscptr)):
+        want = set()
+        for r in np.nonzero(np.diff(ptr) > chunk)[0]:
+            b, e = int(ptr[r]), int(ptr[r + 1])
+            nc = -(-(e - b) // chunk)
+            want |= {(int(r), b + k * chunk, min(e, b + (k + 1) * chunk), nc if k == 0 else 0) for k in range(nc)}
+        assert n == len(want)
+        if n:
+            got = plan.cpu().numpy()[4:4 + 4 * n].reshape(n, 4)
+            assert {tuple(int(v) for v in row) for row in got} == want
+
+
+def test_small_graph_preparation_flags_out_of_range_ids(dev):
+    from ampnet_amd import EdgeCSR
+    ei = torch.tensor([[0, 1, 2, 9], [1, 2, 0, 1]], device=dev)
+    with pytest.raises(ValueError, match='outside'):
+        EdgeCSR(ei, 5)
+    ei[0, 3] = -1
+    with pytest.raises(ValueError, match='outside'):
+        EdgeCSR(ei, 5)
 
 
 def test_edge_cases(dev):
