@@ -63,6 +63,7 @@ SIGNATURES = {
     'ampconv_saint_workspace_bytes': (_sz, [_i64]),
     'ampconv_saint_nodes': (_i32, [_vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'ampconv_saint_count_edges': (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'ampconv_saint_count_edges_bounded': (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'ampconv_saint_fill_edges': (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     'ampconv_saint_add_counts': (_i32, [_vp, _i64, _vp, _vp]),
     'ampconv_saint_norms': (_i32, [_vp, _vp, _vp, _i64, _i64, ctypes.c_float, _vp, _vp, _vp]),

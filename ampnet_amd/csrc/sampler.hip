@@ -68,6 +68,21 @@ __global__ void count_edges_kernel(const int64_t *__restrict__ node_idx, int64_t
   cnt[k] = c;
 }
 
+// the same with the number of sampled nodes still on the device: k runs over an upper bound, entries past it count 0
+__global__ void count_edges_bounded_kernel(const int64_t *__restrict__ node_idx, int64_t n_bound,
+                                           const int32_t *__restrict__ n_sub_dev, const int32_t *__restrict__ cscptr,
+                                           const int32_t *__restrict__ crow, const int32_t *__restrict__ mark,
+                                           int32_t *__restrict__ cnt) {
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k > n_bound) return;
+  int c = 0;
+  if (k < *n_sub_dev) {
+    const int64_t u = node_idx[k];
+    for (int p = cscptr[u]; p < cscptr[u + 1]; ++p) c += mark[crow[p]];
+  }
+  cnt[k] = c;
+}
+
 __global__ void fill_edges_kernel(const int64_t *__restrict__ node_idx, int64_t n_sub,
                                   const int32_t *__restrict__ cscptr, const int32_t *__restrict__ crow,
                                   const int32_t *__restrict__ cperm, const int32_t *__restrict__ mark,
@@ -175,6 +190,25 @@ extern "C" int ampconv_saint_count_edges(const int64_t *node_idx, int64_t n_sub,
   e = hipcub::DeviceScan::ExclusiveSum(workspace, tb, cnt, off, (int)(n_sub + 1), stream);
   if (e != hipSuccess) return (int)e;
   e = hipMemcpyAsync(e_sub, off + n_sub, sizeof(int32_t), hipMemcpyDeviceToDevice, stream);
+  return e == hipSuccess ? AMPCONV_OK : (int)e;
+}
+
+// as count_edges, before the host knows n_sub: `n_bound` >= n_sub (e.g. min(walked nodes, N)), n_sub read from the
+// device; cnt / off have n_bound + 1 entries, e_sub = off[n_bound].  Lets ONE read-back return both sizes.
+extern "C" int ampconv_saint_count_edges_bounded(const int64_t *node_idx, int64_t n_bound, const int32_t *n_sub_dev,
+                                                 const int32_t *cscptr, const int32_t *crow, const int32_t *mark,
+                                                 int32_t *cnt, int32_t *off, int32_t *e_sub, void *workspace,
+                                                 size_t workspace_bytes, void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (n_bound < 0 || !e_sub || !n_sub_dev || !node_idx || !cscptr || !mark || !cnt || !off || !workspace)
+    return AMPCONV_E_BADARG;
+  if (workspace_bytes < scan_bytes(n_bound + 1)) return AMPCONV_E_WORKSPACE;
+  count_edges_bounded_kernel<<<(unsigned)((n_bound + 1 + 127) / 128), 128, 0, stream>>>(node_idx, n_bound, n_sub_dev,
+                                                                                      cscptr, crow, mark, cnt);
+  size_t tb = scan_bytes(n_bound + 1);
+  hipError_t e = hipcub::DeviceScan::ExclusiveSum(workspace, tb, cnt, off, (int)(n_bound + 1), stream);
+  if (e != hipSuccess) return (int)e;
+  e = hipMemcpyAsync(e_sub, off + n_bound, sizeof(int32_t), hipMemcpyDeviceToDevice, stream);
   return e == hipSuccess ? AMPCONV_OK : (int)e;
 }
 

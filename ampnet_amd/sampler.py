@@ -60,6 +60,13 @@ class GraphSAINTRandomWalkSampler:
         with torch.cuda.device(dev):
             if walks is not None:
                 walks = walks.to(device=dev, dtype=torch.int64).contiguous()
+                # replayed ids go straight into mark[node] = 1 on the device: refuse what would write out of bounds
+                # (one read-back, on this test / replay path only)
+                if walks.dim() != 2 or walks.numel() == 0:
+                    raise ValueError(f'walks must be [n_walks, walk_length + 1], got {tuple(walks.shape)}')
+                lo, hi = int(walks.min()), int(walks.max())
+                if lo < 0 or hi >= self.N:
+                    raise ValueError(f'walks contain node ids outside [0, {self.N}): min {lo}, max {hi}')
             else:
                 start = torch.randint(0, self.N, (self.batch_size,), generator=self._gen, device=dev)
                 walks = torch.empty(self.batch_size, self.walk_length + 1, dtype=torch.int64, device=dev)
@@ -72,15 +79,18 @@ class GraphSAINTRandomWalkSampler:
                                                self._relabel.data_ptr(), self._node_buf.data_ptr(),
                                                self._cnt2.data_ptr(), self._ws.data_ptr(), self._ws.numel(), st()),
                        'ampconv_saint_nodes')
-            n_sub = int(self._cnt2[0].item())
+            # the number of sampled nodes stays on the device until the edge count is known too: an upper bound
+            # (walked nodes, at most N) sizes the per-node counters, and both sizes come back in ONE read
+            n_bound = min(int(walks.numel()), self.N)
+            cnt = torch.empty(n_bound + 1, dtype=torch.int32, device=dev)
+            off = torch.empty(n_bound + 1, dtype=torch.int32, device=dev)
+            _lib.check(lib.ampconv_saint_count_edges_bounded(self._node_buf.data_ptr(), n_bound, self._cnt2.data_ptr(),
+                                                             csr.cscptr.data_ptr(), csr.crow.data_ptr(),
+                                                             self._mark.data_ptr(), cnt.data_ptr(), off.data_ptr(),
+                                                             self._cnt2[1:].data_ptr(), self._ws.data_ptr(),
+                                                             self._ws.numel(), st()), 'ampconv_saint_count_edges_bounded')
+            n_sub, e_sub = self._cnt2[:2].tolist()
             node_idx = self._node_buf[:n_sub].clone()
-            cnt = torch.empty(n_sub + 1, dtype=torch.int32, device=dev)
-            off = torch.empty(n_sub + 1, dtype=torch.int32, device=dev)
-            _lib.check(lib.ampconv_saint_count_edges(node_idx.data_ptr(), n_sub, csr.cscptr.data_ptr(),
-                                                     csr.crow.data_ptr(), self._mark.data_ptr(), cnt.data_ptr(),
-                                                     off.data_ptr(), self._cnt2[1:].data_ptr(), self._ws.data_ptr(),
-                                                     self._ws.numel(), st()), 'ampconv_saint_count_edges')
-            e_sub = int(self._cnt2[1].item())
             edge_index = torch.empty(2, e_sub, dtype=torch.int64, device=dev)
             edge_id = torch.empty(e_sub, dtype=torch.int64, device=dev)
             _lib.check(lib.ampconv_saint_fill_edges(node_idx.data_ptr(), n_sub, csr.cscptr.data_ptr(),

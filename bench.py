@@ -417,8 +417,9 @@ def measure_saint(workload, steps, warmup, args, rank, world, dev, dist_on, dt_n
         'batch': {'nodes_avg': n_avg, 'edges_avg': e_avg, 'sampler_ms': sampler_ms,
                   'sampler_share_of_step': sampler_ms / (1e3 * t_step),
                   'allreduce_share_of_step': ar_ms / (1e3 * t_step),
-                  'host_readbacks_per_batch': 'sampler: sub-graph node and edge counts (2), CSR build: bounds flag + '
-                                              'long-segment chunk counts (1); all inside the timed step'},
+                  'host_readbacks_per_batch': 'sampler: sub-graph node and edge counts (1 read of both), graph preparation: '
+                                              'bounds flag + long-segment chunk counts (1 read of the status word); '
+                                              'all inside the timed step'},
         'layer_flops': {'per_step': flops, 'achieved_TFLOPs_per_gpu': flops / t_step / 1e12,
                         'peak_TFLOPs': MFMA_PEAK_TFLOPS[dt_name],
                         'frac_of_peak': flops / t_step / 1e12 / MFMA_PEAK_TFLOPS[dt_name]},

@@ -261,7 +261,9 @@ int ampconv_proj_wgrad(const float *A, int64_t lda, const float *B, int64_t ldb,
  *                 (stays if none); counter-based generator keyed by (seed, walk, step)
  *   nodes       : walked nodes (with repeats) -> mark[N], relabel[N], node_idx (sorted unique)
  *   count/fill  : induced sub-graph, edges grouped by source in CSC order: relabelled
- *                 edge_index [2, e_sub] and the original edge ids
+ *                 edge_index [2, e_sub] and the original edge ids (count_edges_bounded: the same before
+ *                 the host knows n_sub -- an upper bound sizes cnt / off, n_sub is read on the device --
+ *                 so that n_sub and e_sub come back in ONE read)
  *   add_counts  : count[idx[i]] += 1 (occurrence statistics of nodes / edges)
  *   norms       : edge_norm = clamp(node_count[src] / edge_count, 0, 1e4) (NaN -> 0.1),
  *                 node_norm = num_samples / max(node_count, 0.1 if 0) / N               */
@@ -274,6 +276,10 @@ int ampconv_saint_nodes(const int64_t *nodes, int64_t n, int64_t N, int32_t *mar
 int ampconv_saint_count_edges(const int64_t *node_idx, int64_t n_sub, const int32_t *cscptr,
                               const int32_t *crow, const int32_t *mark, int32_t *cnt, int32_t *off,
                               int32_t *e_sub, void *workspace, size_t workspace_bytes, void *stream);
+int ampconv_saint_count_edges_bounded(const int64_t *node_idx, int64_t n_bound, const int32_t *n_sub_dev,
+                                      const int32_t *cscptr, const int32_t *crow, const int32_t *mark,
+                                      int32_t *cnt, int32_t *off, int32_t *e_sub, void *workspace,
+                                      size_t workspace_bytes, void *stream);
 int ampconv_saint_fill_edges(const int64_t *node_idx, int64_t n_sub, const int32_t *cscptr,
                              const int32_t *crow, const int32_t *cperm, const int32_t *mark,
                              const int32_t *relabel, const int32_t *off, int64_t E_sub,

@@ -146,3 +146,21 @@ def test_replay_of_reference_sampler_fixture():
         got = sorted(zip(b.edge_index[0].tolist(), b.edge_index[1].tolist(), b.edge_attr.tolist(),
                          np.round(b.edge_norm.cpu().numpy(), 5).tolist()))
         assert got == want
+
+
+def test_replayed_walks_are_range_checked():
+    """sample(walks=...) feeds the ids into mark[node] = 1 on the device; ids outside [0, N) must be a
+    Python error, not a device write out of bounds."""
+    import types
+    from ampnet_amd import GraphSAINTRandomWalkSampler
+    dev = torch.device('cuda:0')
+    N = 50
+    ei = torch.randint(0, N, (2, 400), device=dev)
+    s = GraphSAINTRandomWalkSampler(types.SimpleNamespace(edge_index=ei, num_nodes=N), batch_size=4, walk_length=5,
+                                    num_nodes=N)
+    good = torch.randint(0, N, (4, 6), device=dev)
+    node_idx, sub_ei, edge_id, _ = s.sample(walks=good)
+    assert node_idx.numel() == good.unique().numel() and int(sub_ei.max()) < node_idx.numel()
+    for bad in (good.clone().index_fill_(0, torch.tensor([0], device=dev), N), good - N, good.flatten()):
+        with pytest.raises(ValueError):
+            s.sample(walks=bad)
