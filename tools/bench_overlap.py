@@ -47,9 +47,18 @@ def main():
                                             csr.cinv.data_ptr(), N, L, D, H, dKv, dVv, None, 0, None, stats.data_ptr(), 0,
                                             st), 'src')
 
+    native = '--native' in sys.argv                  # libampconv's own projection kernels (bf16 matrix cores)
+    img = F_.proj_image(w) if native else None
+    dwo, cso = torch.empty(D, D, device=dev), torch.empty(D, device=dev)
+
     def gemms(k):
-        for _ in range(k):
-            torch.mm(x, w, out=out1)                 # [N L, D] x [D, D]: 2 N L D^2 flop each
+        for i in range(k):
+            if not native:
+                torch.mm(x, w, out=out1)             # [N L, D] x [D, D]: 2 N L D^2 flop each
+            elif i % 2 == 0:
+                F_.proj_rows(x, img)
+            else:
+                F_.proj_wgrad(x, dobar, dwo, cso)    # the weight-gradient kernel: the same flop count
 
     def timed(fn, iters=5):
         fn()

@@ -1,28 +1,52 @@
 """Dev: max error of the GPU layer against the fp64 numpy oracle, relative to the largest entry of each
-tensor (2 000 nodes / 24 000 edges, L=20, D=256, H=8), for both GEMM modes."""
-import sys, numpy as np, torch
-sys.path.insert(0, '.')
-from ampnet_amd import AMPConv
-from oracle.ampconv_numpy import AMPConvOracle
-dev = torch.device('cuda:0')
-N, E, L, D, H = 2000, 24000, 20, 256, 8
-g = torch.Generator().manual_seed(5)
-x = torch.randn(N, L * D, generator=g); dy = torch.randn(N, L * D, generator=g)
-ei = torch.randint(0, N, (2, E), generator=g)
-torch.manual_seed(1)
-layer = AMPConv(D, H).to(dev)
-with torch.no_grad():
-    layer.multi_head_attention.in_proj_bias.normal_(0, 0.1); layer.multi_head_attention.out_proj.bias.normal_(0, 0.1)
-m = layer.multi_head_attention
-o = AMPConvOracle(*(t.detach().cpu().numpy() for t in (m.in_proj_weight, m.in_proj_bias, m.out_proj.weight, m.out_proj.bias)), H)
-y_ref, _ = o.forward(x.numpy(), ei.numpy(), need_weights=False)
-ref = o.backward(dy.numpy())
-for gemm in ('fp32', 'bf16x3'):
-    layer.gemm_precision = gemm
-    layer.zero_grad(set_to_none=True)
-    xg = x.to(dev).requires_grad_(True)
-    y = layer(xg, ei.to(dev)); y.backward(dy.to(dev))
-    def rel(a, b): return float(np.abs(a - b).max() / np.abs(b).max())
-    print(gemm, 'y %.2e dx %.2e dWin %.2e dbin %.2e dWo %.2e' % (
-        rel(y.detach().cpu().numpy(), y_ref), rel(xg.grad.cpu().numpy(), ref[0]), rel(m.in_proj_weight.grad.cpu().numpy(), ref[1]),
-        rel(m.in_proj_bias.grad.cpu().numpy(), ref[2]), rel(m.out_proj.weight.grad.cpu().numpy(), ref[3])))
+tensor (2 000 nodes / 24 000 edges, L=20, D=256, H=8), for every projection mode side by side.
+
+    python tools/measure_error.py [--gemm native|fp32|bf16x3]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ampnet_amd import AMPConv  # noqa: E402
+from oracle.ampconv_numpy import AMPConvOracle  # noqa: E402
+
+
+def main():
+    dev = torch.device('cuda:0')
+    N, E, L, D, H = 2000, 24000, 20, 256, 8
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(N, L * D, generator=g)
+    dy = torch.randn(N, L * D, generator=g)
+    ei = torch.randint(0, N, (2, E), generator=g)
+    torch.manual_seed(1)
+    layer = AMPConv(D, H).to(dev)
+    with torch.no_grad():
+        layer.multi_head_attention.in_proj_bias.normal_(0, 0.1)
+        layer.multi_head_attention.out_proj.bias.normal_(0, 0.1)
+    m = layer.multi_head_attention
+    o = AMPConvOracle(*(t.detach().cpu().double().numpy() for t in (m.in_proj_weight, m.in_proj_bias, m.out_proj.weight,
+                                                                     m.out_proj.bias)), H)
+    y_ref, _ = o.forward(x.double().numpy(), ei.numpy(), need_weights=False)
+    ref = (y_ref,) + tuple(o.backward(dy.double().numpy()))
+    names = ('y', 'dx', 'd in_proj_weight', 'd in_proj_bias', 'd out_proj.weight', 'd out_proj.bias')
+    modes = [sys.argv[sys.argv.index('--gemm') + 1]] if '--gemm' in sys.argv else ['native', 'fp32', 'bf16x3']
+    res = {}
+    for mode in modes:
+        layer.gemm_precision = mode
+        layer.zero_grad(set_to_none=True)
+        xg = x.to(dev).requires_grad_(True)
+        y = layer(xg, ei.to(dev))
+        y.backward(dy.to(dev))
+        got = (y.detach(), xg.grad, m.in_proj_weight.grad, m.in_proj_bias.grad, m.out_proj.weight.grad, m.out_proj.bias.grad)
+        res[mode] = [float(np.abs(a.double().cpu().numpy() - b).max() / np.abs(b).max()) for a, b in zip(got, ref)]
+    print(f'N={N} E={E} L={L} D={D} H={H}; max |error| / max |reference entry| against the fp64 oracle')
+    print('| quantity | ' + ' | '.join(modes) + ' |')
+    print('|---|' + '---|' * len(modes))
+    for i, name in enumerate(names):
+        print(f'| {name} | ' + ' | '.join(f'{res[mode][i]:.1e}' for mode in modes) + ' |')
+
+
+if __name__ == '__main__':
+    main()

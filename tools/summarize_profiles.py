@@ -29,7 +29,10 @@ def bench_line(path):
 
 
 def short(name, n=118):
-    name = re.sub(r'Cijk_\w+', lambda m: 'rocBLAS/Tensile fp32 GEMM ' + m.group(0)[:14], name)
+    # Tensile kernel names carry their types: ..._SB_... = fp32 in / fp32 out, ..._BBS_BH_... = bf16 in, fp32 accumulate
+    name = re.sub(r'Cijk_\w+', lambda m: ('rocBLAS/Tensile bf16 GEMM ' if 'BBS' in m.group(0) or '_BB' in m.group(0)
+                                          else 'rocBLAS/Tensile fp32 GEMM ') + m.group(0)[:14], name)
+    name = name.replace('(anonymous namespace)::', '')
     return name if len(name) <= n else name[:n]
 
 
@@ -54,12 +57,15 @@ def main():
     with open(os.path.join(out, f'{tag}_cfg4_kernel_stats.md'), 'w') as f:
         f.write(f'# rocprofv3 --kernel-trace --stats ({tag}, final code of the round)\n\n')
         f.write(f'Command (on the MI355X box, tools/run_profiles.sh): `rocprofv3 --kernel-trace --stats --output-format csv -d {d} '
-                '-o stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt-gemm`\n\n')
+                '-o stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt-gemm --no-extra`\n\n')
         f.write(f"Workload {cfg['workload'].split(':')[0]} (N={cfg['N']}, E={cfg['E']}, L={cfg['L']}, D={cfg['D']}, "
                 f"H={cfg['H']}, fp32), 3 steps recorded (1 warm-up + 2 timed).\n")
         f.write(f"Bench line printed by this profiled run: {b['value'] / 1e6:.2f} M edges/s, {b['ms_per_step']:.1f} "
                 f"ms/step; HIP-event averages inside bench.py: fwd {ms['ampconv_fwd_edge']:.1f} / bwd_dst "
                 f"{ms['ampconv_bwd_edge_dst']:.1f} / bwd_src {ms['ampconv_bwd_edge_src']:.1f} ms.\n\n")
+        f.write('`proj_rows_kernel` / `proj_wgrad_kernel` = the node-phase projections (csrc/proj_gemm.hip: four row products and '
+                'two weight-gradient products per step); `__amd_rocclr_copyBuffer` and `distribution_elementwise...` are the '
+                "bench's own data fill (make_batch: 1 GiB slabs of randn copied into x and dy), outside the timed steps.\n\n")
         f.write('| kernel | calls | avg ms | total ms | % |\n|---|---|---|---|---|\n')
         for r in rows[:22]:
             f.write(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['AverageNs']) / 1e6:.3f} | "
@@ -119,18 +125,17 @@ def main():
     sq = os.path.join(d, 'sq_summary.txt')
     if os.path.exists(sq):
         with open(os.path.join(out, f'{tag}_sq_counters.md'), 'w') as f:
-            f.write(f'# SQ counters of the edge kernels ({tag}; tools/prof_sq.sh + tools/summarize_sq2.py)\n\n')
+            f.write(f'# SQ counters of the edge and projection kernels ({tag}; tools/prof_sq.sh, tools/prof_sq_proj.sh + tools/summarize_sq2.py)\n\n')
             f.write('Two `rocprofv3 --pmc ... --kernel-trace` passes over `tools/bench_kernels.py` (100 k nodes / 1 M edges, L=20, '
                     'D=256, H=8, fp32): `SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU '
                     'SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE` and `SQ_WAVE_CYCLES '
                     'SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_VALU_MFMA_COEXEC_CYCLES '
                     'SQ_ACTIVE_INST_VMEM GRBM_GUI_ACTIVE`.  Fractions are of SQ_WAVE_CYCLES; mfma_busy = '
                     'SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (duration x clock), clock = GRBM_GUI_ACTIVE / 8 / duration.  '
-                    f'`{tag}_final` = the kernels as shipped (fixed-side tail tokens on v_mfma_f32_4x4x1), `{tag}_nt4off` = the '
-                    'same build with AMPCONV_FWD_NT4=0 AMPCONV_DST_NT4=0 AMPCONV_SRC_NT4=0 (all products on 16x16x4, the '
-                    'round-1 tiling; its source pass is compiled under the same 168-register bound as the shipped one and spills 11 '
-                    'registers there -- round 1 measured 12.9-13.1 ms for it without spills, `profiles/r01_sq_counters.md`).  '
-                    'Profiled runs are a few % slower than un-profiled ones.\n\n```\n')
+                    f'`{tag}_final` = the edge kernels as shipped; `{tag}_proj` = the projection kernels over `tools/bench_proj.py '
+                    '8000000 256` (8 M rows, D = 256: `proj_rows` averages the qkv / out / dx launches, `proj_wgrad` the dWin / dWo '
+                    'launches; their clock column is the DVFS evidence of DESIGN.md 4: bf16 MFMA at ~0.6 pipe occupancy holds '
+                    '~1.7-1.9 GHz on random data).  Profiled runs are a few % slower than un-profiled ones.\n\n```\n')
             f.write(open(sq).read())
             f.write('```\n')
 
