@@ -69,8 +69,10 @@ class AMPConv(MessagePassing):
         self.retain_attention = 'auto'
         self._attn_dropped_bytes = 0
         self._attn_param_versions = None
-        # how fp32 products run on the matrix cores: 'default' | 'exact' | 'bf16x9' | 'bf16x6'
-        # (include/ampconv.h, dtype codes); inputs, outputs and accumulation are fp32 in every mode
+        # how the per-EDGE fp32 products run on the matrix cores: 'default' | 'exact' | 'bf16x9' | 'bf16x6'
+        # (include/ampconv.h, dtype codes); inputs, outputs and accumulation are fp32 in every mode.  On a graph with
+        # long segments (a hub plan) the split modes run the 'exact' kernels for the whole graph: they have no
+        # long-segment pass of their own (include/ampconv.h, FALLBACK)
         self.precision = 'default'
         # how the per-node projections run: 'native' (default: libampconv's own kernels, csrc/proj_gemm.hip -- fp32
         # operands split exactly into three bf16 terms, six partial products on the bf16 matrix cores, fp32

@@ -52,7 +52,12 @@ enum {
  *   AMPCONV_F32         library default = AMPCONV_F32_EXACT; AMPCONV_F32_MODE=bf16x9|bf16x6 in the
  *                       environment selects a split mode where the shape supports it (dh = 32).
  * On MI355X the split modes measure within 4 % of the native mode (the kernels are bound by
- * per-wave latency, not by MFMA issue), so the native fp32 MFMA is the default. */
+ * per-wave latency, not by MFMA issue), so the native fp32 MFMA is the default.
+ * FALLBACK: the split-operand edge kernels have no long-segment pass.  A call that carries a hub plan
+ * (hub_plan != NULL and hub_chunks > 0: the graph has a CSR / CSC segment longer than the chunk) runs
+ * the AMPCONV_F32_EXACT kernels for the WHOLE graph in every AMPCONV_F32* mode -- the result is fp32-grade
+ * either way; which arithmetic ran then depends on the degree distribution.  (This concerns the per-edge
+ * products only; the per-node projections have their own mode, ampconv_proj_* below.) */
 enum { AMPCONV_F32 = 0, AMPCONV_BF16 = 1, AMPCONV_F32_EXACT = 2, AMPCONV_F32_BF16X9 = 3,
        AMPCONV_F32_BF16X6 = 4 };
 
