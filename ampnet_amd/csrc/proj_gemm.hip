@@ -618,7 +618,11 @@ struct WgradPlan {
 inline WgradPlan wgrad_plan(int64_t M, int Na, int Nb) {
   WgradPlan p;
   p.tj = Nb % 256 == 0 ? 256 : 128;
-  p.ti = (Na % 256 == 0 && p.tj == 256) ? 256 : 128;       // 256 x 256: eight waves, one workgroup per CU
+  static const bool small_ti = [] {                        // developer switch: 128 x 256 tiles of four waves, two per CU
+    const char *e = getenv("AMPCONV_PROJ_WGRAD_TI");
+    return e && atoi(e) == 128;
+  }();
+  p.ti = (Na % 256 == 0 && p.tj == 256 && !small_ti) ? 256 : 128;       // 256 x 256: eight waves, one workgroup per CU
   const int64_t ntiles = (int64_t)(Na / p.ti) * (Nb / p.tj);
   const int64_t nstages = (M + kRS - 1) / kRS;
   // one round of workgroups: slices are dealt to the 8 XCDs in turn (round-robin dispatch) and every slice brings
