@@ -61,7 +61,7 @@ def gemm_precision(mode):
     if mode not in GEMM_PRECISIONS:
         raise ValueError(f'gemm precision must be one of {GEMM_PRECISIONS}, got {mode!r}')
     if mode in ('fp32', 'native'):      # 'native': libampconv's own projection kernels (proj_* below); what they
-        yield                           # do not serve (bf16 storage, D % 128 != 0) runs as plain library GEMMs
+        yield                           # do not serve (bf16 storage, D % 4 != 0) runs as plain library GEMMs
         return
     with _GEMM_SWITCH_LOCK:
         prev_env = os.environ.get('HIPBLASLT_ALLOW_TF32')
@@ -100,7 +100,7 @@ def _tn_matmul(a, b, chunks=128):
 # ---- the per-node projections in libampconv.so (csrc/proj_gemm.hip): fp32 operands split exactly into
 # three bf16 terms, six partial products on v_mfma_f32_32x32x16_bf16, fp32 accumulate
 def proj_native(gemm, dtype, D):
-    """Does the 'native' mode serve this layer?  fp32 storage, embed_dim a multiple of 128."""
+    """Does the 'native' mode serve this layer?  fp32 storage, embed_dim a multiple of 4 (float4 rows)."""
     return gemm == 'native' and dtype == torch.float32 and bool(_lib.load().ampconv_proj_supported(D, D))
 
 

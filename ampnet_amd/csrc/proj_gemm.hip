@@ -119,13 +119,16 @@ struct ImageJobs {
 };
 __global__ void weight_image_kernel(ImageJobs jobs) {
   const ImageJob jb = jobs.j[blockIdx.y];
-  const int k8s = jb.K / 8;
+  // the image covers the PADDED shape (columns to a multiple of 128, depth to a multiple of 32): zeros beyond N and K
+  const int Np = (jb.N + 127) / 128 * 128, Kp = (jb.K + 31) / 32 * 32;
+  const int k8s = Kp / 8;
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= jb.N * k8s) return;
+  if (idx >= Np * k8s) return;
   const int n = idx / k8s, k8 = idx - n * k8s;
   float x[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) x[j] = jb.W[(int64_t)n * jb.sn + (int64_t)(8 * k8 + j) * jb.sk];
+  for (int j = 0; j < 8; ++j)
+    x[j] = (n < jb.N && 8 * k8 + j < jb.K) ? jb.W[(int64_t)n * jb.sn + (int64_t)(8 * k8 + j) * jb.sk] : 0.f;
   i32x4 pl[3];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
@@ -133,7 +136,7 @@ __global__ void weight_image_kernel(ImageJobs jobs) {
     pl[0][t] = q.h1; pl[1][t] = q.h2; pl[2][t] = q.h3;
   }
   const int ks = k8 >> 1, h = k8 & 1, n32 = n >> 5, r = n & 31;
-  char *dst = jb.img + ((size_t)(ks * (jb.N / 32) + n32) * 3) * kFrag + (32 * h + r) * 16;
+  char *dst = jb.img + ((size_t)(ks * (Np / 32) + n32) * 3) * kFrag + (32 * h + r) * 16;
 #pragma unroll
   for (int p = 0; p < 3; ++p) *reinterpret_cast<i32x4 *>(dst + p * kFrag) = pl[p];
 }
@@ -164,12 +167,15 @@ struct RowsArgs {
   int64_t ldc;
   int row_tiles;              // ceil(M / BM)
   int64_t tiles;              // tile slots: row tiles rounded up to 8, times column tiles
+  int Kp, Np;                 // K, N padded to multiples of 32 / 128 (= the weight image's shape)
 };
 
 constexpr int kXcd = 8;
 
-template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 2 : 2) void proj_rows_kernel(RowsArgs a) {
+// RAGGED: K % 32 != 0 or N % BN != 0 (e.g. the reference's default embed_dim = 100): row loads beyond K read as zero,
+// columns beyond N are computed on the image's zero padding and not stored
+template <int BM, int BN, int WM, int WN, bool RAGGED>
+__global__ __launch_bounds__(64 * WM * WN, 2) void proj_rows_kernel(RowsArgs a) {
   constexpr int NW = WM * WN, NTHR = 64 * NW;
   constexpr int MTB = BM / 32, NTB = BN / 32;          // 32-row / 32-column tiles per workgroup
   constexpr int MTW = MTB / WM, NTW = NTB / WN;        // ... per wave
@@ -187,8 +193,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 2 : 2) void proj_row
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = w / WN, wn = w % WN;
-  const int nct = a.N / BN;
-  const int KS = a.K / 16;
+  const int nct = (a.Np + BN - 1) / BN;
 
   // rows of this thread: float4 column c of a 16-deep half line, rows r0 + kRowsPerLoad * i
   const int c = t & 3, r0 = t >> 2;
@@ -201,7 +206,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 2 : 2) void proj_row
   const int fr = lane & 31, fh = lane >> 5;
   const int ard = kStepB + (MTW * wm) * kTile3 + ((32 * fh + (fr ^ (4 * fh))) << 4);
   const int brd = (NTW * wn) * kTile3 + lane * 16;
-  const size_t wstep = (size_t)(a.N / 32) * kTile3;            // bytes of one k step of the whole image
+  const size_t wstep = (size_t)(a.Np / 32) * kTile3;           // bytes of one k step of the whole image
   const unsigned lds0 = (unsigned)(uintptr_t)(lds_char *)smem;
 
   // tile slot u -> (row tile, column tile).  Workgroups b, b + 8, ... share an XCD (round-robin dispatch, speed
@@ -231,7 +236,9 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 2 : 2) void proj_row
   };
   // rows of the thread in the NEXT line block to request (advanced 32 floats per block, re-based at a tile seam)
   const float *rp[NLH];
+  int kpos = 4 * c;                     // RAGGED: column of the thread's first float4 in the block to request
   auto rebase = [&](const Tile &tl) {
+    kpos = 4 * c;
 #pragma unroll
     for (int i = 0; i < NLH; ++i) {
       int64_t m = tl.row0 + kRowsPerLoad * i + r0;
@@ -243,10 +250,17 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 2 : 2) void proj_row
   auto load_rows = [&]() {
 #pragma unroll
     for (int i = 0; i < NLH; ++i) {
-      x[0][i] = *reinterpret_cast<const float4 *>(rp[i]);
-      x[1][i] = *reinterpret_cast<const float4 *>(rp[i] + 16);
+      if (!RAGGED) {
+        x[0][i] = *reinterpret_cast<const float4 *>(rp[i]);
+        x[1][i] = *reinterpret_cast<const float4 *>(rp[i] + 16);
+      } else {
+        x[0][i] = x[1][i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (kpos < a.K) x[0][i] = *reinterpret_cast<const float4 *>(rp[i]);
+        if (kpos + 16 < a.K) x[1][i] = *reinterpret_cast<const float4 *>(rp[i] + 16);
+      }
       rp[i] += 32;
     }
+    kpos += 32;
   };
   auto split_rows = [&](auto half, int buf) {       // `half` is a compile-time constant: x stays in registers
     char *base = smem + buf * kBuf + wdst;
@@ -284,7 +298,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 2 : 2) void proj_row
   if (!cur.valid) return;        // slots are ordered: nothing further for this workgroup either
   Tile nxt = tile_of(u + gridDim.x);
   int par = 0;                   // parity of the tile (row flags)
-  const int KB = a.K / 32;       // line blocks per tile; a tile is 2 KB steps, so step parity = buffer, statically
+  const int KB = a.Kp / 32;      // line blocks per tile; a tile is 2 KB steps, so step parity = buffer, statically
   rebase(cur);
   dma_step(cur, 0, 0);
   load_rows();
@@ -359,7 +373,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 2 : 2) void proj_row
 #pragma unroll
           for (int j = 0; j < NTW; ++j) {
             const int colt = cur.col0 + (NTW * wn + j) * 32;
-            const float bj = a.bias ? a.bias[colt + fr] : 0.f;
+            const float bj = (a.bias && (!RAGGED || colt + fr < a.N)) ? a.bias[colt + fr] : 0.f;
 #pragma unroll
             for (int e = 0; e < 16; ++e)
               stage[((e & 3) + 8 * (e >> 2) + 4 * fh) * 32 + fr] = (acc[i][j][e] + bj) * fl[e];
@@ -367,7 +381,7 @@ __global__ __launch_bounds__(64 * WM * WN, (WM * WN == 8) ? 2 : 2) void proj_row
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
               const float4 v = *reinterpret_cast<const float4 *>(stage + (sr + 8 * g) * 32 + 4 * sc4);
-              if (!decltype(ragged)::value || cur.row0 + rl0 + sr + 8 * g < a.M)
+              if ((!decltype(ragged)::value || cur.row0 + rl0 + sr + 8 * g < a.M) && (!RAGGED || colt + 4 * sc4 < a.N))
                 *reinterpret_cast<float4 *>(o + (int64_t)(8 * g) * a.ldc) = v;
             }
           }
@@ -406,9 +420,10 @@ struct WgradArgs {
   int Na, Nb;
   const int32_t *rowptr;
   int L;
-  float *part;                // [S][Na * Nb + Na]
+  float *part;                // [S][Nap * Nbp + Nap]
   int S;
   int64_t rows_per_slice;     // multiple of 16
+  int Nap, Nbp;               // Na, Nb padded to multiples of 128: the shape the tiles and the partial slabs cover
 };
 
 constexpr int kRS = 16;       // rows per stage
@@ -420,7 +435,8 @@ __device__ __forceinline__ i32x4 tr_frag(const char *p0, const char *p1) {
   return i32x4{ai[0], ai[1], bi[0], bi[1]};
 }
 
-template <int TI, int TJ, int WI, int WJ, bool MASK>
+// RAGGED: Na or Nb not a multiple of the tile (the reference's default embed_dim = 100): columns beyond them load as 0
+template <int TI, int TJ, int WI, int WJ, bool MASK, bool RAGGED>
 __global__ __launch_bounds__(64 * WI * WJ, 2) void proj_wgrad_kernel(WgradArgs a) {
   constexpr int NW = WI * WJ, NTHR = 64 * NW;
   constexpr int kRowA = TI * 2, kRowB = TJ * 2;             // bytes per image row
@@ -436,7 +452,7 @@ __global__ __launch_bounds__(64 * WI * WJ, 2) void proj_wgrad_kernel(WgradArgs a
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wi = w / WJ, wj = w % WJ;
-  const int ntj = a.Nb / TJ, ntiles = (a.Na / TI) * ntj;
+  const int ntj = a.Nbp / TJ, ntiles = (a.Nap / TI) * ntj;
   const int b = blockIdx.x, xcd = b % kXcd, i_x = b / kXcd;
   const int slice = (i_x / ntiles) * kXcd + xcd, tile = i_x % ntiles;
   if (slice >= a.S) return;
@@ -484,7 +500,8 @@ __global__ __launch_bounds__(64 * WI * WJ, 2) void proj_wgrad_kernel(WgradArgs a
     for (int i = 0; i < NLA; ++i) {
       const int64_t m = mb + ra + kRowsA * i;
       const int64_t mc = m < m1 ? m : m1 - 1;
-      xa[i] = *reinterpret_cast<const float4 *>(pa + mc * a.lda);
+      if (!RAGGED || ti * TI + 4 * ca < a.Na) xa[i] = *reinterpret_cast<const float4 *>(pa + mc * a.lda);
+      else xa[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       float f = m < m1 ? 1.f : 0.f;
       if (MASK) {
         const int64_t node = mc / a.L;
@@ -496,7 +513,8 @@ __global__ __launch_bounds__(64 * WI * WJ, 2) void proj_wgrad_kernel(WgradArgs a
     for (int i = 0; i < NLB; ++i) {
       const int64_t m = mb + rb + kRowsB * i;
       const int64_t mc = m < m1 ? m : m1 - 1;
-      xb[i] = *reinterpret_cast<const float4 *>(pb + mc * a.ldb);
+      if (!RAGGED || tj * TJ + 4 * cb < a.Nb) xb[i] = *reinterpret_cast<const float4 *>(pb + mc * a.ldb);
+      else xb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   load_stage(0);
@@ -543,14 +561,14 @@ __global__ __launch_bounds__(64 * WI * WJ, 2) void proj_wgrad_kernel(WgradArgs a
   }
 
   // partial tile of this slice
-  float *part = a.part + (size_t)slice * ((size_t)a.Na * a.Nb + a.Na);
+  float *part = a.part + (size_t)slice * ((size_t)a.Nap * a.Nbp + a.Nap);
 #pragma unroll
   for (int i = 0; i < NIW; ++i)
 #pragma unroll
     for (int j = 0; j < NJW; ++j) {
-      float *o = part + (size_t)(ti * TI + (NIW * wi + i) * 32 + 4 * fh) * a.Nb + tj * TJ + (NJW * wj + j) * 32 + fr;
+      float *o = part + (size_t)(ti * TI + (NIW * wi + i) * 32 + 4 * fh) * a.Nbp + tj * TJ + (NJW * wj + j) * 32 + fr;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) o[(size_t)((e & 3) + 8 * (e >> 2)) * a.Nb] = acc[i][j][e];
+      for (int e = 0; e < 16; ++e) o[(size_t)((e & 3) + 8 * (e >> 2)) * a.Nbp] = acc[i][j][e];
     }
   if (tj == 0) {
     // column sums of the A tile: kRowsA row-threads per float4 column, added through LDS in a fixed order
@@ -565,7 +583,7 @@ __global__ __launch_bounds__(64 * WI * WJ, 2) void proj_wgrad_kernel(WgradArgs a
         const float4 v = red[r * kColsA4 + t];
         sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
       }
-      *reinterpret_cast<float4 *>(part + (size_t)a.Na * a.Nb + ti * TI + 4 * t) = sum;
+      *reinterpret_cast<float4 *>(part + (size_t)a.Nap * a.Nbp + ti * TI + 4 * t) = sum;
     }
   }
 }
@@ -573,11 +591,11 @@ __global__ __launch_bounds__(64 * WI * WJ, 2) void proj_wgrad_kernel(WgradArgs a
 // out[e] = sum over the slices of part[s][e]; e < n_dw goes to dW, the rest to colsum.  256 threads = 32 float4
 // elements x 8 slice phases: phase g adds slices g, g + 8, ... in order (four loads in flight), the eight phase sums
 // meet in LDS and are added in a fixed order -- bitwise reproducible, and S / 8 dependent load rounds instead of S
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ part, int S, int64_t n_dw,
-                                                           int64_t n_all, float *__restrict__ dW,
-                                                           float *__restrict__ colsum) {
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ part, int S, int Na, int Nb, int Nap,
+                                                           int Nbp, float *__restrict__ dW, float *__restrict__ colsum) {
   __shared__ float4 red[8][32];
   const int el = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int64_t n_dw = (int64_t)Nap * Nbp, n_all = n_dw + Nap;        // the slabs cover the padded shape
   const int64_t e = ((int64_t)blockIdx.x * 32 + el) * 4;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
   if (e < n_all) {
@@ -603,10 +621,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
       const float4 v = red[k][el];
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
-    if (e < n_dw)
-      *reinterpret_cast<float4 *>(dW + e) = acc;
-    else if (colsum)
+    if (e < n_dw) {
+      const int i = (int)(e / Nbp), j = (int)(e - (int64_t)i * Nbp);
+      if (i < Na && j < Nb) *reinterpret_cast<float4 *>(dW + (size_t)i * Nb + j) = acc;
+    } else if (colsum && e - n_dw < Na) {
       *reinterpret_cast<float4 *>(colsum + (e - n_dw)) = acc;
+    }
   }
 }
 
@@ -615,15 +635,15 @@ struct WgradPlan {
   int64_t rows_per_slice;
   int ti, tj;
 };
-inline WgradPlan wgrad_plan(int64_t M, int Na, int Nb) {
+inline WgradPlan wgrad_plan(int64_t M, int Nap, int Nbp) {       // padded shape (multiples of 128)
   WgradPlan p;
-  p.tj = Nb % 256 == 0 ? 256 : 128;
   static const bool small_ti = [] {                        // developer switch: 128 x 256 tiles of four waves, two per CU
     const char *e = getenv("AMPCONV_PROJ_WGRAD_TI");
     return e && atoi(e) == 128;
   }();
-  p.ti = (Na % 256 == 0 && p.tj == 256 && !small_ti) ? 256 : 128;       // 256 x 256: eight waves, one workgroup per CU
-  const int64_t ntiles = (int64_t)(Na / p.ti) * (Nb / p.tj);
+  p.tj = Nbp % 256 == 0 ? 256 : 128;
+  p.ti = (Nap % 256 == 0 && p.tj == 256 && !small_ti) ? 256 : 128;       // 256 x 256: eight waves, one workgroup per CU
+  const int64_t ntiles = (int64_t)(Nap / p.ti) * (Nbp / p.tj);
   const int64_t nstages = (M + kRS - 1) / kRS;
   // one round of workgroups: slices are dealt to the 8 XCDs in turn (round-robin dispatch) and every slice brings
   // `ntiles` workgroups, so an XCD's 32 CUs (x 2 for the 4-wave shapes) hold floor(32 / ntiles) slices each --
@@ -642,11 +662,13 @@ inline WgradPlan wgrad_plan(int64_t M, int Na, int Nb) {
 
 extern "C" size_t ampconv_proj_weight_image_bytes(int N, int K) {
   if (N <= 0 || K <= 0) return 0;
-  return (size_t)N * (size_t)K * 6;
+  return (size_t)((N + 127) / 128 * 128) * (size_t)((K + 31) / 32 * 32) * 6;      // padded shape, three bf16 planes
 }
 
+// rows and row strides are read as float4: every dimension a multiple of 4 (16-byte aligned rows); the tiles are
+// padded internally (N to 128, K to 32), so embed_dim = 100 -- the reference's AMPGCN default -- is served too
 extern "C" int ampconv_proj_supported(int N, int K) {
-  return N > 0 && K > 0 && N % 128 == 0 && K % 32 == 0;
+  return N > 0 && K > 0 && N % 4 == 0 && K % 4 == 0;
 }
 
 extern "C" int ampconv_proj_weight_images(int count, const ampconv_weight_image_t *jobs, void *stream) {
@@ -658,7 +680,7 @@ extern "C" int ampconv_proj_weight_images(int count, const ampconv_weight_image_
     const ampconv_weight_image_t &w = jobs[i];
     if (!ampconv_proj_supported(w.N, w.K) || !w.W || !w.image || (uintptr_t)w.image % 16) return AMPCONV_E_BADARG;
     js.j[i] = ImageJob{w.W, w.stride_n, w.stride_k, w.N, w.K, (char *)w.image};
-    const int total = w.N * (w.K / 8);
+    const int total = ((w.N + 127) / 128 * 128) * (((w.K + 31) / 32 * 32) / 8);
     most = total > most ? total : most;
   }
   weight_image_kernel<<<dim3((most + 255) / 256, count), 256, 0, (hipStream_t)stream>>>(js);
@@ -684,12 +706,14 @@ extern "C" int ampconv_proj_rows(const float *A, int64_t lda, int64_t M, int K, 
     const char *e = getenv("AMPCONV_PROJ_ROWS");
     return e ? atoi(e) : 0;
   }();
-  const int shape = N % 256 ? 2 : variant;             // 0: 128 x 256 / 4 waves, 1: 256 x 256 / 8 waves, 2: 128 x 128 / 4 waves
+  const int Np = (N + 127) / 128 * 128, Kp = (K + 31) / 32 * 32;
+  const bool ragged = Np != N || Kp != K;
+  const int shape = Np % 256 ? 2 : variant;            // 0: 128 x 256 / 4 waves, 1: 256 x 256 / 8 waves, 2: 128 x 128 / 4 waves
   const int bm = shape == 1 ? 256 : 128, bn = shape == 2 ? 128 : 256;
   const int64_t rts = (M + bm - 1) / bm;
   if (rts > (int64_t)INT32_MAX / 64) return AMPCONV_E_BADARG;
   const int64_t rtp = (rts + 7) / 8 * 8;
-  RowsArgs a{A, lda, M, K, N, (const char *)wimage, bias, rowptr, L, out, ldc, (int)rts, rtp * (N / bn)};
+  RowsArgs a{A, lda, M, K, N, (const char *)wimage, bias, rowptr, L, out, ldc, (int)rts, rtp * (Np / bn), Kp, Np};
   static const int n_cu = [] {
     int dev = 0, n = 256;
     if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
@@ -698,22 +722,27 @@ extern "C" int ampconv_proj_rows(const float *A, int64_t lda, int64_t M, int K, 
   int64_t grid = (int64_t)n_cu * (shape == 1 ? 1 : 2);
   if (grid > a.tiles) grid = a.tiles;
   hipStream_t st = (hipStream_t)stream;
-  if (shape == 0) proj_rows_kernel<128, 256, 2, 2><<<(unsigned)grid, 256, 0, st>>>(a);
-  else if (shape == 1) proj_rows_kernel<256, 256, 2, 4><<<(unsigned)grid, 512, 0, st>>>(a);
-  else proj_rows_kernel<128, 128, 2, 2><<<(unsigned)grid, 256, 0, st>>>(a);
+  const unsigned g = (unsigned)grid;
+  if (shape == 0 && !ragged) proj_rows_kernel<128, 256, 2, 2, false><<<g, 256, 0, st>>>(a);
+  else if (shape == 0) proj_rows_kernel<128, 256, 2, 2, true><<<g, 256, 0, st>>>(a);
+  else if (shape == 1 && !ragged) proj_rows_kernel<256, 256, 2, 4, false><<<g, 512, 0, st>>>(a);
+  else if (shape == 1) proj_rows_kernel<256, 256, 2, 4, true><<<g, 512, 0, st>>>(a);
+  else if (!ragged) proj_rows_kernel<128, 128, 2, 2, false><<<g, 256, 0, st>>>(a);
+  else proj_rows_kernel<128, 128, 2, 2, true><<<g, 256, 0, st>>>(a);
   return ampconv_launch_status();
 }
 
 extern "C" size_t ampconv_proj_wgrad_workspace_bytes(int64_t M, int Na, int Nb) {
-  if (M < 0 || Na <= 0 || Nb <= 0 || Na % 128 || Nb % 128) return 0;
-  const WgradPlan p = wgrad_plan(M, Na, Nb);
-  return (size_t)p.S * ((size_t)Na * Nb + Na) * sizeof(float);
+  if (M < 0 || Na <= 0 || Nb <= 0 || Na % 4 || Nb % 4) return 0;
+  const int Nap = (Na + 127) / 128 * 128, Nbp = (Nb + 127) / 128 * 128;
+  const WgradPlan p = wgrad_plan(M, Nap, Nbp);
+  return (size_t)p.S * ((size_t)Nap * Nbp + Nap) * sizeof(float);
 }
 
 extern "C" int ampconv_proj_wgrad(const float *A, int64_t lda, const float *B, int64_t ldb, int64_t M, int Na,
                                   int Nb, const int32_t *rowptr, int L, float *dW, float *colsum,
                                   void *workspace, size_t workspace_bytes, void *stream) {
-  if (M < 0 || Na <= 0 || Nb <= 0 || Na % 128 || Nb % 128 || lda < Na || ldb < Nb || lda % 4 || ldb % 4)
+  if (M < 0 || Na <= 0 || Nb <= 0 || Na % 4 || Nb % 4 || lda < Na || ldb < Nb || lda % 4 || ldb % 4)
     return AMPCONV_E_BADARG;
   if (!dW || (uintptr_t)dW % 16 || (colsum && (uintptr_t)colsum % 16)) return AMPCONV_E_BADARG;
   if (rowptr && L <= 0) return AMPCONV_E_BADARG;
@@ -725,29 +754,26 @@ extern "C" int ampconv_proj_wgrad(const float *A, int64_t lda, const float *B, i
   }
   if (!A || !B || (uintptr_t)A % 16 || (uintptr_t)B % 16 || !workspace || (uintptr_t)workspace % 16)
     return AMPCONV_E_BADARG;
-  const WgradPlan p = wgrad_plan(M, Na, Nb);
-  const size_t n_all = (size_t)Na * Nb + Na;
+  const int Nap = (Na + 127) / 128 * 128, Nbp = (Nb + 127) / 128 * 128;
+  const bool ragged = Nap != Na || Nbp != Nb;
+  const WgradPlan p = wgrad_plan(M, Nap, Nbp);
+  const size_t n_all = (size_t)Nap * Nbp + Nap;
   if (workspace_bytes < (size_t)p.S * n_all * sizeof(float)) return AMPCONV_E_WORKSPACE;
-  WgradArgs a{A, lda, B, ldb, M, Na, Nb, rowptr, L, (float *)workspace, p.S, p.rows_per_slice};
-  const int ntiles = (Na / p.ti) * (Nb / p.tj);
+  WgradArgs a{A, lda, B, ldb, M, Na, Nb, rowptr, L, (float *)workspace, p.S, p.rows_per_slice, Nap, Nbp};
+  const int ntiles = (Nap / p.ti) * (Nbp / p.tj);
   const unsigned grid = (unsigned)(((p.S + 7) / 8 * 8) * ntiles);
-  if (p.ti == 256) {
-    if (rowptr) proj_wgrad_kernel<256, 256, 2, 4, true><<<grid, 512, 0, st>>>(a);
-    else proj_wgrad_kernel<256, 256, 2, 4, false><<<grid, 512, 0, st>>>(a);
-  } else if (p.tj == 256) {
-    if (rowptr) proj_wgrad_kernel<128, 256, 2, 2, true><<<grid, 256, 0, st>>>(a);
-    else proj_wgrad_kernel<128, 256, 2, 2, false><<<grid, 256, 0, st>>>(a);
-  } else {
-    if (rowptr) proj_wgrad_kernel<128, 128, 2, 2, true><<<grid, 256, 0, st>>>(a);
-    else proj_wgrad_kernel<128, 128, 2, 2, false><<<grid, 256, 0, st>>>(a);
-  }
-  wgrad_reduce_kernel<<<(unsigned)((n_all / 4 + 31) / 32), 256, 0, st>>>((const float *)workspace, p.S,
-                                                                          (int64_t)Na * Nb, (int64_t)n_all, dW, colsum);
+#define WGRAD_LAUNCH(TI_, TJ_, WI_, WJ_, NT_)                                                              \
+  do {                                                                                                     \
+    if (rowptr && ragged) proj_wgrad_kernel<TI_, TJ_, WI_, WJ_, true, true><<<grid, NT_, 0, st>>>(a);       \
+    else if (rowptr) proj_wgrad_kernel<TI_, TJ_, WI_, WJ_, true, false><<<grid, NT_, 0, st>>>(a);           \
+    else if (ragged) proj_wgrad_kernel<TI_, TJ_, WI_, WJ_, false, true><<<grid, NT_, 0, st>>>(a);           \
+    else proj_wgrad_kernel<TI_, TJ_, WI_, WJ_, false, false><<<grid, NT_, 0, st>>>(a);                      \
+  } while (0)
+  if (p.ti == 256) WGRAD_LAUNCH(256, 256, 2, 4, 512);
+  else if (p.tj == 256) WGRAD_LAUNCH(128, 256, 2, 2, 256);
+  else WGRAD_LAUNCH(128, 128, 2, 2, 256);
+#undef WGRAD_LAUNCH
+  wgrad_reduce_kernel<<<(unsigned)((n_all / 4 + 31) / 32), 256, 0, st>>>((const float *)workspace, p.S, Na, Nb, Nap, Nbp,
+                                                                         dW, colsum);
   return ampconv_launch_status();
 }
-
-#ifdef AMPCONV_PROJ_STAMPS
-extern "C" int ampconv_debug_read_proj_stamps(unsigned long long *host_out, int n) {
-  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_proj_stamps), sizeof(unsigned long long) * n);
-}
-#endif

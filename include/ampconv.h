@@ -226,11 +226,12 @@ int ampconv_masked_colsum(const void *dY, const int32_t *rowptr, int64_t N,
  * fp32 in, fp32 out, fp32 accumulate; every operand element is split EXACTLY into three bf16 terms
  * and a product is the sum of the six partial products of order >= 2^-16 on
  * v_mfma_f32_32x32x16_bf16 (error of the dropped terms <= 3 * 2^-26 per product: fp32 grade).
- *   proj_supported     : 1 if (N, K) is served (N % 128 == 0, K % 32 == 0), else 0 -- the caller
- *                        then uses a library GEMM
+ *   proj_supported     : 1 if (N, K) is served (both multiples of 4: rows are read and written as float4; tiles
+ *                        are padded internally, so the reference's default embed_dim = 100 is served), else 0 --
+ *                        the caller then uses a library GEMM
  *   proj_weight_image  : B[n][k] = W[n * stride_n + k * stride_k] (N x K) -> `image`
  *                        (proj_weight_image_bytes(N, K) bytes, 16-byte aligned): the three bf16 planes
- *                        of the weight as ready MFMA fragments.  (stride_n, stride_k) = (K, 1) uses a
+ *                        of the weight as ready MFMA fragments, zero-padded to (N to 128, K to 32).  (stride_n, stride_k) = (K, 1) uses a
  *                        row-major [N, K] weight as it stands (forward), (1, N) its transpose (backward).
  *   proj_weight_images : up to 8 of them in ONE launch (forward and transposed images of both weights of a layer)
  *   proj_rows          : out[m, :N] = (A[m, :K] B^T + bias) * (rowptr ? [node m / L has an in-edge] : 1)

@@ -28,7 +28,11 @@ def _rowptr(n_nodes, empty, dev):
 
 
 @pytest.mark.parametrize('M,K,N', [(5, 128, 128), (129, 128, 384), (1000, 256, 768), (4096, 768, 256),
-                                   (20 * 333, 256, 256), (777, 384, 128)])
+                                   (20 * 333, 256, 256), (777, 384, 128),
+                                   # ragged shapes (tiles padded inside): the reference's default embed_dim = 100
+                                   # (amp_gcn.py:21-35), 64 (fixture wide_L4_D64_H8), 8 and 4 (toy fixtures)
+                                   (40 * 77, 100, 300), (333, 300, 100), (501, 100, 100), (260, 64, 192), (37, 8, 24),
+                                   (5, 4, 12), (700, 200, 100)])
 @pytest.mark.parametrize('transpose', [False, True])
 def test_proj_rows_matches_fp64(M, K, N, transpose):
     from ampnet_amd.conv import functional as F_
@@ -78,7 +82,8 @@ def test_proj_rows_mask_gives_exact_zero_rows(L, empty):
         assert (out[n] == 0).all()
 
 
-@pytest.mark.parametrize('M,Na,Nb', [(37, 128, 128), (20 * 271, 384, 128), (5000, 768, 256), (70001, 256, 256)])
+@pytest.mark.parametrize('M,Na,Nb', [(37, 128, 128), (20 * 271, 384, 128), (5000, 768, 256), (70001, 256, 256),
+                                     (40 * 77, 300, 100), (4000, 100, 100), (999, 192, 64), (61, 24, 8), (20 * 40, 200, 100)])
 @pytest.mark.parametrize('masked', [False, True])
 def test_proj_wgrad_matches_fp64(M, Na, Nb, masked):
     from ampnet_amd.conv import functional as F_
@@ -125,8 +130,10 @@ def test_unsupported_shapes_are_refused_not_miscomputed():
     from ampnet_amd import _lib
     lib = _lib.load()
     assert lib.ampconv_proj_supported(256, 256) == 1 and lib.ampconv_proj_supported(768, 256) == 1
-    assert lib.ampconv_proj_supported(100, 100) == 0 and lib.ampconv_proj_supported(64, 64) == 0
-    assert lib.ampconv_proj_rows(None, 100, 10, 100, None, 100, None, None, 0, None, 100, None) == -1
+    assert lib.ampconv_proj_supported(100, 100) == 1 and lib.ampconv_proj_supported(300, 100) == 1     # padded inside
+    assert lib.ampconv_proj_supported(3, 3) == 0 and lib.ampconv_proj_supported(102, 100) == 0         # not float4 rows
+    assert lib.ampconv_proj_rows(None, 100, 10, 100, None, 100, None, None, 0, None, 100, None) == -1  # null pointers
+    assert lib.ampconv_proj_rows(None, 3, 10, 3, None, 3, None, None, 0, None, 3, None) == -1
 
 
 def test_layer_native_vs_library_gemm_error_table():
