@@ -84,7 +84,44 @@ def evaluate(DH, stride, f, L=20, verbose=False):
     return res
 
 
+W64_GROUPS = [list(range(16 * g, 16 * g + 16)) for g in range(4)]     # ds_write_b64: 4 groups of 16 contiguous lanes, 32 banks
+
+
+def check_proj():
+    """Entry `proj`: the LDS images of csrc/proj_gemm.hip (byte addresses -> dword addresses).
+    rows kernel, A planes of one 16-deep step: thread (c = t & 3, r0 = t >> 2) stores 8 bytes of row r0 at fragment slot
+    32 h + (r ^ 4 h), half q (h = c >> 1, q = c & 1); a fragment read is lane (r, h) -> slot 32 h + (r ^ 4 h), 16 bytes.
+    wgrad kernel: [16 rows][256 columns] bf16 rows of 512 bytes, byte (8 c) ^ ((row & 3) << 6); transposed reads: lane
+    (h, gi, q, p) addresses row 8 h + q, byte ((64 tile) ^ (q << 6)) + 32 gi + 8 p (ds_read_b64_tr_b16 banks as ds_read_b64:
+    two groups of 32 lanes, 64 banks)."""
+    def wr(l):           # 64 consecutive threads of a wave: t = l (any wave: rows shift by 16, same residues)
+        c, r0 = l & 3, l >> 2
+        h, q = c >> 1, c & 1
+        return (((32 * h + ((r0 & 31) ^ (4 * h))) << 4) + 8 * q) // 4
+    def rd(l):
+        r, h = l & 31, l >> 5
+        return ((32 * h + (r ^ (4 * h))) << 4) // 4
+    print('proj rows: A-plane ds_write_b64', cost(W64_GROUPS, wr, 2, 32), ' fragment ds_read_b128', cost(B128_GROUPS, rd, 4, 64))
+    for row_bytes, ncol4 in ((512, 64), (256, 32)):
+        worst_w = worst_r = 0
+        for rbase in range(0, 16, 64 // ncol4 if ncol4 <= 64 else 1):
+            def w(l, rbase=rbase):
+                c, r = l % ncol4, rbase + l // ncol4
+                return (r * row_bytes + ((8 * c) ^ ((r & 3) << 6))) // 4
+            worst_w = max(worst_w, cost(W64_GROUPS, w, 2, 32))
+        for tile in range(row_bytes // 64):
+            for u in range(2):
+                def r(l, tile=tile, u=u):
+                    h, gi, q, p = l >> 5, (l >> 4) & 1, (l >> 2) & 3, l & 3
+                    return ((8 * h + 4 * u + q) * row_bytes + (((tile & 3) ^ q) << 6) + ((tile >> 2) << 8) + 32 * gi + 8 * p) // 4
+                worst_r = max(worst_r, cost(B32_GROUPS, r, 2, 64))
+        print(f'proj wgrad ({row_bytes}-byte rows): plane ds_write_b64', worst_w, ' ds_read_b64_tr_b16', worst_r)
+
+
 if __name__ == '__main__':
+    if len(sys.argv) > 1 and sys.argv[1] == 'proj':
+        check_proj()
+        sys.exit(0)
     for DH in (32, 16):
         best = None
         nchunk = DH // 4
