@@ -1,6 +1,7 @@
 // bf16-storage edge kernels for gfx950 (BASELINE config 5): Q/K/V/O and the gradients live in HBM
 // as bf16, every product runs on v_mfma_f32_16x16x32_bf16 with fp32 accumulation, softmax and all
-// sums are fp32.  L <= 20, dh = 32.  Half the HBM bytes of the fp32 path and 1/16 of its MFMA
+// sums are fp32.  L <= 20, dh = 32 (or dh = 16 as a half-filled dh = 32 tile: `HALF`, see below).  Half the HBM bytes
+// of the fp32 path and 1/16 of its MFMA
 // cycles per product; the reference itself is fp32 only, so this is an extension checked against
 // the fp32 oracle at bf16 tolerance (tests/test_gpu_parity.py::test_bf16_storage).
 //
@@ -26,6 +27,9 @@ typedef unsigned short bf16_t;
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr int kWavesPerBlock = 4;
 constexpr int DH = 32;
+// HALF (dh = 16, BASELINE config 3's head width): the head's 16 channels occupy the lower half of a 32-channel tile;
+// the upper half is never loaded (zero operands: the 32-deep channel contraction is zero-padded), its output tile
+// (mc = 1) is computed on zeros and not stored.  Functional, not tuned: half of every load and MFMA is padding.
 constexpr int kRowBytes = DH * 2;                 // 64-byte token rows
 constexpr int kTileBytes = kLmax * kRowBytes;     // 1280 B
 
@@ -50,7 +54,7 @@ struct PairRegsH {
   i32x4 v[3];
 };
 
-template <bool FULL>
+template <bool FULL, bool HALF>
 __device__ __forceinline__ void pair_load_h(PairRegsH &t, const bf16_t *baseA, int64_t strideA,
                                             const bf16_t *baseB, int64_t strideB, int L, int lane) {
   const int r = lane >> 2, q = lane & 3;
@@ -59,7 +63,8 @@ __device__ __forceinline__ void pair_load_h(PairRegsH &t, const bf16_t *baseA, i
     const int R = r + 16 * i;
     const bool isB = R >= kLmax;
     const int j = isB ? R - kLmax : R;
-    const bool valid = (R < 2 * kLmax) && (FULL || j < L);
+    const bool valid = (R < 2 * kLmax) && (FULL || j < L) && (!HALF || q < 2);
+    if (HALF) t.v[i] = i32x4{0, 0, 0, 0};
     const unsigned off = (unsigned)j * (unsigned)(isB ? strideB : strideA) + 8u * (unsigned)q;
     const bf16_t *p = (isB ? baseB : baseA) + off;
     if (valid) t.v[i] = *reinterpret_cast<const i32x4 *>(p);
@@ -92,12 +97,13 @@ __device__ __forceinline__ i32x4 rowfrag(const char *tile, int mt, int lane) {
   return *reinterpret_cast<const i32x4 *>(tile + plane_off(j, kg));
 }
 // ... of column tile nt straight from global memory (fixed side; token rows >= L read as zero)
+template <bool HALF>
 __device__ __forceinline__ i32x4 rowfrag_global(const bf16_t *base, int64_t row_stride, int nt, int L,
                                                 int lane) {
   const int m = lane & 15, kg = lane >> 4;
   const int j = nt == 0 ? m : 16 + m;
   i32x4 x = {0, 0, 0, 0};
-  if (j < L) x = *reinterpret_cast<const i32x4 *>(base + (int64_t)j * row_stride + 8 * kg);
+  if (j < L && (!HALF || kg < 2)) x = *reinterpret_cast<const i32x4 *>(base + (int64_t)j * row_stride + 8 * kg);
   return x;
 }
 // token-product fragment of channel tile mc: k-slots 0..3 = tokens 4kg..4kg+3, slot 4 = token 16 + kg
@@ -157,6 +163,7 @@ struct Args {
 
 // output tile store: C/D layout lane (i' = lane & 15, g), reg q -> channel 4g + q + 16 mc, token
 // i' + 16 nt; `to_f32` = hub pass (fp32 partial tiles)
+template <bool HALF>
 __device__ __forceinline__ void store_tile(const ampconv_view_t &v, int64_t node, int h, const f32x4 (&T)[2][2],
                                            float scale, bool to_f32, int L, int lane) {
   const int g = lane >> 4;
@@ -165,7 +172,7 @@ __device__ __forceinline__ void store_tile(const ampconv_view_t &v, int64_t node
     const int i = (lane & 15) + 16 * nt;
     if (i < L) {
 #pragma unroll
-      for (int mc = 0; mc < 2; ++mc) {
+      for (int mc = 0; mc < (HALF ? 1 : 2); ++mc) {
         const float a = T[mc][nt][0] * scale, b = T[mc][nt][1] * scale, c = T[mc][nt][2] * scale,
                     d = T[mc][nt][3] * scale;
         const int64_t off = node * v.node_stride + (int64_t)h * v.head_stride + (int64_t)i * v.row_stride +
@@ -181,7 +188,7 @@ __device__ __forceinline__ void store_tile(const ampconv_view_t &v, int64_t node
 }
 
 // ---------------------------------------------------------------- forward
-template <bool FULL>
+template <bool FULL, bool HALF>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void fwd_bf16(Args a) {
   __shared__ __attribute__((aligned(16))) char lds_all[kWavesPerBlock][2 * kTileBytes];
   const int lane = threadIdx.x & 63;
@@ -198,8 +205,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void fwd_bf16(Args a) {
   i32x4 qB[2];
   {
     const bf16_t *qb = tile_ptr<const bf16_t>(a.Q, d, h);
-    qB[0] = rowfrag_global(qb, a.Q.row_stride, 0, L, lane);
-    qB[1] = rowfrag_global(qb, a.Q.row_stride, 1, L, lane);
+    qB[0] = rowfrag_global<HALF>(qb, a.Q.row_stride, 0, L, lane);
+    qB[1] = rowfrag_global<HALF>(qb, a.Q.row_stride, 1, L, lane);
   }
   if (!FULL) tiles_zero(Kt, lane);
   f32x4 OT[2][2];
@@ -210,7 +217,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void fwd_bf16(Args a) {
   IdxWindow win;
   auto fetch = [&](int p) {
     const int64_t s = idxwin_get<false>(win, a.idx, nullptr, p, end, lane, nullptr);
-    pair_load_h<FULL>(kv, tile_ptr<const bf16_t>(a.K, s, h), a.K.row_stride,
+    pair_load_h<FULL, HALF>(kv, tile_ptr<const bf16_t>(a.K, s, h), a.K.row_stride,
                       tile_ptr<const bf16_t>(a.V, s, h), a.V.row_stride, L, lane);
   };
   if (beg < end) {
@@ -244,11 +251,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void fwd_bf16(Args a) {
     __builtin_amdgcn_wave_barrier();
   }
   const bool hubp = a.hub.mode == 2;
-  store_tile(a.O, onode, h, OT, hubp ? 1.f : (deg > 0 ? 1.f / (float)deg : 0.f), hubp, L, lane);
+  store_tile<HALF>(a.O, onode, h, OT, hubp ? 1.f : (deg > 0 ? 1.f / (float)deg : 0.f), hubp, L, lane);
 }
 
 // ---------------------------------------------------------------- backward, destination pass
-template <bool FULL>
+template <bool FULL, bool HALF>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void bwd_dst_bf16(Args a) {
   __shared__ __attribute__((aligned(16))) char lds_all[kWavesPerBlock][2 * kTileBytes];
   const int lane = threadIdx.x & 63;
@@ -268,8 +275,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void bwd_dst_bf16(Args a) {
     const bf16_t *gb = tile_ptr<const bf16_t>(a.dO, r, h);
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
-      qB[nt] = rowfrag_global(qb, a.Q.row_stride, nt, L, lane);
-      gB[nt] = rowfrag_global(gb, a.dO.row_stride, nt, L, lane);
+      qB[nt] = rowfrag_global<HALF>(qb, a.Q.row_stride, nt, L, lane);
+      gB[nt] = rowfrag_global<HALF>(gb, a.dO.row_stride, nt, L, lane);
     }
   }
   if (!FULL) tiles_zero(Kt, lane);
@@ -281,7 +288,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void bwd_dst_bf16(Args a) {
   IdxWindow win;
   auto fetch = [&](int p) {
     const int64_t s = idxwin_get<false>(win, a.idx, nullptr, p, end, lane, nullptr);
-    pair_load_h<FULL>(kv, tile_ptr<const bf16_t>(a.K, s, h), a.K.row_stride,
+    pair_load_h<FULL, HALF>(kv, tile_ptr<const bf16_t>(a.K, s, h), a.K.row_stride,
                       tile_ptr<const bf16_t>(a.V, s, h), a.V.row_stride, L, lane);
   };
   if (beg < end) {
@@ -327,11 +334,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void bwd_dst_bf16(Args a) {
     __builtin_amdgcn_wave_barrier();
   }
   const bool hubp = a.hub.mode == 2;
-  store_tile(a.O, onode, h, dQT, hubp ? 1.f : a.oscale, hubp, L, lane);
+  store_tile<HALF>(a.O, onode, h, dQT, hubp ? 1.f : a.oscale, hubp, L, lane);
 }
 
 // ---------------------------------------------------------------- backward, source pass
-template <bool FULL>
+template <bool FULL, bool HALF>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void bwd_src_bf16(Args a) {
   __shared__ __attribute__((aligned(16))) char lds_all[kWavesPerBlock][2 * kTileBytes];
   const int lane = threadIdx.x & 63;
@@ -350,8 +357,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void bwd_src_bf16(Args a) {
     const bf16_t *vb = tile_ptr<const bf16_t>(a.V, s, h);
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
-      kB[nt] = rowfrag_global(kb, a.K.row_stride, nt, L, lane);
-      vB[nt] = rowfrag_global(vb, a.V.row_stride, nt, L, lane);
+      kB[nt] = rowfrag_global<HALF>(kb, a.K.row_stride, nt, L, lane);
+      vB[nt] = rowfrag_global<HALF>(vb, a.V.row_stride, nt, L, lane);
     }
   }
   if (!FULL) tiles_zero(Qt, lane);
@@ -365,7 +372,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void bwd_src_bf16(Args a) {
   IdxWindow win;
   auto fetch = [&](int p, float &w) {
     const int64_t d = idxwin_get<true>(win, a.idx, a.cinv, p, end, lane, &w);
-    pair_load_h<FULL>(qg, tile_ptr<const bf16_t>(a.Q, d, h), a.Q.row_stride,
+    pair_load_h<FULL, HALF>(qg, tile_ptr<const bf16_t>(a.Q, d, h), a.Q.row_stride,
                       tile_ptr<const bf16_t>(a.dO, d, h), a.dO.row_stride, L, lane);
   };
   if (beg < end) {
@@ -429,16 +436,21 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void bwd_src_bf16(Args a) {
     __builtin_amdgcn_wave_barrier();
   }
   const bool hubp = a.hub.mode == 2;
-  store_tile(a.dK, onode, h, dKT, hubp ? 1.f : a.oscale, hubp, L, lane);
-  store_tile(a.dV, onode, h, dVT, 1.f, hubp, L, lane);
+  store_tile<HALF>(a.dK, onode, h, dKT, hubp ? 1.f : a.oscale, hubp, L, lane);
+  store_tile<HALF>(a.dV, onode, h, dVT, 1.f, hubp, L, lane);
 }
 
-template <typename KT, typename KF>
-int launch(const Args &a, bool full, KT kt, KF kf, hipStream_t stream) {
+// kernels[2 * half + full]
+typedef void (*EdgeKernel)(Args);
+int launch(Args &a, int L, int D, int H, EdgeKernel const (&kernels)[4], hipStream_t stream) {
+  const int dh = D / H;
+  if (dh != DH && dh != DH / 2) return AMPCONV_E_BADARG;
+  a.qscale = kLog2e / sqrtf((float)dh);
+  a.oscale = 1.f / sqrtf((float)dh);
   const int64_t blocks = (a.n_units + kWavesPerBlock - 1) / kWavesPerBlock;
   if (blocks > INT32_MAX) return AMPCONV_E_BADARG;
   const dim3 grid((unsigned)blocks), block(64 * kWavesPerBlock);
-  if (full) kt<<<grid, block, 0, stream>>>(a); else kf<<<grid, block, 0, stream>>>(a);
+  kernels[2 * (dh == DH / 2) + (L == kLmax)]<<<grid, block, 0, stream>>>(a);
   return ampconv_launch_status();
 }
 
@@ -450,7 +462,7 @@ inline bool aligned16h(const ampconv_view_t &v) {
 }  // namespace
 
 bool ampconv_bf16_supported(int L, int D, int H, const ampconv_view_t *views, int n) {
-  if (!(L >= 1 && L <= kLmax && D / H == DH)) return false;
+  if (!(L >= 1 && L <= kLmax && (D / H == DH || D / H == DH / 2) && D % H == 0)) return false;
   for (int i = 0; i < n; ++i)
     if (!aligned16h(views[i])) return false;
   return true;
@@ -463,8 +475,8 @@ int ampconv_fwd_edge_bf16(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V, 
   a.Q = Q; a.K = K; a.V = V; a.O = O;
   a.ptr = rowptr; a.idx = col; a.qidx = qidx; a.hub = hub;
   a.n_units = n_rows * H; a.L = L; a.H = H;
-  a.qscale = kLog2e / sqrtf((float)DH);
-  return launch(a, L == kLmax, fwd_bf16<true>, fwd_bf16<false>, stream);
+  static const EdgeKernel kernels[4] = {fwd_bf16<false, false>, fwd_bf16<true, false>, fwd_bf16<false, true>, fwd_bf16<true, true>};
+  return launch(a, L, D, H, kernels, stream);
 }
 
 int ampconv_bwd_edge_dst_bf16(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V, ampconv_view_t dO,
@@ -474,9 +486,8 @@ int ampconv_bwd_edge_dst_bf16(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t
   a.Q = Q; a.K = K; a.V = V; a.dO = dO; a.O = dQ;
   a.ptr = rowptr; a.idx = col; a.hub = hub;
   a.n_units = n_rows * H; a.L = L; a.H = H;
-  a.qscale = kLog2e / sqrtf((float)DH);
-  a.oscale = 1.f / sqrtf((float)DH);
-  return launch(a, L == kLmax, bwd_dst_bf16<true>, bwd_dst_bf16<false>, stream);
+  static const EdgeKernel kernels[4] = {bwd_dst_bf16<false, false>, bwd_dst_bf16<true, false>, bwd_dst_bf16<false, true>, bwd_dst_bf16<true, true>};
+  return launch(a, L, D, H, kernels, stream);
 }
 
 int ampconv_bwd_edge_src_bf16(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V, ampconv_view_t dO,
@@ -487,7 +498,6 @@ int ampconv_bwd_edge_src_bf16(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t
   a.Q = Q; a.K = K; a.V = V; a.dO = dO; a.dK = dK; a.dV = dV;
   a.ptr = cscptr; a.idx = crow; a.cinv = cinv; a.hub = hub;
   a.n_units = n_src * H; a.L = L; a.H = H;
-  a.qscale = kLog2e / sqrtf((float)DH);
-  a.oscale = 1.f / sqrtf((float)DH);
-  return launch(a, L == kLmax, bwd_src_bf16<true>, bwd_src_bf16<false>, stream);
+  static const EdgeKernel kernels[4] = {bwd_src_bf16<false, false>, bwd_src_bf16<true, false>, bwd_src_bf16<false, true>, bwd_src_bf16<true, true>};
+  return launch(a, L, D, H, kernels, stream);
 }

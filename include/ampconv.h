@@ -41,7 +41,8 @@ enum {
 };
 
 /* dtype codes.  AMPCONV_BF16: every view is bf16 in HBM (Q/K/V/O and gradients), products on the
- * bf16 MFMA with fp32 accumulation, fp32 softmax (L <= 20, dh = 32 only; BASELINE config 5).
+ * bf16 MFMA with fp32 accumulation, fp32 softmax (L <= 20; dh = 32 -- BASELINE config 5 -- or
+ * dh = 16 as half-filled tiles).
  * All AMPCONV_F32* codes take and return fp32 tensors; they differ in how the
  * per-edge products are evaluated on the matrix cores:
  *   AMPCONV_F32_EXACT   v_mfma_f32_16x16x4_f32 (native fp32 MFMA, 1/16 of the bf16 rate)

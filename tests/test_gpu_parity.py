@@ -432,9 +432,12 @@ def test_data_parallel_step_two_ranks(dev, tmp_path):
         assert torch.equal(a0, a1)
 
 
-@pytest.mark.parametrize('shape', [(1200, 12000, 20, 256, 8), (700, 5000, 13, 64, 2)], ids=['L20_D256', 'L13_D64'])
+@pytest.mark.parametrize('shape', [(1200, 12000, 20, 256, 8), (700, 5000, 13, 64, 2), (900, 9000, 20, 128, 8),
+                                   (500, 4000, 7, 48, 3)],
+                         ids=['L20_D256', 'L13_D64', 'L20_D128_dh16', 'L7_D48_dh16'])
 def test_bf16_storage(shape, dev):
-    """bf16-storage mode (BASELINE config 5: Q/K/V/O and gradients in bf16, fp32 accumulate)
+    """bf16-storage mode (BASELINE config 5: Q/K/V/O and gradients in bf16, fp32 accumulate; head width 32, and
+    16 -- BASELINE config 3's -- as half-filled tiles)
     against the fp64 oracle evaluated on the same bf16-rounded inputs and parameters.
     Tolerance: rtol 2e-2, atol 2e-2 of the tensor's scale."""
     from ampnet_amd import AMPConv
@@ -471,6 +474,15 @@ def test_bf16_storage(shape, dev):
     assert_close_scaled(f64(m.out_proj.bias.grad), dbo, 'g_out_proj_bias', atol=2e-2, rtol=2e-2)
     w = layer.attn_output_weights.cpu().numpy()
     assert_close_scaled(w, w_ref, 'attn_output_weights', atol=2e-2, rtol=2e-2)
+
+
+def test_bf16_storage_rejects_other_head_widths(dev):
+    from ampnet_amd import AMPConv
+    layer = AMPConv(100, 2).to(dev).to(torch.bfloat16)                  # dh = 50: fp32 only (edge_block.hip)
+    x = torch.randn(10, 4 * 100, device=dev).to(torch.bfloat16)
+    ei = torch.randint(0, 10, (2, 30), device=dev)
+    with pytest.raises(ValueError, match='head dimensions 32 and 16'):
+        layer(x, ei)
 
 
 def test_training_steps_match_cpu_reference(dev):
