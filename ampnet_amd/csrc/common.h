@@ -51,11 +51,34 @@ struct HubArgs {
                            // 2: hub pass (one unit per (chunk, head), writes partial tiles)
 };
 
-// unit -> (row, head, edge range); returns false if this wave has nothing to do
-__device__ __forceinline__ bool map_unit(const HubArgs &hub, const int32_t *ptr, int64_t unit, int H,
+// unit -> (row, head, edge range); returns false if this wave has nothing to do.
+// Main pass of a graph WITH a long-segment plan (mode 1, i.e. a skewed degree distribution): the row order is a
+// pseudo-random permutation of the rows (scramble_row).  Workgroups go to the 8 XCDs round-robin, so with rows in
+// id order XCD x only ever sees node ids with (2 * id) mod 8 in {x, x - 1}; on an R-MAT graph the degree follows the
+// id's bits (every 0 bit multiplies the expected degree by ~3: ids ending in 00 have ~10 x the edges of ids ending
+// in 11), one XCD gets most of the work and the launch lasts as long as that XCD.  Any assignment that looks at a
+// few id bits only has the same problem; the permutation mixes all of them.
+// Bijection on [0, n): two xorshift-multiply rounds on k = bit_length(n - 1) bits (each step is invertible on k-bit
+// integers), cycle-walked back into [0, n) (fewer than two rounds on average since 2^k < 2 n).
+__device__ __forceinline__ int64_t scramble_row(int64_t u, int64_t n) {
+  if (n < 2) return u;
+  const int k = 64 - __builtin_clzll((unsigned long long)(n - 1));
+  const unsigned mask = k >= 32 ? 0xFFFFFFFFu : ((1u << k) - 1u);
+  const int hs = (k + 1) >> 1;
+  unsigned x = (unsigned)u;
+  do {
+    x ^= x >> hs;
+    x = (x * 0x9E3779B1u) & mask;
+    x ^= x >> hs;
+    x = (x * 0x85EBCA6Bu) & mask;
+    x ^= x >> hs;
+  } while ((int64_t)x >= n);
+  return (int64_t)x;
+}
+__device__ __forceinline__ bool map_unit(const HubArgs &hub, const int32_t *ptr, int64_t unit, int64_t n_units, int H,
                                          int64_t &row, int64_t &out_node, int &h, int &beg, int &end,
                                          int &deg) {
-  const int64_t u = unit / H;
+  int64_t u = unit / H;
   h = (int)(unit - u * H);
   if (hub.mode == 2) {
     const HubDesc d = reinterpret_cast<const HubDesc *>(hub.header + 4)[u];
@@ -66,6 +89,7 @@ __device__ __forceinline__ bool map_unit(const HubArgs &hub, const int32_t *ptr,
     deg = ptr[row + 1] - ptr[row];
     return true;
   }
+  if (hub.mode == 1) u = scramble_row(u, n_units / H);
   row = out_node = u;
   beg = ptr[u];
   end = ptr[u + 1];

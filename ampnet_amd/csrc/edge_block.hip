@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void fwd_block(BArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int64_t r, onode;
   int h, beg, end, deg;
-  if (!map_unit(a.hub, a.ptr, blockIdx.x, a.H, r, onode, h, beg, end, deg)) return;    // block-uniform
+  if (!map_unit(a.hub, a.ptr, blockIdx.x, a.n_units, a.H, r, onode, h, beg, end, deg)) return;    // block-uniform
   const int L = a.L, dh = a.dh, ntok = a.ntok, g = lane >> 4;
   float *Kt = lds, *Vt = lds + 16 * ntok * DHP;
   const int64_t d = a.qidx ? a.qidx[r] : r;
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void bwd_dst_block(BArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int64_t r, onode;
   int h, beg, end, deg;
-  if (!map_unit(a.hub, a.ptr, blockIdx.x, a.H, r, onode, h, beg, end, deg)) return;
+  if (!map_unit(a.hub, a.ptr, blockIdx.x, a.n_units, a.H, r, onode, h, beg, end, deg)) return;
   const int L = a.L, dh = a.dh, ntok = a.ntok, g = lane >> 4;
   float *Kt = lds, *Vt = lds + 16 * ntok * DHP;
   const float inv = deg > 0 ? 1.f / (float)deg : 0.f;       // dO is the gradient of the MEAN
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256) void bwd_src_block(BArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int64_t s, onode;
   int h, beg, end, deg;
-  if (!map_unit(a.hub, a.ptr, blockIdx.x, a.H, s, onode, h, beg, end, deg)) return;
+  if (!map_unit(a.hub, a.ptr, blockIdx.x, a.n_units, a.H, s, onode, h, beg, end, deg)) return;
   const int L = a.L, dh = a.dh, ntok = a.ntok, g = lane >> 4, n = lane & 15;
   float *Qt = lds, *Gt = lds + 16 * ntok * DHP;
 

@@ -134,7 +134,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void fwd_mfma(FwdArgs a) {
   if (unit >= a.n_units) return;
   int64_t r, onode;
   int h, beg, end, deg;
-  if (!map_unit(a.hub, a.rowptr, unit, a.H, r, onode, h, beg, end, deg)) return;
+  if (!map_unit(a.hub, a.rowptr, unit, a.n_units, a.H, r, onode, h, beg, end, deg)) return;
   const int L = a.L, g = lane >> 4;
   float *Kt = lds_all[wave][0], *Vt = lds_all[wave][1];
   const int64_t d = a.qidx ? a.qidx[r] : r;
@@ -282,7 +282,7 @@ __global__ LB_DST void bwd_dst_mfma(BwdArgs a) {
   if (unit >= a.n_units) return;
   int64_t r, onode;
   int h, beg, end, deg;
-  if (!map_unit(a.hub, a.ptr, unit, a.H, r, onode, h, beg, end, deg)) return;
+  if (!map_unit(a.hub, a.ptr, unit, a.n_units, a.H, r, onode, h, beg, end, deg)) return;
   const int L = a.L, g = lane >> 4;
   float *Kt = lds_all[wave][0], *Vt = lds_all[wave][1];
   const float inv = deg > 0 ? 1.f / (float)deg : 0.f;       // dO is the gradient of the MEAN
@@ -419,7 +419,7 @@ __global__ LB_SRC void bwd_src_mfma(BwdArgs a) {
   if (unit >= a.n_units) return;
   int64_t s, onode;
   int h, beg, end, deg;
-  if (!map_unit(a.hub, a.ptr, unit, a.H, s, onode, h, beg, end, deg)) return;
+  if (!map_unit(a.hub, a.ptr, unit, a.n_units, a.H, s, onode, h, beg, end, deg)) return;
   const int L = a.L, n = lane & 15;
   float *Qt = lds_all[wave][0], *Gt = lds_all[wave][1];
   const float oscale = a.hub.mode == 2 ? 1.f : a.oscale;
@@ -643,7 +643,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? AMPCONV_SRC_WAVES :
   if (unit >= a.n_units) return;
   int64_t s, onode;
   int h, beg, end, deg;
-  if (!map_unit(a.hub, a.ptr, unit, a.H, s, onode, h, beg, end, deg)) return;
+  if (!map_unit(a.hub, a.ptr, unit, a.n_units, a.H, s, onode, h, beg, end, deg)) return;
   STAMP_DECL
   const int L = a.L, n = lane & 15, g = lane >> 4, sg = (lane >> 2) & 3, jt = lane & 3;
   float *Qt = lds_all[wave], *Gt = Qt + kMain, *stash = Qt + 2 * kMain;
@@ -1091,7 +1091,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, AMPCONV_FWD_WAVES) void fwd_mf
   if (unit >= a.n_units) return;
   int64_t r, onode;
   int h, beg, end, deg;
-  if (!map_unit(a.hub, a.rowptr, unit, a.H, r, onode, h, beg, end, deg)) return;
+  if (!map_unit(a.hub, a.rowptr, unit, a.n_units, a.H, r, onode, h, beg, end, deg)) return;
   const int L = a.L, g = lane >> 4, n = lane & 15, sg = (lane >> 2) & 3, jt = lane & 3;
   float *Kt = lds_all[wave], *Vt = Kt + 16 * DH, *Ktail = Kt + 32 * DH, *Vtail = Kt + 48 * DH;
   const int64_t d = a.qidx ? a.qidx[r] : r;
@@ -1366,7 +1366,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? AMPCONV_DST_WAVES :
   if (unit >= a.n_units) return;
   int64_t r, onode;
   int h, beg, end, deg;
-  if (!map_unit(a.hub, a.ptr, unit, a.H, r, onode, h, beg, end, deg)) return;
+  if (!map_unit(a.hub, a.ptr, unit, a.n_units, a.H, r, onode, h, beg, end, deg)) return;
   constexpr int NTM = NT4 ? 1 : 2;           // 16-wide destination-token column tiles on the 16x16x4 path
   const int L = a.L, g = lane >> 4, n = lane & 15, sg = (lane >> 2) & 3, jt = lane & 3;
   float *Kt = lds_all[wave], *Vt = Kt + kImg, *tails = lds_tails[wave];

@@ -197,7 +197,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void fwd_bf16(Args a) {
   if (unit >= a.n_units) return;
   int64_t r, onode;
   int h, beg, end, deg;
-  if (!map_unit(a.hub, a.ptr, unit, a.H, r, onode, h, beg, end, deg)) return;
+  if (!map_unit(a.hub, a.ptr, unit, a.n_units, a.H, r, onode, h, beg, end, deg)) return;
   const int L = a.L, g = lane >> 4;
   char *Kt = lds_all[wave], *Vt = Kt + kTileBytes;
   const int64_t d = a.qidx ? a.qidx[r] : r;
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void bwd_dst_bf16(Args a) {
   if (unit >= a.n_units) return;
   int64_t r, onode;
   int h, beg, end, deg;
-  if (!map_unit(a.hub, a.ptr, unit, a.H, r, onode, h, beg, end, deg)) return;
+  if (!map_unit(a.hub, a.ptr, unit, a.n_units, a.H, r, onode, h, beg, end, deg)) return;
   const int L = a.L, g = lane >> 4;
   char *Kt = lds_all[wave], *Vt = Kt + kTileBytes;
   const float inv = deg > 0 ? 1.f / (float)deg : 0.f;     // dO is the gradient of the MEAN
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void bwd_src_bf16(Args a) {
   if (unit >= a.n_units) return;
   int64_t s, onode;
   int h, beg, end, deg;
-  if (!map_unit(a.hub, a.ptr, unit, a.H, s, onode, h, beg, end, deg)) return;
+  if (!map_unit(a.hub, a.ptr, unit, a.n_units, a.H, s, onode, h, beg, end, deg)) return;
   const int L = a.L, n = lane & 15;
   char *Qt = lds_all[wave], *Gt = Qt + kTileBytes;
 

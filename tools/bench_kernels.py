@@ -1,6 +1,6 @@
 """Developer micro-benchmark: time each C-ABI edge kernel on a synthetic uniform graph.
 
-    python tools/bench_kernels.py [N E L D H] [--generic]
+    python tools/bench_kernels.py [N E L D H] [--generic] [--bf16] [--mode=exact|bf16x6|bf16x9] [--hub] [--rmat] [--compact]
 """
 import os
 import sys
@@ -44,9 +44,30 @@ def main():
     tdt = torch.bfloat16 if '--bf16' in sys.argv else torch.float32
     if tdt == torch.bfloat16:
         dt = _lib.AMPCONV_BF16
-    qkv = torch.randn(N * L, 3 * D, device=dev).to(tdt)
-    dobar = torch.randn(N * L, D, device=dev).to(tdt)
+    pad = next((int(a.split('=')[1]) for a in sys.argv if a.startswith('--rowpad=')), 0)   # extra elements per token row
+    qkv = torch.randn(N * L, 3 * D + pad, device=dev).to(tdt)
+    dobar = torch.randn(N * L, D + pad, device=dev).to(tdt)
     ei = torch.randint(0, N, (2, E), device=dev)
+    if '--rmat' in sys.argv:                      # BASELINE config 5's generator (N must be a power of two)
+        import bench
+        ei = bench.rmat_edges(N.bit_length() - 1, E, torch.Generator(device=dev).manual_seed(1234), dev)
+    if '--sortdeg' in sys.argv:                   # relabel nodes by descending in+out degree (0 = the biggest hub)
+        deg = torch.bincount(ei[0], minlength=N) + torch.bincount(ei[1], minlength=N)
+        order = torch.argsort(deg, descending=True, stable=True)
+        relabel = torch.empty(N, dtype=torch.int64, device=dev)
+        relabel[order] = torch.arange(N, device=dev)
+        ei = relabel[ei]
+    if '--shuffle' in sys.argv:                   # relabel nodes by a random permutation
+        relabel = torch.randperm(N, device=dev)
+        ei = relabel[ei]
+    if '--compact' in sys.argv:                   # relabel so that only nodes with an edge remain (N shrinks)
+        ids = torch.unique(ei)
+        relabel = torch.empty(N, dtype=torch.int64, device=dev)
+        relabel[ids] = torch.arange(ids.numel(), device=dev)
+        ei = relabel[ei]
+        N = int(ids.numel())
+        qkv, dobar = qkv[: N * L], dobar[: N * L]
+        print('compacted to', N, 'nodes')
     if '--hub' in sys.argv:                       # 5 % of the edges end at node 3, 5 % start at node 5
         ei[1, : E // 20] = 3
         ei[0, E // 20: E // 10] = 5
@@ -70,8 +91,8 @@ def main():
             views = [_lib.View(t.data_ptr(), L * dh, dh, N * L * dh) for t in keep_in]
         Qv, Kv, Vv, dOv = views
     print('input layout', layout)
-    obar = torch.empty(N * L, D, device=dev, dtype=tdt)
-    dqkv = torch.empty(N * L, 3 * D, device=dev, dtype=tdt)
+    obar = torch.empty(N * L, D + pad, device=dev, dtype=tdt)
+    dqkv = torch.empty(N * L, 3 * D + pad, device=dev, dtype=tdt)
     dQv, dKv, dVv = (F_._view(dqkv, i * D, L, dh) for i in range(3))
     st = torch.cuda.current_stream().cuda_stream
     R = L * D * qkv.element_size()

@@ -10,7 +10,7 @@ import os
 import re
 import sys
 
-KERNELS = (('fwd', r'\bfwd_(mfma|bf16)'), ('bwd_dst', r'\bbwd_dst_(mfma|bf16)'), ('bwd_src', r'\bbwd_src_(mfma|bf16)'),
+KERNELS = (('fwd', r'\bfwd_(mfma|bf16|split)'), ('bwd_dst', r'\bbwd_dst_(mfma|bf16|split)'), ('bwd_src', r'\bbwd_src_(mfma|bf16|split)'),
            ('proj_rows', r'proj_rows_kernel'), ('proj_wgrad', r'proj_wgrad_kernel'))
 
 
