@@ -18,7 +18,14 @@ AMPCONV_F32_BF16X9 = 3     # fp32 operands split exactly into 3 bf16, 9 partial 
 AMPCONV_F32_BF16X6 = 4     # ... 6 partial products
 PRECISIONS = {'default': AMPCONV_F32, 'exact': AMPCONV_F32_EXACT, 'bf16x9': AMPCONV_F32_BF16X9,
               'bf16x6': AMPCONV_F32_BF16X6}
-HUB_CHUNK = int(os.environ.get('AMPCONV_HUB_CHUNK', 64))   # edges per chunk of a long CSR/CSC segment (include/ampconv.h, long segments)
+HUB_CHUNK = int(os.environ.get('AMPCONV_HUB_CHUNK', 0))    # edges per chunk of a long CSR/CSC segment (include/ampconv.h, long segments); 0 = by size
+
+
+def hub_chunk(num_edges):
+    """Edges per chunk of a long segment.  64 on small graphs (a chunk is walked by ONE wave, so it bounds the launch's
+    latency: ~1.5 us per edge), 128 from a million edges up (cfg5: 619 -> 611 ms per step, half the partial-tile
+    workspace; 128-256 is a flat optimum once the main pass is XCD-balanced, tools/sweep_hub_chunk.sh)."""
+    return HUB_CHUNK if HUB_CHUNK > 0 else (128 if num_edges >= (1 << 20) else 64)
 COLSUM_BLOCKS = 1024      # scratch blocks of ampconv_masked_colsum (csrc/node_ops.hip)
 
 

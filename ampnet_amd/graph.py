@@ -50,12 +50,13 @@ class EdgeCSR:
             self.hub_dst = self.hub_src = None
             self.hub_dst_chunks = self.hub_src_chunks = 0
             plans = [None, None]
-            if E > _lib.HUB_CHUNK:
-                nb = lib.ampconv_hub_plan_bytes(E, _lib.HUB_CHUNK)
+            self.hub_chunk = chunk = _lib.hub_chunk(E)
+            if E > chunk:
+                nb = lib.ampconv_hub_plan_bytes(E, chunk)
                 plans = [torch.empty(nb // 4, **i32), torch.empty(nb // 4, **i32)]
             rc = lib.ampconv_graph_build(ei.data_ptr(), E, N, self.rowptr.data_ptr(), self.col.data_ptr(),
                                          self.eperm.data_ptr(), self.cscptr.data_ptr(), self.crow.data_ptr(),
-                                         self.cperm.data_ptr(), self.cinv.data_ptr(), status.data_ptr(), _lib.HUB_CHUNK,
+                                         self.cperm.data_ptr(), self.cinv.data_ptr(), status.data_ptr(), chunk,
                                          plans[0].data_ptr() if plans[0] is not None else None,
                                          plans[1].data_ptr() if plans[1] is not None else None,
                                          self._by_edge.data_ptr(), ws.data_ptr(), ws_bytes, _stream())
@@ -81,6 +82,7 @@ class EdgeCSR:
         self.cinv = torch.ones(max(n, 1), dtype=torch.float32, device=device)
         self.hub_dst = self.hub_src = None
         self.hub_dst_chunks = self.hub_src_chunks = 0
+        self.hub_chunk = 0
         return self
 
     def csc_positions(self):

@@ -181,7 +181,8 @@ def test_csr_build_is_a_stable_sort(N, E, hub, dev):
     cscptr = np.concatenate([[0], np.cumsum(np.bincount(ei[0], minlength=N))])
     np.testing.assert_array_equal(csr.cscptr.cpu().numpy(), cscptr)
     np.testing.assert_array_equal(csr.cinv.cpu().numpy(), (1.0 / np.bincount(ei[1], minlength=N)[ei[1][cperm]]).astype(np.float32))
-    chunk = _lib.HUB_CHUNK
+    chunk = csr.hub_chunk
+    assert chunk == _lib.hub_chunk(E)
     for plan, n, ptr in ((csr.hub_dst, csr.hub_dst_chunks, rowptr), (csr.hub_src, csr.hub_src_chunks, cscptr)):
         want = set()
         for r in np.nonzero(np.diff(ptr) > chunk)[0]:
