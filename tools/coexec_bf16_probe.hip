@@ -10,6 +10,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define MF16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16((a), (b), (c), 0, 0, 0)
 #define MF32(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+#define MFF(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#define MF4(a, b, c) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (c), 0, 0, 0)
 
 __device__ __forceinline__ unsigned long long now() {
   unsigned long long t;
@@ -36,7 +38,8 @@ __global__ __launch_bounds__(512) void two_waves(float *sink, unsigned long long
   float m = 1.0001f;
   float v0 = x, v1 = x + 1, v2 = x + 2, v3 = x + 3, v4 = x + 4, v5 = x + 5, v6 = x + 6, v7 = x + 7;
   // MFMA roles run 8 x the iterations so that both waves of a SIMD stay busy for a comparable time
-  const int n = role == 0 || role == 2 || role == 6 ? 8 * iters : iters;
+  const int n = role == 0 || role == 2 || role == 6 || role >= 7 ? 8 * iters : iters;
+  const float fa = x + threadIdx.x, fb = x - threadIdx.x;
   const unsigned long long t0 = now();
 #define VALU_LOOP(OP)                                                                            \
   for (int i = 0; i < n; ++i) {                                                                  \
@@ -48,6 +51,31 @@ __global__ __launch_bounds__(512) void two_waves(float *sink, unsigned long long
     for (int i = 0; i < n; ++i) { c0 = MF16(a, b, c0); c0 = MF16(a, b, c0); c0 = MF16(a, b, c0); c0 = MF16(a, b, c0); }
   } else if (role == 2) {
     for (int i = 0; i < n; ++i) { d0 = MF32(a, b, d0); d1 = MF32(a, b, d1); }
+  } else if (role == 7) {      // fp32 16x16x4, four accumulators
+    for (int i = 0; i < n; ++i) { c0 = MFF(fa, fb, c0); c1 = MFF(fa, fb, c1); c2 = MFF(fa, fb, c2); c3 = MFF(fa, fb, c3); }
+  } else if (role == 8) {      // fp32 16x16x4, one dependent chain
+    for (int i = 0; i < n; ++i) { c0 = MFF(fa, fb, c0); c0 = MFF(fa, fb, c0); c0 = MFF(fa, fb, c0); c0 = MFF(fa, fb, c0); }
+  } else if (role == 9) {      // fp32 16x16x4 chain with a 4x4x1 on another accumulator in between (the edge kernels' S phase)
+    for (int i = 0; i < n; ++i) {
+      c0 = MFF(fa, fb, c0); c1 = MF4(fa, fb, c1); c0 = MFF(fa, fb, c0); c1 = MF4(fa, fb, c1);
+      c0 = MFF(fa, fb, c0); c1 = MF4(fa, fb, c1); c0 = MFF(fa, fb, c0); c1 = MF4(fa, fb, c1);
+    }
+  } else if (role == 11) {     // the same 4 + 4, grouped: four 16x16x4 then four 4x4x1
+    for (int i = 0; i < n; ++i) {
+      c0 = MFF(fa, fb, c0); c0 = MFF(fa, fb, c0); c0 = MFF(fa, fb, c0); c0 = MFF(fa, fb, c0);
+      c1 = MF4(fa, fb, c1); c1 = MF4(fa, fb, c1); c1 = MF4(fa, fb, c1); c1 = MF4(fa, fb, c1);
+    }
+  } else if (role == 12) {     // 4x4x1 only, one chain (4 per iteration)
+    for (int i = 0; i < n; ++i) { c1 = MF4(fa, fb, c1); c1 = MF4(fa, fb, c1); c1 = MF4(fa, fb, c1); c1 = MF4(fa, fb, c1); }
+  } else if (role == 13) {     // 4x4x1 only, two chains alternating
+    for (int i = 0; i < n; ++i) { c1 = MF4(fa, fb, c1); c2 = MF4(fa, fb, c2); c1 = MF4(fa, fb, c1); c2 = MF4(fa, fb, c2); }
+  } else if (role == 14) {     // 16x16x4 with TWO 4x4x1 behind each (4 + 8)
+    for (int i = 0; i < n; ++i) {
+      c0 = MFF(fa, fb, c0); c1 = MF4(fa, fb, c1); c2 = MF4(fa, fb, c2); c0 = MFF(fa, fb, c0); c1 = MF4(fa, fb, c1); c2 = MF4(fa, fb, c2);
+      c0 = MFF(fa, fb, c0); c1 = MF4(fa, fb, c1); c2 = MF4(fa, fb, c2); c0 = MFF(fa, fb, c0); c1 = MF4(fa, fb, c1); c2 = MF4(fa, fb, c2);
+    }
+  } else if (role == 10) {     // two fp32 chains alternating
+    for (int i = 0; i < n; ++i) { c0 = MFF(fa, fb, c0); c1 = MFF(fa, fb, c1); c0 = MFF(fa, fb, c0); c1 = MFF(fa, fb, c1); }
   } else if (role == 1) {
     VALU_LOOP(VFMA)
   } else if (role == 3) {
@@ -116,6 +144,16 @@ int main() {
   run_two("waves 0..3 MFMA16x16x32 (4 accumulators)", 1, 0, 0);
   run_two("waves 0..3 MFMA16x16x32 (one dependent chain)", 1, 6, 6);
   run_two("waves 0..3 MFMA32x32x16 (2 accumulators)", 1, 2, 2);
+  run_two("waves 0..3 fp32 MFMA16x16x4 (4 accumulators)", 1, 7, 7);
+  run_two("waves 0..3 fp32 MFMA16x16x4 (one dependent chain)", 1, 8, 8);
+  run_two("waves 0..3 fp32 MFMA16x16x4 chain + 4x4x1 between (4 + 4 per iteration)", 1, 9, 9);
+  run_two("waves 0..3 fp32 MFMA16x16x4 two chains alternating", 1, 10, 10);
+  run_two("waves 0..3 fp32 four 16x16x4 then four 4x4x1 (grouped)", 1, 11, 11);
+  run_two("waves 0..3 fp32 4x4x1 one chain (4 per iteration)", 1, 12, 12);
+  run_two("waves 0..3 fp32 4x4x1 two chains alternating (4 per iteration)", 1, 13, 13);
+  run_two("waves 0..3 fp32 16x16x4 + two 4x4x1 behind each (4 + 8)", 1, 14, 14);
+  run_two("fp32 chain + fp32 chain (same SIMDs)", 3, 8, 8);
+  run_two("fp32 chain+4x4x1 + same (same SIMDs)", 3, 9, 9);
   run_two("waves 0..3 v_fma", 1, 1, 1);
   run_two("waves 0..3 v_cvt_pk_bf16_f32", 1, 3, 3);
   run_two("waves 0..3 v_and_b32", 1, 4, 4);
