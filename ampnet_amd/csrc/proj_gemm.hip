@@ -294,28 +294,28 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void proj_rows_kernel(RowsArgs a) 
     for (int j = 0; j < NTW; ++j)
 #pragma unroll
       for (int p = 0; p < 3; ++p) bf[j][p] = *reinterpret_cast<const i32x4 *>(bb + brd + j * kTile3 + p * kFrag);
-#ifdef AMPCONV_PROJ_PAIR_MAJOR
-    i32x4 af[MTW][3];
+    // accumulator rows in groups of G so that consecutive MFMAs are at least four accumulators apart (mfma6_row)
+    constexpr int G = NTW >= 4 ? 1 : (4 / NTW < MTW ? 4 / NTW : MTW);
+    static_assert(MTW % G == 0, "accumulator rows are taken in groups");
 #pragma unroll
-    for (int i = 0; i < MTW; ++i)
+    for (int i = 0; i < MTW; i += G) {
+      i32x4 af[G][3];
 #pragma unroll
-      for (int p = 0; p < 3; ++p) af[i][p] = *reinterpret_cast<const i32x4 *>(bb + ard + i * kTile3 + p * kFrag);
-    constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+      for (int ii = 0; ii < G; ++ii)
 #pragma unroll
-    for (int q = 0; q < 6; ++q)
+        for (int p = 0; p < 3; ++p) af[ii][p] = *reinterpret_cast<const i32x4 *>(bb + ard + (i + ii) * kTile3 + p * kFrag);
+      if constexpr (G == 1) {
+        mfma6_row<NTW>(af[0], bf, acc[i]);
+      } else {
+        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
-      for (int i = 0; i < MTW; ++i)
+        for (int q = 0; q < 6; ++q)
 #pragma unroll
-        for (int j = 0; j < NTW; ++j) acc[i][j] = MFMA32(af[i][PA[q]], bf[j][PB[q]], acc[i][j]);
-#else
+          for (int ii = 0; ii < G; ++ii)
 #pragma unroll
-    for (int i = 0; i < MTW; ++i) {
-      i32x4 af[3];
-#pragma unroll
-      for (int p = 0; p < 3; ++p) af[p] = *reinterpret_cast<const i32x4 *>(bb + ard + i * kTile3 + p * kFrag);
-      mfma6_row<NTW>(af, bf, acc[i]);
+            for (int j = 0; j < NTW; ++j) acc[i + ii][j] = MFMA32(af[ii][PA[q]], bf[j][PB[q]], acc[i + ii][j]);
+      }
     }
-#endif
   };
 
   PSTAMP_DECL
