@@ -186,10 +186,11 @@ class AMPConvFunction(torch.autograd.Function):
             dtype = _lib.AMPCONV_BF16
             if w_in.dtype != torch.bfloat16:
                 raise ValueError('bf16 inputs need bf16 parameters: call layer.to(torch.bfloat16)')
-            if dh not in (16, 32) or L > 20:
-                raise ValueError(f'bf16 storage is implemented for head dimensions 32 and 16 and at most 20 tokens per '
-                                 f'node (csrc/edge_mfma_bf16.hip; BASELINE configs 5 and 3); got head dimension {dh}, '
-                                 f'{L} tokens: use float32 for this shape')
+            if not ((dh in (16, 32) and L <= 20) or (dh % 2 == 0 and dh <= 64 and L <= 64)):
+                raise ValueError(f'bf16 storage is implemented for head dimensions 32 and 16 with at most 20 tokens per '
+                                 f'node (csrc/edge_mfma_bf16.hip; BASELINE configs 5 and 3) and for even head dimensions '
+                                 f'up to 64 with at most 64 tokens (csrc/edge_block.hip: fp32 arithmetic on bf16 rows); '
+                                 f'got head dimension {dh}, {L} tokens: use float32 for this shape')
         Nq, Nk = xq.size(0), xkv.size(0)
         xq2 = xq.contiguous().view(Nq * L, D)
         native = proj_native(gemm, xq.dtype, D)

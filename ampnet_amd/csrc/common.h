@@ -128,20 +128,21 @@ int ampconv_bwd_edge_src_mfma(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t
                               ampconv_view_t dK, ampconv_view_t dV, HubArgs hub, StatsArgs st,
                               hipStream_t stream);
 
-// ---- workgroup-per-unit MFMA path (edge_block.hip): L <= 64, even dh <= 64, 8-byte aligned views.
-// The source pass of this path exists only with the statistics of the destination pass.
-bool ampconv_block_supported(int L, int D, int H, const ampconv_view_t *views, int n);
+// ---- workgroup-per-unit MFMA path (edge_block.hip): L <= 64, even dh <= 64, views aligned to two elements; fp32 or
+// bf16 storage (`bf16`), fp32 arithmetic.  The source pass of this path exists only with the statistics of the
+// destination pass.
+bool ampconv_block_supported(int L, int D, int H, const ampconv_view_t *views, int n, bool bf16);
 int ampconv_block_stats_floats(int L);      // floats per (edge, head): 2 * 16 * ceil(L / 16)
 int ampconv_fwd_edge_block(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V, const int32_t *rowptr,
                            const int32_t *col, const int32_t *qidx, int64_t n_rows, int L, int D, int H,
-                           ampconv_view_t O, HubArgs hub, hipStream_t stream);
+                           ampconv_view_t O, HubArgs hub, bool bf16, hipStream_t stream);
 int ampconv_bwd_edge_dst_block(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V, ampconv_view_t dO,
                                const int32_t *rowptr, const int32_t *col, int64_t n_rows, int L, int D, int H,
-                               ampconv_view_t dQ, HubArgs hub, StatsArgs sa, hipStream_t stream);
+                               ampconv_view_t dQ, HubArgs hub, StatsArgs sa, bool bf16, hipStream_t stream);
 int ampconv_bwd_edge_src_block(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V, ampconv_view_t dO,
                                const int32_t *cscptr, const int32_t *crow, const float *cinv, int64_t n_src,
                                int L, int D, int H, ampconv_view_t dK, ampconv_view_t dV, HubArgs hub,
-                               const float *stats, hipStream_t stream);
+                               const float *stats, bool bf16, hipStream_t stream);
 
 // ---- split-operand bf16 MFMA path (edge_mfma_split.hip): L <= 20, dh == 32; nprod = 9 or 6
 bool ampconv_split_supported(int L, int D, int H);

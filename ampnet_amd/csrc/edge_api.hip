@@ -60,8 +60,8 @@ extern "C" int ampconv_fwd_edge(ampconv_view_t Q, ampconv_view_t K, ampconv_view
   if (n_rows == 0) return AMPCONV_OK;
   if (!view_ok(Q) || !view_ok(K) || !view_ok(V) || !view_ok(O) || !rowptr) return AMPCONV_E_BADARG;
   const ampconv_view_t views[] = {Q, K, V, O};
-  if (dtype == AMPCONV_BF16) {
-    if (!ampconv_bf16_supported(L, D, H, views, 4)) return AMPCONV_E_DTYPE;
+  const bool bf = dtype == AMPCONV_BF16;
+  if (bf && ampconv_bf16_supported(L, D, H, views, 4)) {
     hipStream_t st = (hipStream_t)stream;
     if (hub_plan && hub_chunks > 0 && hub_ws && !qidx) {
       if (int rc = ampconv_fwd_edge_bf16(Q, K, V, rowptr, col, nullptr, n_rows, L, D, H, O,
@@ -75,7 +75,9 @@ extern "C" int ampconv_fwd_edge(ampconv_view_t Q, ampconv_view_t K, ampconv_view
     }
     return ampconv_fwd_edge_bf16(Q, K, V, rowptr, col, qidx, n_rows, L, D, H, O, HubArgs{nullptr, 0}, st);
   }
-  if (!force_generic() && ampconv_mfma_supported(L, D, H) && ampconv_mfma_views_ok(views, 4)) {
+  // bf16 storage of the other shapes: the workgroup-per-unit kernels widen / round the rows themselves
+  if (bf && !ampconv_block_supported(L, D, H, views, 4, true)) return AMPCONV_E_DTYPE;
+  if (!bf && !force_generic() && ampconv_mfma_supported(L, D, H) && ampconv_mfma_views_ok(views, 4)) {
     // the split-operand kernels have no long-segment (hub) pass: with a plan the native fp32 kernels run
     // (exact fp32 as well) instead of one wave walking a hub's whole segment
     const bool hubs = hub_plan && hub_chunks > 0 && hub_ws && !qidx;
@@ -97,18 +99,18 @@ extern "C" int ampconv_fwd_edge(ampconv_view_t Q, ampconv_view_t K, ampconv_view
     return ampconv_fwd_edge_mfma(Q, K, V, rowptr, col, qidx, n_rows, L, D, H, O, HubArgs{nullptr, 0},
                                  (hipStream_t)stream);
   }
-  if (!force_generic() && ampconv_block_supported(L, D, H, views, 4)) {
+  if ((bf || !force_generic()) && ampconv_block_supported(L, D, H, views, 4, bf)) {
     hipStream_t st = (hipStream_t)stream;
     if (hub_plan && hub_chunks > 0 && hub_ws && !qidx) {      // long segments: main + hub + combine
-      if (int rc = ampconv_fwd_edge_block(Q, K, V, rowptr, col, nullptr, n_rows, L, D, H, O, hub_args(hub_plan, 1), st))
+      if (int rc = ampconv_fwd_edge_block(Q, K, V, rowptr, col, nullptr, n_rows, L, D, H, O, hub_args(hub_plan, 1), bf, st))
         return rc;
       ampconv_view_t P = partial_view(hub_ws, 0, hub_chunks, L, D, H);
       if (int rc = ampconv_fwd_edge_block(Q, K, V, rowptr, col, nullptr, hub_chunks, L, D, H, P,
-                                          hub_args(hub_plan, 2), st))
+                                          hub_args(hub_plan, 2), bf, st))
         return rc;
-      return ampconv_hub_combine(hub_plan, hub_chunks, (const float *)P.ptr, O, rowptr, L, D, H, 1.f, 0, st);
+      return ampconv_hub_combine(hub_plan, hub_chunks, (const float *)P.ptr, O, rowptr, L, D, H, 1.f, bf ? 1 : 0, st);
     }
-    return ampconv_fwd_edge_block(Q, K, V, rowptr, col, qidx, n_rows, L, D, H, O, HubArgs{nullptr, 0}, st);
+    return ampconv_fwd_edge_block(Q, K, V, rowptr, col, qidx, n_rows, L, D, H, O, HubArgs{nullptr, 0}, bf, st);
   }
   return ampconv_fwd_edge_generic(Q, K, V, rowptr, col, qidx, n_rows, L, D, H, O,
                                   (hipStream_t)stream);
@@ -117,10 +119,14 @@ extern "C" int ampconv_fwd_edge(ampconv_view_t Q, ampconv_view_t K, ampconv_view
 extern "C" size_t ampconv_softmax_stats_bytes(int64_t E, int L, int D, int H, int dtype) {
   // bf16 storage keeps none: there the passes are HBM-bound and the extra 2 x 160 B per edge and
   // head cost the destination pass what they save the source pass (measured: +0.54 / -0.53 ms)
-  if (E <= 0 || check_common(L, D, H, dtype) != AMPCONV_OK || dtype == AMPCONV_BF16 || force_generic()) return 0;
+  if (E <= 0 || check_common(L, D, H, dtype) != AMPCONV_OK) return 0;
+  if (dtype == AMPCONV_BF16)       // the bf16 MFMA kernels keep none; bf16 storage of the other shapes runs the
+    return ampconv_bf16_supported(L, D, H, nullptr, 0) || !ampconv_block_supported(L, D, H, nullptr, 0, true)
+               ? 0 : (size_t)E * H * ampconv_block_stats_floats(L) * sizeof(float);   // workgroup-per-unit kernels
+  if (force_generic()) return 0;
   if (ampconv_mfma_supported(L, D, H))
     return split_products(dtype, L, D, H) ? 0 : (size_t)E * H * kStatsPerUnit * sizeof(float);
-  if (ampconv_block_supported(L, D, H, nullptr, 0))     // shapes of the workgroup-per-unit kernels
+  if (ampconv_block_supported(L, D, H, nullptr, 0, false))     // shapes of the workgroup-per-unit kernels
     return (size_t)E * H * ampconv_block_stats_floats(L) * sizeof(float);
   return 0;
 }
@@ -139,8 +145,8 @@ extern "C" int ampconv_bwd_edge_dst(ampconv_view_t Q, ampconv_view_t K, ampconv_
   if (!view_ok(Q) || !view_ok(K) || !view_ok(V) || !view_ok(dObar) || !view_ok(dQ) || !rowptr)
     return AMPCONV_E_BADARG;
   const ampconv_view_t views[] = {Q, K, V, dObar, dQ};
-  if (dtype == AMPCONV_BF16) {
-    if (!ampconv_bf16_supported(L, D, H, views, 5)) return AMPCONV_E_DTYPE;
+  const bool bf = dtype == AMPCONV_BF16;
+  if (bf && ampconv_bf16_supported(L, D, H, views, 5)) {
     if (stats) return AMPCONV_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     if (hub_plan && hub_chunks > 0 && hub_ws) {
@@ -156,7 +162,8 @@ extern "C" int ampconv_bwd_edge_dst(ampconv_view_t Q, ampconv_view_t K, ampconv_
     }
     return ampconv_bwd_edge_dst_bf16(Q, K, V, dObar, rowptr, col, n_rows, L, D, H, dQ, HubArgs{nullptr, 0}, st);
   }
-  if (!force_generic() && ampconv_mfma_supported(L, D, H) && ampconv_mfma_views_ok(views, 5)) {
+  if (bf && !ampconv_block_supported(L, D, H, views, 5, true)) return AMPCONV_E_DTYPE;
+  if (!bf && !force_generic() && ampconv_mfma_supported(L, D, H) && ampconv_mfma_views_ok(views, 5)) {
     const bool hubs = hub_plan && hub_chunks > 0 && hub_ws;      // see ampconv_fwd_edge
     if (const int np = hubs ? 0 : split_products(dtype, L, D, H))
       return stats ? AMPCONV_E_BADARG : ampconv_bwd_edge_dst_split(np, Q, K, V, dObar, rowptr, col, n_rows, L, D, H, dQ,
@@ -177,21 +184,23 @@ extern "C" int ampconv_bwd_edge_dst(ampconv_view_t Q, ampconv_view_t K, ampconv_
                                      HubArgs{nullptr, 0}, sa, (hipStream_t)stream);
   }
   // (a statistics buffer sized for the edge_mfma layout must not reach these kernels)
-  if (!force_generic() && ampconv_block_supported(L, D, H, views, 5) && !(stats && ampconv_mfma_supported(L, D, H))) {
+  if ((bf || !force_generic()) && ampconv_block_supported(L, D, H, views, 5, bf) &&
+      !(stats && !bf && ampconv_mfma_supported(L, D, H))) {
     hipStream_t st = (hipStream_t)stream;
     if (hub_plan && hub_chunks > 0 && hub_ws) {
       if (int rc = ampconv_bwd_edge_dst_block(Q, K, V, dObar, rowptr, col, n_rows, L, D, H, dQ,
-                                              hub_args(hub_plan, 1), sa, st))
+                                              hub_args(hub_plan, 1), sa, bf, st))
         return rc;
       ampconv_view_t P = partial_view(hub_ws, 0, hub_chunks, L, D, H);
       if (int rc = ampconv_bwd_edge_dst_block(Q, K, V, dObar, rowptr, col, hub_chunks, L, D, H, P,
-                                              hub_args(hub_plan, 2), sa, st))
+                                              hub_args(hub_plan, 2), sa, bf, st))
         return rc;
       return ampconv_hub_combine(hub_plan, hub_chunks, (const float *)P.ptr, dQ, nullptr, L, D, H,
-                                 1.f / sqrtf((float)(D / H)), 0, st);
+                                 1.f / sqrtf((float)(D / H)), bf ? 1 : 0, st);
     }
-    return ampconv_bwd_edge_dst_block(Q, K, V, dObar, rowptr, col, n_rows, L, D, H, dQ, HubArgs{nullptr, 0}, sa, st);
+    return ampconv_bwd_edge_dst_block(Q, K, V, dObar, rowptr, col, n_rows, L, D, H, dQ, HubArgs{nullptr, 0}, sa, bf, st);
   }
+  if (bf) return AMPCONV_E_DTYPE;
   if (stats) return AMPCONV_E_BADARG;     // this shape's kernels keep no statistics (ampconv_softmax_stats_bytes = 0)
   return ampconv_bwd_edge_dst_generic(Q, K, V, dObar, rowptr, col, n_rows, L, D, H, dQ,
                                       (hipStream_t)stream);
@@ -212,8 +221,8 @@ extern "C" int ampconv_bwd_edge_src(ampconv_view_t Q, ampconv_view_t K, ampconv_
       !view_ok(dV) || !cscptr || !cinv)
     return AMPCONV_E_BADARG;
   const ampconv_view_t views[] = {Q, K, V, dObar, dK, dV};
-  if (dtype == AMPCONV_BF16) {
-    if (!ampconv_bf16_supported(L, D, H, views, 6)) return AMPCONV_E_DTYPE;
+  const bool bf = dtype == AMPCONV_BF16;
+  if (bf && ampconv_bf16_supported(L, D, H, views, 6)) {
     if (stats) return AMPCONV_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     if (hub_plan && hub_chunks > 0 && hub_ws) {
@@ -233,7 +242,8 @@ extern "C" int ampconv_bwd_edge_src(ampconv_view_t Q, ampconv_view_t K, ampconv_
     return ampconv_bwd_edge_src_bf16(Q, K, V, dObar, cscptr, crow, cinv, n_src, L, D, H, dK, dV,
                                      HubArgs{nullptr, 0}, st);
   }
-  if (!force_generic() && ampconv_mfma_supported(L, D, H) && ampconv_mfma_views_ok(views, 6)) {
+  if (bf && !(stats && ampconv_block_supported(L, D, H, views, 6, true))) return AMPCONV_E_DTYPE;
+  if (!bf && !force_generic() && ampconv_mfma_supported(L, D, H) && ampconv_mfma_views_ok(views, 6)) {
     const bool hubs = hub_plan && hub_chunks > 0 && hub_ws;      // see ampconv_fwd_edge
     if (const int np = hubs ? 0 : split_products(dtype, L, D, H))
       return stats ? AMPCONV_E_BADARG : ampconv_bwd_edge_src_split(np, Q, K, V, dObar, cscptr, crow, cinv, n_src, L, D, H,
@@ -258,25 +268,28 @@ extern "C" int ampconv_bwd_edge_src(ampconv_view_t Q, ampconv_view_t K, ampconv_
                                      HubArgs{nullptr, 0}, sa, (hipStream_t)stream);
   }
   // the workgroup-per-unit source pass exists only with the statistics; without them: generic kernels
-  if (stats && !force_generic() && ampconv_block_supported(L, D, H, views, 6) && !ampconv_mfma_supported(L, D, H)) {
+  if (stats && (bf || !force_generic()) && ampconv_block_supported(L, D, H, views, 6, bf) &&
+      (bf || !ampconv_mfma_supported(L, D, H))) {
     hipStream_t st = (hipStream_t)stream;
+    const int obf = bf ? 1 : 0;
     if (hub_plan && hub_chunks > 0 && hub_ws) {
       if (int rc = ampconv_bwd_edge_src_block(Q, K, V, dObar, cscptr, crow, cinv, n_src, L, D, H, dK, dV,
-                                              hub_args(hub_plan, 1), stats, st))
+                                              hub_args(hub_plan, 1), stats, bf, st))
         return rc;
       ampconv_view_t PK = partial_view(hub_ws, 0, hub_chunks, L, D, H);
       ampconv_view_t PV = partial_view(hub_ws, 1, hub_chunks, L, D, H);
       if (int rc = ampconv_bwd_edge_src_block(Q, K, V, dObar, cscptr, crow, cinv, hub_chunks, L, D, H, PK, PV,
-                                              hub_args(hub_plan, 2), stats, st))
+                                              hub_args(hub_plan, 2), stats, bf, st))
         return rc;
       if (int rc = ampconv_hub_combine(hub_plan, hub_chunks, (const float *)PK.ptr, dK, nullptr, L, D, H,
-                                       0.6931471805599453f, 0, st))
+                                       0.6931471805599453f, obf, st))
         return rc;
-      return ampconv_hub_combine(hub_plan, hub_chunks, (const float *)PV.ptr, dV, nullptr, L, D, H, 1.f, 0, st);
+      return ampconv_hub_combine(hub_plan, hub_chunks, (const float *)PV.ptr, dV, nullptr, L, D, H, 1.f, obf, st);
     }
     return ampconv_bwd_edge_src_block(Q, K, V, dObar, cscptr, crow, cinv, n_src, L, D, H, dK, dV,
-                                      HubArgs{nullptr, 0}, stats, st);
+                                      HubArgs{nullptr, 0}, stats, bf, st);
   }
+  if (bf) return AMPCONV_E_DTYPE;
   if (stats) return AMPCONV_E_BADARG;
   return ampconv_bwd_edge_src_generic(Q, K, V, dObar, cscptr, crow, cinv, n_src, L, D, H, dK,
                                       dV, (hipStream_t)stream);

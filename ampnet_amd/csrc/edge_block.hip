@@ -1,5 +1,7 @@
 // MFMA edge-phase kernels for the shapes edge_mfma.hip does not take: L <= 64 tokens, even
-// dh <= 64 (the reference's AMPGCN class defaults are L = 40, dh = 50: amp_gcn.py:23-26), fp32.
+// dh <= 64 (the reference's AMPGCN class defaults are L = 40, dh = 50: amp_gcn.py:23-26); fp32 arithmetic, fp32 or bf16
+// storage (`bf16`: tiles are widened on the way into registers and rounded to nearest-even on the way out; long-segment
+// partial tiles stay fp32).
 //
 // One WORKGROUP owns one (row, head) unit; its ntok = ceil(L / 16) wavefronts share the LDS
 // images of the per-edge tiles and each owns one 16-token tile of the unit's own ("fixed") side:
@@ -29,6 +31,50 @@ __device__ __forceinline__ int bidx(int j, int c) {
   return j * DHP + ((((c >> 2) ^ bswz<DHP>(j)) << 2) | (c & 3));
 }
 
+// ---- storage type: fp32 or bf16 rows behind the same views (strides in elements)
+struct Rows {              // base of one (node, head) tile
+  const void *p;
+  bool bf;
+};
+__device__ __forceinline__ Rows rows_of(const ampconv_view_t &v, int64_t n, int h, bool bf) {
+  const int64_t off = n * v.node_stride + (int64_t)h * v.head_stride;
+  return Rows{bf ? (const void *)(reinterpret_cast<const unsigned short *>(v.ptr) + off)
+                 : (const void *)(reinterpret_cast<const float *>(v.ptr) + off), bf};
+}
+__device__ __forceinline__ float bf_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float bf_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xFFFF0000u); }
+__device__ __forceinline__ float ld1(const Rows &r, int64_t off) {
+  return r.bf ? bf_lo(reinterpret_cast<const unsigned short *>(r.p)[off]) : reinterpret_cast<const float *>(r.p)[off];
+}
+template <int VEC>
+__device__ __forceinline__ void ldv(float (&out)[VEC], const Rows &r, int64_t off) {
+  if (r.bf) {
+    const unsigned short *q = reinterpret_cast<const unsigned short *>(r.p) + off;
+    if constexpr (VEC == 4) {
+      const uint2 u = *reinterpret_cast<const uint2 *>(q);
+      out[0] = bf_lo(u.x); out[1] = bf_hi(u.x); out[2] = bf_lo(u.y); out[3] = bf_hi(u.y);
+    } else {
+      const unsigned u = *reinterpret_cast<const unsigned *>(q);
+      out[0] = bf_lo(u); out[1] = bf_hi(u);
+    }
+  } else {
+    const float *q = reinterpret_cast<const float *>(r.p) + off;
+    if constexpr (VEC == 4) {
+      const float4 x = *reinterpret_cast<const float4 *>(q);
+      out[0] = x.x; out[1] = x.y; out[2] = x.z; out[3] = x.w;
+    } else {
+      const float2 x = *reinterpret_cast<const float2 *>(q);
+      out[0] = x.x; out[1] = x.y;
+    }
+  }
+}
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {     // v_cvt_pk_bf16_f32, round to nearest even
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  f32x2_t v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+
 // ROW operand of token tile t from an LDS image: op[kk] = tile[16 t + m][KK ks + kk]
 template <int DHP>
 __device__ __forceinline__ void b_rowop_lds(float (&op)[DHP / 4], const float *lds, int t, int lane) {
@@ -44,14 +90,14 @@ __device__ __forceinline__ void b_rowop_lds(float (&op)[DHP / 4], const float *l
 // ROW operand of token tile t straight from global memory (the unit's fixed side), scaled;
 // token rows >= L and channels >= dh read as zero
 template <int DHP>
-__device__ __forceinline__ void b_rowop_global(float (&op)[DHP / 4], const float *base, int64_t row_stride,
+__device__ __forceinline__ void b_rowop_global(float (&op)[DHP / 4], const Rows &base, int64_t row_stride,
                                                int t, float mul, int L, int dh, int lane) {
   constexpr int KK = DHP / 4;
   const int m = lane & 15, ks = lane >> 4, j = 16 * t + m;
 #pragma unroll
   for (int kk = 0; kk < KK; ++kk) {
     const int c = KK * ks + kk;
-    op[kk] = (j < L && c < dh) ? base[(int64_t)j * row_stride + c] * mul : 0.f;
+    op[kk] = (j < L && c < dh) ? ld1(base, (int64_t)j * row_stride + c) * mul : 0.f;
   }
 }
 
@@ -65,8 +111,8 @@ struct Stage {
 };
 
 template <int DHP, int VEC>
-__device__ __forceinline__ void stage_load(Stage<DHP, VEC> &s, const float *baseA, int64_t strideA,
-                                           const float *baseB, int64_t strideB, int L, int dh, int tid,
+__device__ __forceinline__ void stage_load(Stage<DHP, VEC> &s, const Rows &baseA, int64_t strideA,
+                                           const Rows &baseB, int64_t strideB, int L, int dh, int tid,
                                            int nthreads) {
   using S = Stage<DHP, VEC>;
   const int cv = tid % S::DVP, r0 = tid / S::DVP, RS = nthreads / S::DVP, c = cv * VEC;
@@ -74,16 +120,8 @@ __device__ __forceinline__ void stage_load(Stage<DHP, VEC> &s, const float *base
   for (int i = 0; i < S::NP; ++i) {
     const int j = r0 + i * RS;
     if (j < L && c < dh) {
-      const float *pa = baseA + (int64_t)j * strideA + c, *pb = baseB + (int64_t)j * strideB + c;
-      if constexpr (VEC == 4) {
-        const float4 x = *reinterpret_cast<const float4 *>(pa), y = *reinterpret_cast<const float4 *>(pb);
-        s.v[0][i][0] = x.x; s.v[0][i][1] = x.y; s.v[0][i][2] = x.z; s.v[0][i][3] = x.w;
-        s.v[1][i][0] = y.x; s.v[1][i][1] = y.y; s.v[1][i][2] = y.z; s.v[1][i][3] = y.w;
-      } else {
-        const float2 x = *reinterpret_cast<const float2 *>(pa), y = *reinterpret_cast<const float2 *>(pb);
-        s.v[0][i][0] = x.x; s.v[0][i][1] = x.y;
-        s.v[1][i][0] = y.x; s.v[1][i][1] = y.y;
-      }
+      ldv<VEC>(s.v[0][i], baseA, (int64_t)j * strideA + c);
+      ldv<VEC>(s.v[1][i], baseB, (int64_t)j * strideB + c);
     }
   }
 }
@@ -111,23 +149,33 @@ __device__ __forceinline__ void stage_store(float *ldsA, float *ldsB, const Stag
   }
 }
 
-// C/D tile [channel tile mc][this wave's token tile] -> global rows of `v` (channels < dh, tokens < L)
+// C/D tile [channel tile mc][this wave's token tile] -> global rows of `v` (channels < dh, tokens < L); `bf`: bf16 rows
 template <int DHP, int VEC>
 __device__ __forceinline__ void store_ct(const ampconv_view_t &v, int64_t node, int h, const f32x4 (&T)[DHP / 16],
-                                         float scale, int tile, int L, int dh, int lane) {
+                                         float scale, int tile, int L, int dh, int lane, bool bf) {
   const int i = (lane & 15) + 16 * tile, g = lane >> 4;
   if (i >= L) return;
-  float *ob = tile_ptr<float>(v, node, h) + (int64_t)i * v.row_stride;
+  const int64_t row = node * v.node_stride + (int64_t)h * v.head_stride + (int64_t)i * v.row_stride;
 #pragma unroll
   for (int mc = 0; mc < DHP / 16; ++mc) {
     const int c = 4 * g + 16 * mc;
-    if constexpr (VEC == 4) {
-      if (c < dh)
-        *reinterpret_cast<float4 *>(ob + c) = make_float4(T[mc][0] * scale, T[mc][1] * scale, T[mc][2] * scale,
-                                                          T[mc][3] * scale);
+    const float x0 = T[mc][0] * scale, x1 = T[mc][1] * scale, x2 = T[mc][2] * scale, x3 = T[mc][3] * scale;
+    if (bf) {
+      unsigned short *ob = reinterpret_cast<unsigned short *>(v.ptr) + row + c;
+      if constexpr (VEC == 4) {
+        if (c < dh) *reinterpret_cast<uint2 *>(ob) = uint2{pk_bf16(x0, x1), pk_bf16(x2, x3)};
+      } else {
+        if (c < dh) *reinterpret_cast<unsigned *>(ob) = pk_bf16(x0, x1);
+        if (c + 2 < dh) *reinterpret_cast<unsigned *>(ob + 2) = pk_bf16(x2, x3);
+      }
     } else {
-      if (c < dh) *reinterpret_cast<float2 *>(ob + c) = make_float2(T[mc][0] * scale, T[mc][1] * scale);
-      if (c + 2 < dh) *reinterpret_cast<float2 *>(ob + c + 2) = make_float2(T[mc][2] * scale, T[mc][3] * scale);
+      float *ob = reinterpret_cast<float *>(v.ptr) + row + c;
+      if constexpr (VEC == 4) {
+        if (c < dh) *reinterpret_cast<float4 *>(ob) = make_float4(x0, x1, x2, x3);
+      } else {
+        if (c < dh) *reinterpret_cast<float2 *>(ob) = make_float2(x0, x1);
+        if (c + 2 < dh) *reinterpret_cast<float2 *>(ob + 2) = make_float2(x2, x3);
+      }
     }
   }
 }
@@ -141,6 +189,7 @@ struct BArgs {
   HubArgs hub;              // long-segment plan (hub.hip): mode 1 skips long rows, mode 2 = one unit per chunk
   int64_t n_units;
   int L, dh, H, ntok;
+  int bf16;                 // storage of Q / K / V / dO and of the outputs of the main pass (partial tiles: fp32)
   float qscale, oscale;
 };
 
@@ -190,11 +239,12 @@ __global__ __launch_bounds__(256) void fwd_block(BArgs a) {
   int h, beg, end, deg;
   if (!map_unit(a.hub, a.ptr, blockIdx.x, a.n_units, a.H, r, onode, h, beg, end, deg)) return;    // block-uniform
   const int L = a.L, dh = a.dh, ntok = a.ntok, g = lane >> 4;
+  const bool bf = a.bf16 != 0;
   float *Kt = lds, *Vt = lds + 16 * ntok * DHP;
   const int64_t d = a.qidx ? a.qidx[r] : r;
 
   float qB[KK];
-  b_rowop_global<DHP>(qB, tile_ptr<const float>(a.Q, d, h), a.Q.row_stride, wave, a.qscale, L, dh, lane);
+  b_rowop_global<DHP>(qB, rows_of(a.Q, d, h, bf), a.Q.row_stride, wave, a.qscale, L, dh, lane);
   for (int i = tid; i < 2 * 16 * ntok * DHP; i += nthreads) lds[i] = 0.f;     // padding stays zero
   f32x4 OT[MC];
 #pragma unroll
@@ -204,8 +254,8 @@ __global__ __launch_bounds__(256) void fwd_block(BArgs a) {
   IdxWindow win;
   auto fetch = [&](int p) {
     const int64_t s = idxwin_get<false>(win, a.idx, nullptr, p, end, lane, nullptr);
-    stage_load<DHP, VEC>(st, tile_ptr<const float>(a.K, s, h), a.K.row_stride,
-                         tile_ptr<const float>(a.V, s, h), a.V.row_stride, L, dh, tid, nthreads);
+    stage_load<DHP, VEC>(st, rows_of(a.K, s, h, bf), a.K.row_stride,
+                         rows_of(a.V, s, h, bf), a.V.row_stride, L, dh, tid, nthreads);
   };
   if (beg < end) {
     idxwin_load<false>(win, a.idx, nullptr, beg, end, lane);
@@ -244,7 +294,7 @@ __global__ __launch_bounds__(256) void fwd_block(BArgs a) {
   }
   // hub pass: unnormalised partial tile, the combine pass applies 1/deg
   store_ct<DHP, VEC>(a.O, onode, h, OT, a.hub.mode == 2 ? 1.f : (deg > 0 ? 1.f / (float)deg : 0.f), wave, L, dh,
-                     lane);
+                     lane, bf && a.hub.mode != 2);
 }
 
 // ---------------------------------------------------------------- backward, destination pass
@@ -258,12 +308,13 @@ __global__ __launch_bounds__(256) void bwd_dst_block(BArgs a) {
   int h, beg, end, deg;
   if (!map_unit(a.hub, a.ptr, blockIdx.x, a.n_units, a.H, r, onode, h, beg, end, deg)) return;
   const int L = a.L, dh = a.dh, ntok = a.ntok, g = lane >> 4;
+  const bool bf = a.bf16 != 0;
   float *Kt = lds, *Vt = lds + 16 * ntok * DHP;
   const float inv = deg > 0 ? 1.f / (float)deg : 0.f;       // dO is the gradient of the MEAN
 
   float qB[KK], gB[KK];
-  b_rowop_global<DHP>(qB, tile_ptr<const float>(a.Q, r, h), a.Q.row_stride, wave, a.qscale, L, dh, lane);
-  b_rowop_global<DHP>(gB, tile_ptr<const float>(a.dO, r, h), a.dO.row_stride, wave, inv, L, dh, lane);
+  b_rowop_global<DHP>(qB, rows_of(a.Q, r, h, bf), a.Q.row_stride, wave, a.qscale, L, dh, lane);
+  b_rowop_global<DHP>(gB, rows_of(a.dO, r, h, bf), a.dO.row_stride, wave, inv, L, dh, lane);
   for (int i = tid; i < 2 * 16 * ntok * DHP; i += nthreads) lds[i] = 0.f;
   f32x4 dQT[MC];
 #pragma unroll
@@ -275,8 +326,8 @@ __global__ __launch_bounds__(256) void bwd_dst_block(BArgs a) {
   const float *wts = reinterpret_cast<const float *>(a.spos);
   auto fetch = [&](int p) {
     const int64_t s = idxwin_get<STATS>(win, a.idx, wts, p, end, lane, &pos_next);
-    stage_load<DHP, VEC>(st, tile_ptr<const float>(a.K, s, h), a.K.row_stride,
-                         tile_ptr<const float>(a.V, s, h), a.V.row_stride, L, dh, tid, nthreads);
+    stage_load<DHP, VEC>(st, rows_of(a.K, s, h, bf), a.K.row_stride,
+                         rows_of(a.V, s, h, bf), a.V.row_stride, L, dh, tid, nthreads);
   };
   if (beg < end) {
     idxwin_load<STATS>(win, a.idx, wts, beg, end, lane);
@@ -333,7 +384,7 @@ __global__ __launch_bounds__(256) void bwd_dst_block(BArgs a) {
       }
     __syncthreads();
   }
-  store_ct<DHP, VEC>(a.O, onode, h, dQT, a.hub.mode == 2 ? 1.f : a.oscale, wave, L, dh, lane);
+  store_ct<DHP, VEC>(a.O, onode, h, dQT, a.hub.mode == 2 ? 1.f : a.oscale, wave, L, dh, lane, bf && a.hub.mode != 2);
 }
 
 // ---------------------------------------------------------------- backward, source pass (needs the statistics)
@@ -347,11 +398,12 @@ __global__ __launch_bounds__(256) void bwd_src_block(BArgs a) {
   int h, beg, end, deg;
   if (!map_unit(a.hub, a.ptr, blockIdx.x, a.n_units, a.H, s, onode, h, beg, end, deg)) return;
   const int L = a.L, dh = a.dh, ntok = a.ntok, g = lane >> 4, n = lane & 15;
+  const bool bf = a.bf16 != 0;
   float *Qt = lds, *Gt = lds + 16 * ntok * DHP;
 
   float kB[KK], vB[KK];
-  b_rowop_global<DHP>(kB, tile_ptr<const float>(a.K, s, h), a.K.row_stride, wave, 1.f, L, dh, lane);
-  b_rowop_global<DHP>(vB, tile_ptr<const float>(a.V, s, h), a.V.row_stride, wave, 1.f, L, dh, lane);
+  b_rowop_global<DHP>(kB, rows_of(a.K, s, h, bf), a.K.row_stride, wave, 1.f, L, dh, lane);
+  b_rowop_global<DHP>(vB, rows_of(a.V, s, h, bf), a.V.row_stride, wave, 1.f, L, dh, lane);
   for (int i = tid; i < 2 * 16 * ntok * DHP; i += nthreads) lds[i] = 0.f;
   f32x4 dKT[MC], dVT[MC];
 #pragma unroll
@@ -362,8 +414,8 @@ __global__ __launch_bounds__(256) void bwd_src_block(BArgs a) {
   float inv_next = 0.f;
   auto fetch = [&](int p) {
     const int64_t d = idxwin_get<true>(win, a.idx, a.cinv, p, end, lane, &inv_next);
-    stage_load<DHP, VEC>(st, tile_ptr<const float>(a.Q, d, h), a.Q.row_stride,
-                         tile_ptr<const float>(a.dO, d, h), a.dO.row_stride, L, dh, tid, nthreads);
+    stage_load<DHP, VEC>(st, rows_of(a.Q, d, h, bf), a.Q.row_stride,
+                         rows_of(a.dO, d, h, bf), a.dO.row_stride, L, dh, tid, nthreads);
   };
   if (beg < end) {
     idxwin_load<true>(win, a.idx, a.cinv, beg, end, lane);
@@ -408,15 +460,15 @@ __global__ __launch_bounds__(256) void bwd_src_block(BArgs a) {
       }
     __syncthreads();
   }
-  store_ct<DHP, VEC>(a.dK, onode, h, dKT, a.hub.mode == 2 ? 1.f : a.oscale, wave, L, dh, lane);
-  store_ct<DHP, VEC>(a.dV, onode, h, dVT, 1.f, wave, L, dh, lane);
+  store_ct<DHP, VEC>(a.dK, onode, h, dKT, a.hub.mode == 2 ? 1.f : a.oscale, wave, L, dh, lane, bf && a.hub.mode != 2);
+  store_ct<DHP, VEC>(a.dV, onode, h, dVT, 1.f, wave, L, dh, lane, bf && a.hub.mode != 2);
 }
 
-inline int vec_of(const ampconv_view_t *views, int n, int dh) {
+inline int vec_of(const ampconv_view_t *views, int n, int dh, int esize) {
   int vec = dh % 4 == 0 ? 4 : 2;
   for (int i = 0; i < n; ++i) {
     const ampconv_view_t &v = views[i];
-    while (vec > 1 && (((uintptr_t)v.ptr % (4 * vec)) || v.node_stride % vec || v.row_stride % vec ||
+    while (vec > 1 && (((uintptr_t)v.ptr % (esize * vec)) || v.node_stride % vec || v.row_stride % vec ||
                        v.head_stride % vec))
       vec >>= 1;
   }
@@ -436,9 +488,10 @@ int launch_block(const BArgs &a, int dhp, int vec, K4 k64v4, K2 k64v2, K4 k32v4,
   return ampconv_launch_status();
 }
 
-BArgs base_args(int64_t n_rows, int L, int D, int H) {
+BArgs base_args(int64_t n_rows, int L, int D, int H, bool bf16) {
   BArgs a{};
   a.L = L; a.dh = D / H; a.H = H; a.ntok = (L + 15) / 16;
+  a.bf16 = bf16;
   a.n_units = n_rows * H;
   a.qscale = kLog2eB / sqrtf((float)a.dh);
   return a;
@@ -446,36 +499,36 @@ BArgs base_args(int64_t n_rows, int L, int D, int H) {
 
 }  // namespace
 
-bool ampconv_block_supported(int L, int D, int H, const ampconv_view_t *views, int n) {
+bool ampconv_block_supported(int L, int D, int H, const ampconv_view_t *views, int n, bool bf16) {
   const int dh = D / H;
   if (!(L >= 1 && L <= 16 * kMaxTok && dh >= 2 && dh <= 64 && dh % 2 == 0)) return false;
-  return vec_of(views, n, dh) >= 2;
+  return vec_of(views, n, dh, bf16 ? 2 : 4) >= 2;
 }
 
 int ampconv_block_stats_floats(int L) { return 2 * 16 * ((L + 15) / 16); }
 
 int ampconv_fwd_edge_block(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V, const int32_t *rowptr,
                            const int32_t *col, const int32_t *qidx, int64_t n_rows, int L, int D, int H,
-                           ampconv_view_t O, HubArgs hub, hipStream_t stream) {
-  BArgs a = base_args(n_rows, L, D, H);
+                           ampconv_view_t O, HubArgs hub, bool bf16, hipStream_t stream) {
+  BArgs a = base_args(n_rows, L, D, H, bf16);
   a.hub = hub;
   a.Q = Q; a.K = K; a.V = V; a.O = O;
   a.ptr = rowptr; a.idx = col; a.qidx = qidx;
   const ampconv_view_t views[] = {Q, K, V, O};
-  const int vec = vec_of(views, 4, a.dh), dhp = a.dh > 32 ? 64 : 32;
+  const int vec = vec_of(views, 4, a.dh, bf16 ? 2 : 4), dhp = a.dh > 32 ? 64 : 32;
   return launch_block(a, dhp, vec, fwd_block<64, 4>, fwd_block<64, 2>, fwd_block<32, 4>, fwd_block<32, 2>, stream);
 }
 
 int ampconv_bwd_edge_dst_block(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V, ampconv_view_t dO,
                                const int32_t *rowptr, const int32_t *col, int64_t n_rows, int L, int D, int H,
-                               ampconv_view_t dQ, HubArgs hub, StatsArgs sa, hipStream_t stream) {
-  BArgs a = base_args(n_rows, L, D, H);
+                               ampconv_view_t dQ, HubArgs hub, StatsArgs sa, bool bf16, hipStream_t stream) {
+  BArgs a = base_args(n_rows, L, D, H, bf16);
   a.hub = hub;
   a.Q = Q; a.K = K; a.V = V; a.dO = dO; a.O = dQ;
   a.ptr = rowptr; a.idx = col; a.spos = sa.spos; a.stats = sa.stats;
   a.oscale = 1.f / sqrtf((float)a.dh);
   const ampconv_view_t views[] = {Q, K, V, dO, dQ};
-  const int vec = vec_of(views, 5, a.dh), dhp = a.dh > 32 ? 64 : 32;
+  const int vec = vec_of(views, 5, a.dh, bf16 ? 2 : 4), dhp = a.dh > 32 ? 64 : 32;
   if (sa.stats)
     return launch_block(a, dhp, vec, bwd_dst_block<64, 4, true>, bwd_dst_block<64, 2, true>,
                         bwd_dst_block<32, 4, true>, bwd_dst_block<32, 2, true>, stream);
@@ -486,15 +539,15 @@ int ampconv_bwd_edge_dst_block(ampconv_view_t Q, ampconv_view_t K, ampconv_view_
 int ampconv_bwd_edge_src_block(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V, ampconv_view_t dO,
                                const int32_t *cscptr, const int32_t *crow, const float *cinv, int64_t n_src,
                                int L, int D, int H, ampconv_view_t dK, ampconv_view_t dV, HubArgs hub,
-                               const float *stats, hipStream_t stream) {
+                               const float *stats, bool bf16, hipStream_t stream) {
   if (!stats) return AMPCONV_E_BADARG;
-  BArgs a = base_args(n_src, L, D, H);
+  BArgs a = base_args(n_src, L, D, H, bf16);
   a.hub = hub;
   a.Q = Q; a.K = K; a.V = V; a.dO = dO; a.dK = dK; a.dV = dV;
   a.ptr = cscptr; a.idx = crow; a.cinv = cinv; a.stats = const_cast<float *>(stats);
   a.oscale = 0.6931471805599453f;       // dK = ln2 * sum dS^T (Q * log2e / sqrt(dh))
   const ampconv_view_t views[] = {Q, K, V, dO, dK, dV};
-  const int vec = vec_of(views, 6, a.dh), dhp = a.dh > 32 ? 64 : 32;
+  const int vec = vec_of(views, 6, a.dh, bf16 ? 2 : 4), dhp = a.dh > 32 ? 64 : 32;
   return launch_block(a, dhp, vec, bwd_src_block<64, 4>, bwd_src_block<64, 2>, bwd_src_block<32, 4>,
                       bwd_src_block<32, 2>, stream);
 }

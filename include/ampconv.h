@@ -40,9 +40,11 @@ enum {
   AMPCONV_E_WORKSPACE = -3 /* workspace too small */
 };
 
-/* dtype codes.  AMPCONV_BF16: every view is bf16 in HBM (Q/K/V/O and gradients), products on the
- * bf16 MFMA with fp32 accumulation, fp32 softmax (L <= 20; dh = 32 -- BASELINE config 5 -- or
- * dh = 16 as half-filled tiles).
+/* dtype codes.  AMPCONV_BF16: every view is bf16 in HBM (Q/K/V/O and gradients), fp32 softmax and accumulation.
+ * L <= 20 with dh = 32 (BASELINE config 5) or dh = 16 (half-filled tiles): products on the bf16 MFMA, no softmax
+ * statistics.  Other even dh <= 64 with L <= 64 (e.g. the reference's class default L = 40, dh = 50): the fp32
+ * workgroup-per-unit kernels read / write the bf16 rows themselves (fp32 MFMA arithmetic); their source pass needs
+ * the statistics buffer of ampconv_softmax_stats_bytes like the fp32 call.  Anything else: AMPCONV_E_DTYPE.
  * All AMPCONV_F32* codes take and return fp32 tensors; they differ in how the
  * per-edge products are evaluated on the matrix cores:
  *   AMPCONV_F32_EXACT   v_mfma_f32_16x16x4_f32 (native fp32 MFMA, 1/16 of the bf16 rate)

@@ -434,11 +434,13 @@ def test_data_parallel_step_two_ranks(dev, tmp_path):
 
 
 @pytest.mark.parametrize('shape', [(1200, 12000, 20, 256, 8), (700, 5000, 13, 64, 2), (900, 9000, 20, 128, 8),
-                                   (500, 4000, 7, 48, 3)],
-                         ids=['L20_D256', 'L13_D64', 'L20_D128_dh16', 'L7_D48_dh16'])
+                                   (500, 4000, 7, 48, 3), (300, 2500, 40, 100, 2), (260, 2000, 33, 24, 2)],
+                         ids=['L20_D256', 'L13_D64', 'L20_D128_dh16', 'L7_D48_dh16', 'L40_D100_dh50_block',
+                              'L33_D24_dh12_block'])
 def test_bf16_storage(shape, dev):
     """bf16-storage mode (BASELINE config 5: Q/K/V/O and gradients in bf16, fp32 accumulate; head width 32, and
-    16 -- BASELINE config 3's -- as half-filled tiles)
+    16 -- BASELINE config 3's -- as half-filled tiles; the reference's class default L=40, D=100, H=2 and other even
+    head widths on the workgroup-per-unit kernels, which widen / round the rows themselves)
     against the fp64 oracle evaluated on the same bf16-rounded inputs and parameters.
     Tolerance: rtol 2e-2, atol 2e-2 of the tensor's scale."""
     from ampnet_amd import AMPConv
@@ -479,8 +481,8 @@ def test_bf16_storage(shape, dev):
 
 def test_bf16_storage_rejects_other_head_widths(dev):
     from ampnet_amd import AMPConv
-    layer = AMPConv(100, 2).to(dev).to(torch.bfloat16)                  # dh = 50: fp32 only (edge_block.hip)
-    x = torch.randn(10, 4 * 100, device=dev).to(torch.bfloat16)
+    layer = AMPConv(66, 2).to(dev).to(torch.bfloat16)                   # dh = 33: odd, fp32 only (edge_generic.hip)
+    x = torch.randn(10, 4 * 66, device=dev).to(torch.bfloat16)
     ei = torch.randint(0, 10, (2, 30), device=dev)
     with pytest.raises(ValueError, match='head dimensions 32 and 16'):
         layer(x, ei)
