@@ -558,16 +558,7 @@ def measure_full(workload, steps, warmup, args, rank, world, dev, dist_on, dt_na
                         'floor_ms': {'hbm_at_8TBps': 1e3 * t_hbm, 'mfma_at_peak': 1e3 * t_mfma},
                         'binding': 'mfma' if t_mfma > t_hbm else 'hbm'},
         'node_phase_ms': 1e3 * t_step - edge_ms,             # projections + glue + CSR build (+ all-reduce)
-        # the node phase against ITS roofline (the matrix pipe): 24 L D^2 per node of fp32-equivalent FLOPs;
-        # the native fp32 projections issue six bf16 MFMA products per fp32 product, the bf16-storage ones one
-        'node_phase_mfma': (lambda t_node, issue: {
-            'bound': 'mfma', 'flops_fp32_equivalent': flops_proj, 'bf16_products_per_fp32_product': issue,
-            'achieved_TFLOPs_fp32_equivalent': flops_proj / t_node / 1e12,
-            'achieved_TFLOPs_bf16_issued': issue * flops_proj / t_node / 1e12, 'peak_TFLOPs': MFMA_PEAK_TFLOPS['bf16'],
-            'frac': issue * flops_proj / t_node / 1e12 / MFMA_PEAK_TFLOPS['bf16'],
-            'note': 'upper bound of the time (node_phase_ms also holds the CSR build and glue); DESIGN.md 4a: power-limited'}
-        )(t_step - edge_ms * 1e-3, 6 if (dt_name == 'f32' and args.gemm == 'native') else 1)
-        if (dt_name == 'bf16' or args.gemm == 'native') and t_step > edge_ms * 1e-3 else None,
+        'node_phase_mfma': _node_phase_mfma(flops_proj, t_step - edge_ms * 1e-3, dt_name, args.gemm),
         'kernels_ms': ms, 'per_rank_ms': _per_rank(by_rank, dist_on),
         'allreduce_ms': ar_ms,
         'timing': 'value = wall clock over the K steps between barrier+synchronize fences, max over ranks '
@@ -587,6 +578,21 @@ def measure_full(workload, steps, warmup, args, rank, world, dev, dist_on, dt_na
     if alt_out is not None:
         out['alt_gemm'] = alt_out
     return out
+
+
+def _node_phase_mfma(flops_proj, t_node, dt_name, gemm):
+    """The node phase against ITS roofline (SURVEY.md 8d: the matrix pipe).  24 L D^2 per node of fp32-equivalent FLOPs;
+    the native fp32 projections issue six bf16 MFMA products per fp32 product, the bf16-storage ones one.  None for the
+    library fp32 GEMMs (they run on the fp32 pipe: `layer_flops`)."""
+    if t_node <= 0 or not (dt_name == 'bf16' or gemm == 'native'):
+        return None
+    issue = 6 if dt_name == 'f32' else 1
+    peak = MFMA_PEAK_TFLOPS['bf16']
+    return {'bound': 'mfma', 'flops_fp32_equivalent': flops_proj, 'bf16_products_per_fp32_product': issue,
+            'achieved_TFLOPs_fp32_equivalent': flops_proj / t_node / 1e12,
+            'achieved_TFLOPs_bf16_issued': issue * flops_proj / t_node / 1e12, 'peak_TFLOPs': peak,
+            'frac': issue * flops_proj / t_node / 1e12 / peak,
+            'note': 'lower bound of the rate: node_phase_ms also holds the CSR build and glue; DESIGN.md 4a: power-limited'}
 
 
 def _brief(m):
