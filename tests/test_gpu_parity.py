@@ -877,6 +877,52 @@ def test_split_precision_on_hub_graph_uses_hub_plan(dev):
         assert_close_scaled(b.cpu().numpy(), a.cpu().numpy(), name + ' (bf16x9 with hubs vs exact)')
 
 
+@pytest.mark.parametrize('dtype', ['f32', 'bf16'])
+def test_rmat_graph_with_id_structured_degrees(dtype, dev):
+    """BASELINE config 5's generator at test size (R-MAT, no label permutation: a node's degree follows the bits of its
+    id, long segments on both sides, isolated nodes, a row count that is NOT a power of two): the main launch walks the
+    rows in the scrambled order of common.h, the long segments go through the chunk plan -- against the fp64 oracle."""
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    import bench
+    from ampnet_amd import AMPConv
+    from oracle.ampconv_numpy import AMPConvOracle
+    N, E, L, D, H = 3000, 36000, 20, 64, 2
+    g = torch.Generator().manual_seed(77)
+    ei = bench.rmat_edges(12, E, g, 'cpu')                      # ids in [0, 4096) ...
+    ei = ei[:, (ei < N).all(dim=0)]                             # ... cut to N = 3000 rows
+    E = ei.size(1)
+    deg_in, deg_out = torch.bincount(ei[1], minlength=N), torch.bincount(ei[0], minlength=N)
+    assert deg_in.max() > 64 and deg_out.max() > 64 and (deg_in == 0).sum() > 50      # hubs and empty rows exist
+    torch.manual_seed(78)
+    layer = AMPConv(D, H)
+    with torch.no_grad():
+        layer.multi_head_attention.in_proj_bias.normal_(0, 0.1)
+        layer.multi_head_attention.out_proj.bias.normal_(0, 0.1)
+    tdt = torch.bfloat16 if dtype == 'bf16' else torch.float32
+    layer = layer.to(dev).to(tdt)
+    x = torch.randn(N, L * D, generator=g).to(tdt)
+    dy = torch.randn(N, L * D, generator=g).to(tdt)
+    xg = x.to(dev).requires_grad_(True)
+    y = layer(xg, ei.to(dev))
+    y.backward(dy.to(dev))
+    m = layer.multi_head_attention
+    f64 = lambda t: t.detach().float().cpu().numpy().astype(np.float64)
+    o = AMPConvOracle(f64(m.in_proj_weight), f64(m.in_proj_bias), f64(m.out_proj.weight), f64(m.out_proj.bias),
+                      H, dtype=np.float64, edge_chunk=2048)
+    y_ref, _ = o.forward(f64(x), ei.numpy(), need_weights=False)
+    dx_ref, dWin, dbin, dWo, dbo = o.backward(f64(dy))
+    tol = dict(atol=2e-2, rtol=2e-2) if dtype == 'bf16' else {}
+    assert_close_scaled(f64(y), y_ref, 'y', **tol)
+    assert (f64(y)[deg_in.numpy() == 0] == 0).all()
+    assert_close_scaled(f64(xg.grad), dx_ref, 'dx', **tol)
+    assert_close_scaled(f64(m.in_proj_weight.grad), dWin, 'g_in_proj_weight', **tol)
+    assert_close_scaled(f64(m.in_proj_bias.grad), dbin, 'g_in_proj_bias', **tol)
+    assert_close_scaled(f64(m.out_proj.weight.grad), dWo, 'g_out_proj_weight', **tol)
+    assert_close_scaled(f64(m.out_proj.bias.grad), dbo, 'g_out_proj_bias', **tol)
+
+
 def test_bench_rccl_path_single_rank(dev):
     """The N-rank run's RCCL code path (nccl process group with device_id, parameter broadcast, gradient all-reduce,
     barriers, MAX reduction of the time) executed by ONE rank on the one GPU of the test box -- two ranks cannot share
