@@ -108,3 +108,28 @@ def test_abi_version_mismatch_fails_loudly(built, monkeypatch):
     monkeypatch.setattr(_lib, 'EXPECTED_ABI', _lib.EXPECTED_ABI + 1)
     with pytest.raises(_lib.AmpconvError, match='ABI version'):
         _lib.load()
+
+
+def test_long_segment_chunk_follows_the_graph_size(monkeypatch):
+    """64 edges per chunk on small graphs (a chunk is one wave's serial walk), 128 from a million edges up
+    (DESIGN.md section 5); AMPCONV_HUB_CHUNK pins it."""
+    from ampnet_amd import _lib
+    monkeypatch.setattr(_lib, 'HUB_CHUNK', 0)
+    assert _lib.hub_chunk(10_556) == 64 and _lib.hub_chunk((1 << 20) - 1) == 64
+    assert _lib.hub_chunk(1 << 20) == 128 and _lib.hub_chunk(40_000_000) == 128
+    monkeypatch.setattr(_lib, 'HUB_CHUNK', 256)
+    assert _lib.hub_chunk(100) == 256 and _lib.hub_chunk(40_000_000) == 256
+
+
+def test_bench_node_phase_roofline_object():
+    """`node_phase_mfma` of the bench line: six bf16 products per fp32 product for the native fp32 projections, one for
+    bf16 storage, none for the library fp32 GEMMs (they run on the fp32 pipe)."""
+    import bench
+    flops = 24 * 20 * 256 * 256 * 1_000_000
+    o = bench._node_phase_mfma(flops, 0.1725, 'f32', 'native')
+    assert o['bound'] == 'mfma' and o['bf16_products_per_fp32_product'] == 6 and o['peak_TFLOPs'] == 2500.0
+    assert abs(o['achieved_TFLOPs_bf16_issued'] - 6 * flops / 0.1725 / 1e12) < 1e-6
+    assert abs(o['frac'] - o['achieved_TFLOPs_bf16_issued'] / 2500.0) < 1e-12
+    assert bench._node_phase_mfma(flops, 0.12, 'bf16', 'native')['bf16_products_per_fp32_product'] == 1
+    assert bench._node_phase_mfma(flops, 0.24, 'f32', 'fp32') is None
+    assert bench._node_phase_mfma(flops, 0.0, 'f32', 'native') is None
