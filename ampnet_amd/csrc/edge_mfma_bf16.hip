@@ -187,6 +187,16 @@ __device__ __forceinline__ void store_tile(const ampconv_view_t &v, int64_t node
   }
 }
 
+// a unit without edges: its output rows are zero; nothing of its own side needs to be read (R-MAT graphs: half of the
+// units of cfg5's main launch)
+template <bool HALF>
+__device__ __forceinline__ void store_zero_tile(const ampconv_view_t &v, int64_t node, int h, int L, int lane) {
+  f32x4 Z[2][2];
+#pragma unroll
+  for (int mc = 0; mc < 2; ++mc) Z[mc][0] = Z[mc][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  store_tile<HALF>(v, node, h, Z, 0.f, false, L, lane);
+}
+
 // ---------------------------------------------------------------- forward
 template <bool FULL, bool HALF>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void fwd_bf16(Args a) {
@@ -198,6 +208,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void fwd_bf16(Args a) {
   int64_t r, onode;
   int h, beg, end, deg;
   if (!map_unit(a.hub, a.ptr, unit, a.n_units, a.H, r, onode, h, beg, end, deg)) return;
+  if (beg >= end && a.hub.mode != 2) return store_zero_tile<HALF>(a.O, onode, h, a.L, lane);
   const int L = a.L, g = lane >> 4;
   char *Kt = lds_all[wave], *Vt = Kt + kTileBytes;
   const int64_t d = a.qidx ? a.qidx[r] : r;
@@ -265,6 +276,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void bwd_dst_bf16(Args a) {
   int64_t r, onode;
   int h, beg, end, deg;
   if (!map_unit(a.hub, a.ptr, unit, a.n_units, a.H, r, onode, h, beg, end, deg)) return;
+  if (beg >= end && a.hub.mode != 2) return store_zero_tile<HALF>(a.O, onode, h, a.L, lane);
   const int L = a.L, g = lane >> 4;
   char *Kt = lds_all[wave], *Vt = Kt + kTileBytes;
   const float inv = deg > 0 ? 1.f / (float)deg : 0.f;     // dO is the gradient of the MEAN
@@ -348,6 +360,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void bwd_src_bf16(Args a) {
   int64_t s, onode;
   int h, beg, end, deg;
   if (!map_unit(a.hub, a.ptr, unit, a.n_units, a.H, s, onode, h, beg, end, deg)) return;
+  if (beg >= end && a.hub.mode != 2) {
+    store_zero_tile<HALF>(a.dK, onode, h, a.L, lane);
+    return store_zero_tile<HALF>(a.dV, onode, h, a.L, lane);
+  }
   const int L = a.L, n = lane & 15;
   char *Qt = lds_all[wave], *Gt = Qt + kTileBytes;
 
