@@ -9,15 +9,10 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('AMPCONV_LIB_PATH', os.path.join(_HERE, 'libampconv.so'))   # override: dev A/B builds
 
-EXPECTED_ABI = 102          # AMPCONV_VERSION of include/ampconv.h this binding was written against
+EXPECTED_ABI = 103          # AMPCONV_VERSION of include/ampconv.h this binding was written against
 
 AMPCONV_F32 = 0
 AMPCONV_BF16 = 1
-AMPCONV_F32_EXACT = 2      # native fp32 MFMA
-AMPCONV_F32_BF16X9 = 3     # fp32 operands split exactly into 3 bf16, 9 partial products
-AMPCONV_F32_BF16X6 = 4     # ... 6 partial products
-PRECISIONS = {'default': AMPCONV_F32, 'exact': AMPCONV_F32_EXACT, 'bf16x9': AMPCONV_F32_BF16X9,
-              'bf16x6': AMPCONV_F32_BF16X6}
 HUB_CHUNK = int(os.environ.get('AMPCONV_HUB_CHUNK', 0))    # edges per chunk of a long CSR/CSC segment (include/ampconv.h, long segments); 0 = by size
 
 
@@ -78,13 +73,13 @@ SIGNATURES = {
     'ampconv_feat_sample_present': (_i32, [_vp, _i64, _i32, _i32, ctypes.c_uint64, _vp, _vp, _vp]),
     'ampconv_feat_build': (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     'ampconv_feat_table_grad': (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
-    'ampconv_proj_supported': (_i32, [_i32, _i32]),
-    'ampconv_proj_weight_image_bytes': (_sz, [_i32, _i32]),
-    'ampconv_proj_weight_image': (_i32, [_vp, _i64, _i64, _i32, _i32, _vp, _vp]),
-    'ampconv_proj_weight_images': (_i32, [_i32, _vp, _vp]),
-    'ampconv_proj_rows': (_i32, [_vp, _i64, _i64, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i64, _vp]),
-    'ampconv_proj_wgrad_workspace_bytes': (_sz, [_i64, _i32, _i32]),
-    'ampconv_proj_wgrad': (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _sz, _vp]),
+    'ampconv_proj_supported': (_i32, [_i32, _i32, _i32]),
+    'ampconv_proj_weight_image_bytes': (_sz, [_i32, _i32, _i32]),
+    'ampconv_proj_weight_image': (_i32, [_vp, _i64, _i64, _i32, _i32, _vp, _i32, _vp]),
+    'ampconv_proj_weight_images': (_i32, [_i32, _vp, _i32, _vp]),
+    'ampconv_proj_rows': (_i32, [_vp, _i64, _i64, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i64, _i32, _vp]),
+    'ampconv_proj_wgrad_workspace_bytes': (_sz, [_i64, _i32, _i32, _i32]),
+    'ampconv_proj_wgrad': (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _sz, _i32, _vp]),
     'ampconv_segment_mean': (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _vp]),
     'ampconv_mask_rows': (_i32, [_vp, _vp, _i64, _i64, _i32, _vp]),
     'ampconv_masked_colsum': (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, _i32, _vp]),

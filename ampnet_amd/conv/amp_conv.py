@@ -69,11 +69,6 @@ class AMPConv(MessagePassing):
         self.retain_attention = 'auto'
         self._attn_dropped_bytes = 0
         self._attn_param_versions = None
-        # how the per-EDGE fp32 products run on the matrix cores: 'default' | 'exact' | 'bf16x9' | 'bf16x6'
-        # (include/ampconv.h, dtype codes); inputs, outputs and accumulation are fp32 in every mode.  On a graph with
-        # long segments (a hub plan) the split modes run the 'exact' kernels for the whole graph: they have no
-        # long-segment pass of their own (include/ampconv.h, FALLBACK)
-        self.precision = 'default'
         # how the per-node projections run: 'native' (default: libampconv's own kernels, csrc/proj_gemm.hip -- fp32
         # operands split exactly into three bf16 terms, six partial products on the bf16 matrix cores, fp32
         # accumulate; fp32 storage with embed_dim % 4 == 0 -- tiles are padded inside, so the reference's default 100 is
@@ -128,7 +123,7 @@ class AMPConv(MessagePassing):
         self._attn_ctx = self._attn_output = self._attn_output_weights = None
         if self.softmax:
             y, qkv, _ = F_.AMPConvFunction.apply(x, x, *self._params(), csr, self.num_heads, True,
-                                                 _lib.PRECISIONS[self.precision], self.gemm_precision)
+                                                 _lib.AMPCONV_F32, self.gemm_precision)
         else:
             self._check_linear(x)
             y, qkv, _ = FL_.LinearAMPConvFunction.apply(x, x, *self._params(), csr, self.num_heads, True,
@@ -149,7 +144,7 @@ class AMPConv(MessagePassing):
         self._attn_ctx = self._attn_output = self._attn_output_weights = None
         if self.softmax:
             y, q, kv = F_.AMPConvFunction.apply(x_i, x_j, *self._params(), csr, self.num_heads, False,
-                                                _lib.PRECISIONS[self.precision], self.gemm_precision)
+                                                _lib.AMPCONV_F32, self.gemm_precision)
         else:
             self._check_linear(x_i)
             y, q, kv = FL_.LinearAMPConvFunction.apply(x_i, x_j, *self._params(), csr, self.num_heads, False,
@@ -251,7 +246,7 @@ class AMPConv(MessagePassing):
             o = torch.empty(E * L, D, dtype=torch.float32, device=edge_index.device)
             with torch.cuda.device(edge_index.device):
                 F_.edge_forward(Qv, Kv, Vv, ident, E, L, D, H, o, qidx=qidx,
-                                dtype=_lib.PRECISIONS[self.precision])   # fp32 views (see _attn_views)
+                                dtype=_lib.AMPCONV_F32)   # fp32 views (see _attn_views)
             m = self.multi_head_attention
             with torch.no_grad():
                 self._attn_output = torch.addmm(m.out_proj.bias.float(), o,

@@ -97,33 +97,47 @@ def _tn_matmul(a, b, chunks=128):
     return out
 
 
-# ---- the per-node projections in libampconv.so (csrc/proj_gemm.hip): fp32 operands split exactly into
-# three bf16 terms, six partial products on v_mfma_f32_32x32x16_bf16, fp32 accumulate
+# ---- the per-node projections in libampconv.so.  fp32 storage (csrc/proj_gemm.hip): operands split exactly into
+# three bf16 terms, six partial products on v_mfma_f32_32x32x16_bf16, fp32 accumulate; bf16 storage
+# (csrc/proj_gemm_bf16.hip): one product, fp32 accumulate, one rounding on the way out
+def _code(dtype):
+    return _lib.AMPCONV_BF16 if dtype == torch.bfloat16 else _lib.AMPCONV_F32
+
+
 def proj_native(gemm, dtype, D):
-    """Does the 'native' mode serve this layer?  fp32 storage, embed_dim a multiple of 4 (float4 rows)."""
-    return gemm == 'native' and dtype == torch.float32 and bool(_lib.load().ampconv_proj_supported(D, D))
+    """Does the 'native' mode serve this layer?  fp32 storage with embed_dim a multiple of 4, bf16 storage with a
+    multiple of 8 (rows move in 16-byte pieces)."""
+    return (gemm == 'native' and dtype in (torch.float32, torch.bfloat16)
+            and bool(_lib.load().ampconv_proj_supported(D, D, _code(dtype))))
+
+
+def _aligned(t):
+    """Rows in 16-byte pieces: a view whose first element is not 16-byte aligned (a slice of a larger tensor) is copied."""
+    return t if t.data_ptr() % 16 == 0 else t.clone(memory_format=torch.contiguous_format)
 
 
 def proj_images(jobs):
-    """MFMA-fragment images of fp32 weights, ALL in one launch: `jobs` = [(W, transpose), ...] (at most 8), W [R, C]
-    with contiguous rows; an image of W itself serves out = in @ W^T (the forward direction of nn.Linear), of W^T
-    serves out = in @ W (its input gradient).  Returns [(image bytes, N, K), ...]."""
+    """MFMA-fragment images of weights, ALL in one launch: `jobs` = [(W, transpose), ...] (at most 8), W [R, C]
+    with contiguous rows, all of one dtype; an image of W itself serves out = in @ W^T (the forward direction of
+    nn.Linear), of W^T serves out = in @ W (its input gradient).  Returns [(image bytes, N, K, dtype), ...]."""
     lib = _lib.load()
     descs, outs, off = (_lib.WeightImage * len(jobs))(), [], 0
     dims = []
+    wdt = jobs[0][0].dtype
+    code = _code(wdt)
     for W, transpose in jobs:
-        assert W.dim() == 2 and W.stride(1) == 1 and W.dtype == torch.float32
+        assert W.dim() == 2 and W.stride(1) == 1 and W.dtype == wdt
         R, C = W.shape
         N, K = (C, R) if transpose else (R, C)
-        dims.append((N, K, lib.ampconv_proj_weight_image_bytes(N, K)))
+        dims.append((N, K, lib.ampconv_proj_weight_image_bytes(N, K, code)))
     buf = torch.empty(sum(d[2] for d in dims), dtype=torch.uint8, device=jobs[0][0].device)
     for i, ((W, transpose), (N, K, nb)) in enumerate(zip(jobs, dims)):
         sn, sk = (1, W.stride(0)) if transpose else (W.stride(0), 1)
         img = buf[off:off + nb]
         descs[i] = _lib.WeightImage(W.data_ptr(), sn, sk, N, K, img.data_ptr())
-        outs.append((img, N, K))
+        outs.append((img, N, K, wdt))
         off += nb
-    _lib.check(lib.ampconv_proj_weight_images(len(jobs), ctypes.cast(descs, ctypes.c_void_p), _stream()),
+    _lib.check(lib.ampconv_proj_weight_images(len(jobs), ctypes.cast(descs, ctypes.c_void_p), code, _stream()),
                'ampconv_proj_weight_images')
     return outs
 
@@ -135,26 +149,32 @@ def proj_image(W, transpose=False):
 def proj_rows(a2, image, bias=None, rowptr=None, L=0):
     """out[M, N] = (a2[M, K] @ B^T + bias) * [node of the row has an in-edge]  (mask only with rowptr)."""
     lib = _lib.load()
-    img, N, K = image
-    assert a2.dim() == 2 and a2.size(1) == K and a2.stride(1) == 1 and a2.dtype == torch.float32
-    out = torch.empty(a2.size(0), N, dtype=torch.float32, device=a2.device)
+    img, N, K, wdt = image
+    assert a2.dim() == 2 and a2.size(1) == K and a2.stride(1) == 1 and a2.dtype == wdt
+    assert bias is None or bias.dtype == wdt
+    a2 = _aligned(a2)
+    out = torch.empty(a2.size(0), N, dtype=wdt, device=a2.device)
     _lib.check(lib.ampconv_proj_rows(a2.data_ptr(), a2.stride(0), a2.size(0), K, img.data_ptr(), N, _ptr(bias),
-                                     _ptr(rowptr), L, out.data_ptr(), N, _stream()), 'ampconv_proj_rows')
+                                     _ptr(rowptr), L, out.data_ptr(), N, _code(wdt), _stream()), 'ampconv_proj_rows')
     return out
 
 
 def proj_wgrad(a2, b2, dw, colsum=None, rowptr=None, L=0):
     """dw[Na, Nb] = (mask * a2)^T @ b2 and colsum[Na] = column sums of mask * a2, into caller-owned (views of)
-    contiguous fp32 tensors; reduction over the rows in fixed slices (bitwise reproducible)."""
+    contiguous tensors of the inputs' dtype; reduction over the rows in fixed slices (bitwise reproducible).
+    bf16: the mask acts on the column sums only (include/ampconv.h)."""
     lib = _lib.load()
     M, Na = a2.shape
     Nb = b2.size(1)
     assert b2.size(0) == M and dw.shape == (Na, Nb) and dw.is_contiguous() and a2.stride(1) == 1 and b2.stride(1) == 1
-    nws = lib.ampconv_proj_wgrad_workspace_bytes(M, Na, Nb)
+    assert a2.dtype == b2.dtype == dw.dtype and (colsum is None or colsum.dtype == a2.dtype)
+    a2, b2 = _aligned(a2), _aligned(b2)
+    code = _code(a2.dtype)
+    nws = lib.ampconv_proj_wgrad_workspace_bytes(M, Na, Nb, code)
     ws = torch.empty(max(nws, 16) // 4, dtype=torch.float32, device=a2.device)
     _lib.check(lib.ampconv_proj_wgrad(a2.data_ptr(), a2.stride(0), b2.data_ptr(), b2.stride(0), M, Na, Nb,
-                                      _ptr(rowptr), L, dw.data_ptr(), _ptr(colsum), ws.data_ptr(), nws, _stream()),
-               'ampconv_proj_wgrad')
+                                      _ptr(rowptr), L, dw.data_ptr(), _ptr(colsum), ws.data_ptr(), nws, code,
+                                      _stream()), 'ampconv_proj_wgrad')
 
 
 def edge_forward(Q, K, V, csr, n_rows, L, D, H, out2d, qidx=None, dtype=_lib.AMPCONV_F32):
@@ -182,10 +202,11 @@ class AMPConvFunction(torch.autograd.Function):
         H = int(num_heads)
         dh = D // H
         L = xq.size(1) // D
+        if w_in.dtype != xq.dtype or w_out.dtype != xq.dtype:
+            raise ValueError(f'inputs are {xq.dtype} but the parameters are {w_in.dtype}: storage is all float32 or all '
+                             f'bfloat16 (layer.to(torch.bfloat16))')
         if xq.dtype == torch.bfloat16:                   # bf16 storage: one mode only
             dtype = _lib.AMPCONV_BF16
-            if w_in.dtype != torch.bfloat16:
-                raise ValueError('bf16 inputs need bf16 parameters: call layer.to(torch.bfloat16)')
             if not ((dh in (16, 32) and L <= 20) or (dh % 2 == 0 and dh <= 64 and L <= 64)):
                 raise ValueError(f'bf16 storage is implemented for head dimensions 32 and 16 with at most 20 tokens per '
                                  f'node (csrc/edge_mfma_bf16.hip; BASELINE configs 5 and 3) and for even head dimensions '
@@ -251,7 +272,7 @@ class AMPConvFunction(torch.autograd.Function):
             # the bias gradient masks them explicitly)
             if native:
                 dw_out = torch.empty_like(w_out)
-                db_out = torch.empty(D, dtype=torch.float32, device=dev)
+                db_out = torch.empty(D, dtype=dy2.dtype, device=dev)
                 proj_wgrad(dy2, obar, dw_out, db_out, csr.rowptr, L)
                 dobar = proj_rows(dy2, ctx.images_t[-1])
             else:
@@ -304,7 +325,7 @@ class AMPConvFunction(torch.autograd.Function):
                 # weight and bias gradients in one pass each (the column sums ride on the rows the product reads
                 # anyway: all three thirds of in_proj_bias.grad are the true sums, as autograd's are)
                 dw_in = torch.empty_like(w_in)
-                db_in = torch.empty(3 * D, dtype=torch.float32, device=dev)
+                db_in = torch.empty(3 * D, dtype=dy2.dtype, device=dev)
                 if shared:
                     proj_wgrad(dqkv, xq2, dw_in, db_in)
                     dxq = proj_rows(dqkv, ctx.images_t[0]).view(Nq, L * D) if need_xq else None

@@ -144,20 +144,6 @@ int ampconv_bwd_edge_src_block(ampconv_view_t Q, ampconv_view_t K, ampconv_view_
                                int L, int D, int H, ampconv_view_t dK, ampconv_view_t dV, HubArgs hub,
                                const float *stats, bool bf16, hipStream_t stream);
 
-// ---- split-operand bf16 MFMA path (edge_mfma_split.hip): L <= 20, dh == 32; nprod = 9 or 6
-bool ampconv_split_supported(int L, int D, int H);
-int ampconv_fwd_edge_split(int nprod, ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
-                           const int32_t *rowptr, const int32_t *col, const int32_t *qidx,
-                           int64_t n_rows, int L, int D, int H, ampconv_view_t O, hipStream_t stream);
-int ampconv_bwd_edge_dst_split(int nprod, ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
-                               ampconv_view_t dO, const int32_t *rowptr, const int32_t *col,
-                               int64_t n_rows, int L, int D, int H, ampconv_view_t dQ,
-                               hipStream_t stream);
-int ampconv_bwd_edge_src_split(int nprod, ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
-                               ampconv_view_t dO, const int32_t *cscptr, const int32_t *crow,
-                               const float *cinv, int64_t n_src, int L, int D, int H,
-                               ampconv_view_t dK, ampconv_view_t dV, hipStream_t stream);
-
 // hub.hip
 int ampconv_hub_combine(const void *plan, int64_t n_chunks, const float *P, ampconv_view_t out,
                         const int32_t *ptr_for_mean, int L, int D, int H, float scale, int out_bf16,

@@ -11,13 +11,10 @@ bool force_generic() {
   return e && e[0] == '1';
 }
 int check_common(int L, int D, int H, int dtype) {
-  if (dtype != AMPCONV_F32 && dtype != AMPCONV_F32_EXACT && dtype != AMPCONV_F32_BF16X9 &&
-      dtype != AMPCONV_F32_BF16X6 && dtype != AMPCONV_BF16)
-    return AMPCONV_E_DTYPE;
+  if (dtype != AMPCONV_F32 && dtype != AMPCONV_BF16) return AMPCONV_E_DTYPE;
   if (L <= 0 || D <= 0 || H <= 0 || D % H != 0) return AMPCONV_E_BADARG;
   return AMPCONV_OK;
 }
-// number of bf16 partial products of the split path to use (9 / 6), or 0 for native fp32 MFMA
 // partial-tile view of the hub workspace: chunk c, token l, channel cc at P[(c*L + l)*D + cc]
 ampconv_view_t partial_view(void *ws, int64_t tile, int64_t n_chunks, int L, int D, int H) {
   return ampconv_view_t{(float *)ws + tile * n_chunks * L * D, (int64_t)L * D, (int64_t)D,
@@ -25,17 +22,6 @@ ampconv_view_t partial_view(void *ws, int64_t tile, int64_t n_chunks, int L, int
 }
 HubArgs hub_args(const void *plan, int mode) { return HubArgs{(const int32_t *)plan, mode}; }
 
-int split_products(int dtype, int L, int D, int H) {
-  if (dtype == AMPCONV_F32) {
-    const char *e = std::getenv("AMPCONV_F32_MODE");
-    if (e && e[0] == 'b' && e[1] == 'f' && e[2] == '1' && e[3] == '6' && e[4] == 'x')
-      dtype = e[5] == '6' ? AMPCONV_F32_BF16X6 : AMPCONV_F32_BF16X9;
-    else
-      dtype = AMPCONV_F32_EXACT;
-  }
-  if (dtype == AMPCONV_F32_EXACT || !ampconv_split_supported(L, D, H)) return 0;
-  return dtype == AMPCONV_F32_BF16X6 ? 6 : 9;
-}
 }  // namespace
 
 extern "C" int ampconv_version(void) { return AMPCONV_VERSION; }
@@ -78,12 +64,6 @@ extern "C" int ampconv_fwd_edge(ampconv_view_t Q, ampconv_view_t K, ampconv_view
   // bf16 storage of the other shapes: the workgroup-per-unit kernels widen / round the rows themselves
   if (bf && !ampconv_block_supported(L, D, H, views, 4, true)) return AMPCONV_E_DTYPE;
   if (!bf && !force_generic() && ampconv_mfma_supported(L, D, H) && ampconv_mfma_views_ok(views, 4)) {
-    // the split-operand kernels have no long-segment (hub) pass: with a plan the native fp32 kernels run
-    // (exact fp32 as well) instead of one wave walking a hub's whole segment
-    const bool hubs = hub_plan && hub_chunks > 0 && hub_ws && !qidx;
-    if (const int np = hubs ? 0 : split_products(dtype, L, D, H))
-      return ampconv_fwd_edge_split(np, Q, K, V, rowptr, col, qidx, n_rows, L, D, H, O,
-                                    (hipStream_t)stream);
     if (hub_plan && hub_chunks > 0 && hub_ws && !qidx) {      // long segments: main + hub + combine
       HubArgs hm = hub_args(hub_plan, 1), hh = hub_args(hub_plan, 2);
       if (int rc = ampconv_fwd_edge_mfma(Q, K, V, rowptr, col, nullptr, n_rows, L, D, H, O, hm,
@@ -125,7 +105,7 @@ extern "C" size_t ampconv_softmax_stats_bytes(int64_t E, int L, int D, int H, in
                ? 0 : (size_t)E * H * ampconv_block_stats_floats(L) * sizeof(float);   // workgroup-per-unit kernels
   if (force_generic()) return 0;
   if (ampconv_mfma_supported(L, D, H))
-    return split_products(dtype, L, D, H) ? 0 : (size_t)E * H * kStatsPerUnit * sizeof(float);
+    return (size_t)E * H * kStatsPerUnit * sizeof(float);
   if (ampconv_block_supported(L, D, H, nullptr, 0, false))     // shapes of the workgroup-per-unit kernels
     return (size_t)E * H * ampconv_block_stats_floats(L) * sizeof(float);
   return 0;
@@ -164,10 +144,6 @@ extern "C" int ampconv_bwd_edge_dst(ampconv_view_t Q, ampconv_view_t K, ampconv_
   }
   if (bf && !ampconv_block_supported(L, D, H, views, 5, true)) return AMPCONV_E_DTYPE;
   if (!bf && !force_generic() && ampconv_mfma_supported(L, D, H) && ampconv_mfma_views_ok(views, 5)) {
-    const bool hubs = hub_plan && hub_chunks > 0 && hub_ws;      // see ampconv_fwd_edge
-    if (const int np = hubs ? 0 : split_products(dtype, L, D, H))
-      return stats ? AMPCONV_E_BADARG : ampconv_bwd_edge_dst_split(np, Q, K, V, dObar, rowptr, col, n_rows, L, D, H, dQ,
-                                        (hipStream_t)stream);
     if (hub_plan && hub_chunks > 0 && hub_ws) {
       HubArgs hm = hub_args(hub_plan, 1), hh = hub_args(hub_plan, 2);
       if (int rc = ampconv_bwd_edge_dst_mfma(Q, K, V, dObar, rowptr, col, n_rows, L, D, H, dQ, hm, sa,
@@ -244,10 +220,6 @@ extern "C" int ampconv_bwd_edge_src(ampconv_view_t Q, ampconv_view_t K, ampconv_
   }
   if (bf && !(stats && ampconv_block_supported(L, D, H, views, 6, true))) return AMPCONV_E_DTYPE;
   if (!bf && !force_generic() && ampconv_mfma_supported(L, D, H) && ampconv_mfma_views_ok(views, 6)) {
-    const bool hubs = hub_plan && hub_chunks > 0 && hub_ws;      // see ampconv_fwd_edge
-    if (const int np = hubs ? 0 : split_products(dtype, L, D, H))
-      return stats ? AMPCONV_E_BADARG : ampconv_bwd_edge_src_split(np, Q, K, V, dObar, cscptr, crow, cinv, n_src, L, D, H,
-                                        dK, dV, (hipStream_t)stream);
     if (hub_plan && hub_chunks > 0 && hub_ws) {
       HubArgs hm = hub_args(hub_plan, 1), hh = hub_args(hub_plan, 2);
       if (int rc = ampconv_bwd_edge_src_mfma(Q, K, V, dObar, cscptr, crow, cinv, n_src, L, D, H, dK, dV,

@@ -24,28 +24,12 @@
 //              ds_read_b64_tr_b16; deterministic two-step reduction over row slices)
 #include <stdlib.h>
 #include <type_traits>
-#include "common.h"
+#include "proj_common.h"
 
 namespace {
+using namespace proj;
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef int i32x4 __attribute__((ext_vector_type(4)));
-typedef int i32x2 __attribute__((ext_vector_type(2)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) char lds_char;
-
-constexpr int kFrag = 1024;          // one MFMA operand fragment: 64 lanes x 8 bf16
 constexpr int kTile3 = 3 * kFrag;    // the three planes of one (32-row tile, 16-deep k step)
-
-__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {   // v_cvt_pk_bf16_f32 (RNE)
-  f32x2 v = {a, b};
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-}
-__device__ __forceinline__ float lo_as_f32(unsigned h) { return __builtin_bit_cast(float, h << 16); }
-__device__ __forceinline__ float hi_as_f32(unsigned h) { return __builtin_bit_cast(float, h & 0xFFFF0000u); }
 
 // (x0, x1) -> packed bf16 pairs of the three planes; x == h1 + h2 + h3 exactly
 struct Pair3 {
@@ -58,9 +42,6 @@ __device__ __forceinline__ Pair3 split_pair(float x0, float x1) {
   const float s0 = r0 - lo_as_f32(b), s1 = r1 - hi_as_f32(b);
   return Pair3{(int)a, (int)b, (int)cvt_pk_bf16(s0, s1)};
 }
-
-#define MFMA32(a, b, c) \
-  __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), (c), 0, 0, 0)
 
 // six partial products, smallest first
 __device__ __forceinline__ f32x16 mfma6(const i32x4 (&a)[3], const i32x4 (&b)[3], f32x16 c) {
@@ -83,18 +64,6 @@ __device__ __forceinline__ void mfma6_row(const i32x4 (&a)[3], const i32x4 (&b)[
   for (int q = 0; q < 6; ++q)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) c[j] = MFMA32(a[PA[q]], b[j][PB[q]], c[j]);
-}
-
-// LDS-DMA of 16 bytes per lane: LDS destination = wave-uniform `lds_dst` + 16 * lane, source per lane.
-// Inline assembly on purpose: behind the builtin hipcc orders every later LDS read after the DMA with
-// `s_waitcnt vmcnt(0)` (the whole memory latency); the kernels below wait for their DMAs themselves.
-__device__ __forceinline__ void dma16(const void *gsrc, unsigned lds_dst) {
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\t"
-               "s_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(gsrc), "s"(lds_dst)
-               : "memory");
 }
 
 #ifdef AMPCONV_PROJ_STAMPS
@@ -182,8 +151,6 @@ struct RowsArgs {
   int Kp, Np;                 // K, N padded to multiples of 32 / 128 (= the weight image's shape)
 };
 
-constexpr int kXcd = 8;
-
 // RAGGED: K % 32 != 0 or N % BN != 0 (e.g. the reference's default embed_dim = 100): row loads beyond K read as zero,
 // columns beyond N are computed on the image's zero padding and not stored
 template <int BM, int BN, int WM, int WN, bool RAGGED>
@@ -266,9 +233,16 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void proj_rows_kernel(RowsArgs a) 
         x[0][i] = *reinterpret_cast<const float4 *>(rp[i]);
         x[1][i] = *reinterpret_cast<const float4 *>(rp[i] + 16);
       } else {
-        x[0][i] = x[1][i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (kpos < a.K) x[0][i] = *reinterpret_cast<const float4 *>(rp[i]);
-        if (kpos + 16 < a.K) x[1][i] = *reinterpret_cast<const float4 *>(rp[i] + 16);
+        // The even step waits for the weight DMAs with a COUNTED vmcnt (2 * NLH younger row loads stay in flight), so
+        // the number of vector-memory instructions a wave issues here must not depend on K: a conditional load is
+        // skipped by the whole wave when no lane needs it (K % 32 in [1, 16]: the reference's embed_dim = 100) and the
+        // count would then cover this wave's DMA pieces only by luck.  Load unconditionally from an in-bounds address
+        // (the row's first float4 where the column lies beyond K) and zero by select.
+        const bool in0 = kpos < a.K, in1 = kpos + 16 < a.K;
+        const float4 v0 = *reinterpret_cast<const float4 *>(in0 ? rp[i] : rp[i] - kpos);
+        const float4 v1 = *reinterpret_cast<const float4 *>(in1 ? rp[i] + 16 : rp[i] - kpos);
+        x[0][i] = make_float4(in0 ? v0.x : 0.f, in0 ? v0.y : 0.f, in0 ? v0.z : 0.f, in0 ? v0.w : 0.f);
+        x[1][i] = make_float4(in1 ? v1.x : 0.f, in1 ? v1.y : 0.f, in1 ? v1.z : 0.f, in1 ? v1.w : 0.f);
       }
       rp[i] += 32;
     }
@@ -453,13 +427,6 @@ struct WgradArgs {
 };
 
 constexpr int kRS = 16;       // rows per stage
-
-__device__ __forceinline__ i32x4 tr_frag(const char *p0, const char *p1) {
-  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)p0);
-  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)p1);
-  const i32x2 ai = __builtin_bit_cast(i32x2, a), bi = __builtin_bit_cast(i32x2, b);
-  return i32x4{ai[0], ai[1], bi[0], bi[1]};
-}
 
 // RAGGED: Na or Nb not a multiple of the tile (the reference's default embed_dim = 100): columns beyond them load as 0
 template <int TI, int TJ, int WI, int WJ, bool MASK, bool RAGGED>
@@ -696,26 +663,33 @@ inline WgradPlan wgrad_plan(int64_t M, int Nap, int Nbp) {       // padded shape
 
 }  // namespace
 
-extern "C" size_t ampconv_proj_weight_image_bytes(int N, int K) {
-  if (N <= 0 || K <= 0) return 0;
+extern "C" size_t ampconv_proj_weight_image_bytes(int N, int K, int dtype) {
+  if (dtype == AMPCONV_BF16) return ampconv_proj_weight_image_bytes_bf16(N, K);
+  if (dtype != AMPCONV_F32 || N <= 0 || K <= 0) return 0;
   return (size_t)((N + 127) / 128 * 128) * (size_t)((K + 31) / 32 * 32) * 6;      // padded shape, three bf16 planes
 }
 
-// rows and row strides are read as float4: every dimension a multiple of 4 (16-byte aligned rows); the tiles are
-// padded internally (N to 128, K to 32), so embed_dim = 100 -- the reference's AMPGCN default -- is served too
-extern "C" int ampconv_proj_supported(int N, int K) {
-  return N > 0 && K > 0 && N % 4 == 0 && K % 4 == 0;
+static bool supported_f32(int N, int K) { return N > 0 && K > 0 && N % 4 == 0 && K % 4 == 0; }
+
+// fp32: rows and row strides are read as float4: every dimension a multiple of 4 (16-byte aligned rows); the tiles are
+// padded internally (N to 128, K to 32), so embed_dim = 100 -- the reference's AMPGCN default -- is served too.
+// bf16: multiples of 8 (the same 16 bytes)
+extern "C" int ampconv_proj_supported(int N, int K, int dtype) {
+  if (dtype == AMPCONV_BF16) return ampconv_proj_supported_bf16(N, K) ? 1 : 0;
+  return dtype == AMPCONV_F32 && supported_f32(N, K);
 }
 
-extern "C" int ampconv_proj_weight_images(int count, const ampconv_weight_image_t *jobs, void *stream) {
+extern "C" int ampconv_proj_weight_images(int count, const ampconv_weight_image_t *jobs, int dtype, void *stream) {
   if (count < 0 || count > 8 || (count && !jobs)) return AMPCONV_E_BADARG;
   if (count == 0) return AMPCONV_OK;
+  if (dtype == AMPCONV_BF16) return ampconv_proj_weight_images_bf16(count, jobs, (hipStream_t)stream);
+  if (dtype != AMPCONV_F32) return AMPCONV_E_DTYPE;
   ImageJobs js;
   int most = 0;
   for (int i = 0; i < count; ++i) {
     const ampconv_weight_image_t &w = jobs[i];
-    if (!ampconv_proj_supported(w.N, w.K) || !w.W || !w.image || (uintptr_t)w.image % 16) return AMPCONV_E_BADARG;
-    js.j[i] = ImageJob{w.W, w.stride_n, w.stride_k, w.N, w.K, (char *)w.image};
+    if (!supported_f32(w.N, w.K) || !w.W || !w.image || (uintptr_t)w.image % 16) return AMPCONV_E_BADARG;
+    js.j[i] = ImageJob{(const float *)w.W, w.stride_n, w.stride_k, w.N, w.K, (char *)w.image};
     const int total = ((w.N + 127) / 128 * 128) * (((w.K + 31) / 32 * 32) / 8);
     most = total > most ? total : most;
   }
@@ -723,21 +697,26 @@ extern "C" int ampconv_proj_weight_images(int count, const ampconv_weight_image_
   return ampconv_launch_status();
 }
 
-extern "C" int ampconv_proj_weight_image(const float *W, int64_t stride_n, int64_t stride_k, int N, int K,
-                                         void *image, void *stream) {
+extern "C" int ampconv_proj_weight_image(const void *W, int64_t stride_n, int64_t stride_k, int N, int K,
+                                         void *image, int dtype, void *stream) {
   const ampconv_weight_image_t job{W, stride_n, stride_k, N, K, image};
-  return ampconv_proj_weight_images(1, &job, stream);
+  return ampconv_proj_weight_images(1, &job, dtype, stream);
 }
 
-extern "C" int ampconv_proj_rows(const float *A, int64_t lda, int64_t M, int K, const void *wimage, int N,
-                                 const float *bias, const int32_t *rowptr, int L, float *out, int64_t ldc,
-                                 void *stream) {
-  if (M < 0 || !ampconv_proj_supported(N, K) || lda < K || ldc < N || lda % 4) return AMPCONV_E_BADARG;
+extern "C" int ampconv_proj_rows(const void *A_, int64_t lda, int64_t M, int K, const void *wimage, int N,
+                                 const void *bias_, const int32_t *rowptr, int L, void *out_, int64_t ldc,
+                                 int dtype, void *stream) {
+  if (dtype == AMPCONV_BF16)
+    return ampconv_proj_rows_bf16(A_, lda, M, K, wimage, N, bias_, rowptr, L, out_, ldc, (hipStream_t)stream);
+  if (dtype != AMPCONV_F32) return AMPCONV_E_DTYPE;
+  const float *A = (const float *)A_, *bias = (const float *)bias_;
+  float *out = (float *)out_;
+  if (M < 0 || !supported_f32(N, K) || lda < K || ldc < N || lda % 4) return AMPCONV_E_BADARG;
   if (M == 0) return AMPCONV_OK;
   if (!A || !wimage || !out || (uintptr_t)A % 16 || (uintptr_t)wimage % 16) return AMPCONV_E_BADARG;
   if (rowptr && L <= 0) return AMPCONV_E_BADARG;
   if (ldc % 4 || (uintptr_t)out % 16) return AMPCONV_E_BADARG;
-  // tile shape (developer switch AMPCONV_PROJ_ROWS: 0 = 256 x 256 tile of 8 waves where N allows, 1 = 128 x 128 of 4)
+  // tile shape (developer switch AMPCONV_PROJ_ROWS: 0 = 128 x 256 tile of 4 waves where N allows, 1 = 256 x 256 of 8)
   static const int variant = [] {
     const char *e = getenv("AMPCONV_PROJ_ROWS");
     return e ? atoi(e) : 0;
@@ -750,12 +729,11 @@ extern "C" int ampconv_proj_rows(const float *A, int64_t lda, int64_t M, int K, 
   if (rts > (int64_t)INT32_MAX / 64) return AMPCONV_E_BADARG;
   const int64_t rtp = (rts + 7) / 8 * 8;
   RowsArgs a{A, lda, M, K, N, (const char *)wimage, bias, rowptr, L, out, ldc, (int)rts, rtp * (Np / bn), Kp, Np};
-  static const int n_cu = [] {
-    int dev = 0, n = 256;
-    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-    return n;
-  }();
-  int64_t grid = (int64_t)n_cu * (shape == 1 ? 1 : 2);
+  const int n_cu = cu_count();
+  // a multiple of 8: slot u of a workgroup keeps u % 8 (its XCD label), so "my next slot is invalid" means "nothing
+  // further for me" only then (a.tiles is a multiple of 8 by construction)
+  int64_t grid = (int64_t)n_cu * (shape == 1 ? 1 : 2) / kXcd * kXcd;
+  if (grid < kXcd) grid = kXcd;
   if (grid > a.tiles) grid = a.tiles;
   hipStream_t st = (hipStream_t)stream;
   const unsigned g = (unsigned)grid;
@@ -768,16 +746,23 @@ extern "C" int ampconv_proj_rows(const float *A, int64_t lda, int64_t M, int K, 
   return ampconv_launch_status();
 }
 
-extern "C" size_t ampconv_proj_wgrad_workspace_bytes(int64_t M, int Na, int Nb) {
-  if (M < 0 || Na <= 0 || Nb <= 0 || Na % 4 || Nb % 4) return 0;
+extern "C" size_t ampconv_proj_wgrad_workspace_bytes(int64_t M, int Na, int Nb, int dtype) {
+  if (dtype == AMPCONV_BF16) return ampconv_proj_wgrad_workspace_bytes_bf16(M, Na, Nb);
+  if (dtype != AMPCONV_F32 || M < 0 || Na <= 0 || Nb <= 0 || Na % 4 || Nb % 4) return 0;
   const int Nap = (Na + 127) / 128 * 128, Nbp = (Nb + 127) / 128 * 128;
   const WgradPlan p = wgrad_plan(M, Nap, Nbp);
   return (size_t)p.S * ((size_t)Nap * Nbp + Nap) * sizeof(float);
 }
 
-extern "C" int ampconv_proj_wgrad(const float *A, int64_t lda, const float *B, int64_t ldb, int64_t M, int Na,
-                                  int Nb, const int32_t *rowptr, int L, float *dW, float *colsum,
-                                  void *workspace, size_t workspace_bytes, void *stream) {
+extern "C" int ampconv_proj_wgrad(const void *A_, int64_t lda, const void *B_, int64_t ldb, int64_t M, int Na,
+                                  int Nb, const int32_t *rowptr, int L, void *dW_, void *colsum_,
+                                  void *workspace, size_t workspace_bytes, int dtype, void *stream) {
+  if (dtype == AMPCONV_BF16)
+    return ampconv_proj_wgrad_bf16(A_, lda, B_, ldb, M, Na, Nb, rowptr, L, dW_, colsum_, workspace, workspace_bytes,
+                                   (hipStream_t)stream);
+  if (dtype != AMPCONV_F32) return AMPCONV_E_DTYPE;
+  const float *A = (const float *)A_, *B = (const float *)B_;
+  float *dW = (float *)dW_, *colsum = (float *)colsum_;
   if (M < 0 || Na <= 0 || Nb <= 0 || Na % 4 || Nb % 4 || lda < Na || ldb < Nb || lda % 4 || ldb % 4)
     return AMPCONV_E_BADARG;
   if (!dW || (uintptr_t)dW % 16 || (colsum && (uintptr_t)colsum % 16)) return AMPCONV_E_BADARG;

@@ -246,4 +246,4 @@ class PartitionedAMPConv(torch.nn.Module):
         if x_local.dtype != torch.float32 or not conv.softmax:
             raise ValueError('the partitioned layer runs the float32 softmax path')
         return _PartitionedFunction.apply(x_local, *conv._params(), graph, conv.num_heads, part,
-                                          _lib.PRECISIONS[conv.precision], conv.gemm_precision)
+                                          _lib.AMPCONV_F32, conv.gemm_precision)

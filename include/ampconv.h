@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define AMPCONV_VERSION 102
+#define AMPCONV_VERSION 103
 
 enum {
   AMPCONV_OK = 0,
@@ -40,29 +40,19 @@ enum {
   AMPCONV_E_WORKSPACE = -3 /* workspace too small */
 };
 
-/* dtype codes.  AMPCONV_BF16: every view is bf16 in HBM (Q/K/V/O and gradients), fp32 softmax and accumulation.
- * L <= 20 with dh = 32 (BASELINE config 5) or dh = 16 (half-filled tiles): products on the bf16 MFMA, no softmax
- * statistics.  Other even dh <= 64 with L <= 64 (e.g. the reference's class default L = 40, dh = 50): the fp32
- * workgroup-per-unit kernels read / write the bf16 rows themselves (fp32 MFMA arithmetic); their source pass needs
- * the statistics buffer of ampconv_softmax_stats_bytes like the fp32 call.  Anything else: AMPCONV_E_DTYPE.
- * All AMPCONV_F32* codes take and return fp32 tensors; they differ in how the
- * per-edge products are evaluated on the matrix cores:
- *   AMPCONV_F32_EXACT   v_mfma_f32_16x16x4_f32 (native fp32 MFMA, 1/16 of the bf16 rate)
- *   AMPCONV_F32_BF16X9  every fp32 operand split EXACTLY into 3 bf16 terms, all 9 partial
- *                       products on v_mfma_f32_16x16x32_bf16, fp32 accumulate: no operand
- *                       rounding at all (error = fp32 accumulation only)
- *   AMPCONV_F32_BF16X6  as X9 without the three partial products of order <= 2^-24
- *   AMPCONV_F32         library default = AMPCONV_F32_EXACT; AMPCONV_F32_MODE=bf16x9|bf16x6 in the
- *                       environment selects a split mode where the shape supports it (dh = 32).
- * On MI355X the split modes measure within 4 % of the native mode (the kernels are bound by
- * per-wave latency, not by MFMA issue), so the native fp32 MFMA is the default.
- * FALLBACK: the split-operand edge kernels have no long-segment pass.  A call that carries a hub plan
- * (hub_plan != NULL and hub_chunks > 0: the graph has a CSR / CSC segment longer than the chunk) runs
- * the AMPCONV_F32_EXACT kernels for the WHOLE graph in every AMPCONV_F32* mode -- the result is fp32-grade
- * either way; which arithmetic ran then depends on the degree distribution.  (This concerns the per-edge
- * products only; the per-node projections have their own mode, ampconv_proj_* below.) */
-enum { AMPCONV_F32 = 0, AMPCONV_BF16 = 1, AMPCONV_F32_EXACT = 2, AMPCONV_F32_BF16X9 = 3,
-       AMPCONV_F32_BF16X6 = 4 };
+/* dtype codes.
+ * AMPCONV_F32:  every view is fp32 in HBM; the per-edge products run on v_mfma_f32_16x16x4_f32 (exact fp32,
+ *               fmaf-chain numerics), the per-node projections (ampconv_proj_*) on the bf16 matrix cores with every
+ *               fp32 operand split exactly into three bf16 terms (fp32-grade error).
+ * AMPCONV_BF16: every view is bf16 in HBM (Q/K/V/O and gradients), fp32 softmax and accumulation.
+ *               L <= 20 with dh = 32 (BASELINE config 5) or dh = 16 (half-filled tiles): products on the bf16 MFMA,
+ *               no softmax statistics.  Other even dh <= 64 with L <= 64 (e.g. the reference's class default L = 40,
+ *               dh = 50): the fp32 workgroup-per-unit kernels read / write the bf16 rows themselves (fp32 MFMA
+ *               arithmetic); their source pass needs the statistics buffer of ampconv_softmax_stats_bytes like the
+ *               fp32 call.  Anything else: AMPCONV_E_DTYPE.
+ * (Versions <= 102 had three more codes for split-operand edge kernels; they were slower than the native fp32 MFMA
+ * kernels on MI355X and were removed in 103.) */
+enum { AMPCONV_F32 = 0, AMPCONV_BF16 = 1 };
 
 /*
  * Strided view of a per-node token matrix: element (node n, token l, head h,
@@ -226,40 +216,53 @@ int ampconv_masked_colsum(const void *dY, const int32_t *rowptr, int64_t N,
  * reference's copy src/ampnet/conv/custom_multihead_attn_forward.py:4070-4077) and the
  * out-projection (torch functional.py:6600), once per NODE instead of once per edge, and their
  * autograd backward (dObar = dY Wo, dX = dQKV Win, dW = dOut^T In, db = colsum).
- * fp32 in, fp32 out, fp32 accumulate; every operand element is split EXACTLY into three bf16 terms
- * and a product is the sum of the six partial products of order >= 2^-16 on
- * v_mfma_f32_32x32x16_bf16 (error of the dropped terms <= 3 * 2^-26 per product: fp32 grade).
- *   proj_supported     : 1 if (N, K) is served (both multiples of 4: rows are read and written as float4; tiles
- *                        are padded internally, so the reference's default embed_dim = 100 is served), else 0 --
- *                        the caller then uses a library GEMM
+ * `dtype` names the storage of EVERY tensor of a call (rows, weights, bias, outputs, gradients):
+ *   AMPCONV_F32   fp32 in, fp32 out, fp32 accumulate; every operand element is split EXACTLY into three bf16 terms
+ *                 and a product is the sum of the six partial products of order >= 2^-16 on
+ *                 v_mfma_f32_32x32x16_bf16 (error of the dropped terms <= 3 * 2^-26 per product: fp32 grade).
+ *                 Non-finite inputs: NaN propagates; +-Inf (and |x| above the largest bf16, 3.39e38) comes out as
+ *                 NaN where an fp32 GEMM would return +-Inf (the residual planes are inf - inf).
+ *   AMPCONV_BF16  bf16 in HBM (BASELINE config 5), ONE product per fragment pair on the same instruction, fp32
+ *                 accumulate, results rounded to bf16 once (weight / bias gradients: after the ordered fp32 sum over
+ *                 the row slices).  The weight-gradient PRODUCT is not masked in this mode (the in-degree mask acts
+ *                 on the column sums only): the rows of nodes without in-edges contribute nothing because the other
+ *                 operand (the forward pass's Obar) is exactly 0 there -- as in a plain dY^T Obar.
+ *   proj_supported     : 1 if (N, K) is served, else 0 -- the caller then uses a library GEMM.  fp32: both multiples
+ *                        of 4, bf16: of 8 (rows are read and written in 16-byte pieces); tiles are padded
+ *                        internally, so the reference's default embed_dim = 100 is served in fp32
  *   proj_weight_image  : B[n][k] = W[n * stride_n + k * stride_k] (N x K) -> `image`
- *                        (proj_weight_image_bytes(N, K) bytes, 16-byte aligned): the three bf16 planes
- *                        of the weight as ready MFMA fragments, zero-padded to (N to 128, K to 32).  (stride_n, stride_k) = (K, 1) uses a
+ *                        (proj_weight_image_bytes(N, K, dtype) bytes, 16-byte aligned): the weight as ready MFMA
+ *                        fragments (fp32: its three bf16 planes), zero-padded.  (stride_n, stride_k) = (K, 1) uses a
  *                        row-major [N, K] weight as it stands (forward), (1, N) its transpose (backward).
  *   proj_weight_images : up to 8 of them in ONE launch (forward and transposed images of both weights of a layer)
  *   proj_rows          : out[m, :N] = (A[m, :K] B^T + bias) * (rowptr ? [node m / L has an in-edge] : 1)
  *                        A row-major with leading dimension lda (elements), out with ldc
  *   proj_wgrad         : dW[Na, Nb] = sum_m (mask_m A[m, :Na])^T B[m, :Nb] and colsum[Na] = sum_m mask_m A[m, :Na]
- *                        (mask as above, rowptr may be NULL); deterministic: fixed row slices, ordered sum.
- *                        `workspace`: proj_wgrad_workspace_bytes(M, Na, Nb) bytes.  */
-int ampconv_proj_supported(int N, int K);
-size_t ampconv_proj_weight_image_bytes(int N, int K);
-int ampconv_proj_weight_image(const float *W, int64_t stride_n, int64_t stride_k, int N, int K,
-                              void *image, void *stream);
+ *                        (mask as above, rowptr may be NULL; bf16: see above); deterministic: fixed row slices,
+ *                        ordered sum.  `workspace`: proj_wgrad_workspace_bytes(M, Na, Nb, dtype) bytes.
+ * Developer switches read from the environment at the first call (A/B measurements; the defaults are the
+ * shipped configuration, nothing else keeps state): AMPCONV_PROJ_ROWS=1 (256 x 256 row tiles),
+ * AMPCONV_PROJ_WGRAD_TI=128, and for the edge phase AMPCONV_FORCE_GENERIC=1, AMPCONV_{FWD,DST,SRC}_T4=0,
+ * AMPCONV_{FWD,DST,SRC}_NT4=0 (older tilings of the same kernels, kept as cross-checks for the tests),
+ * AMPCONV_CSR_SMALL=0 (graph preparation by the multi-launch path).  */
+int ampconv_proj_supported(int N, int K, int dtype);
+size_t ampconv_proj_weight_image_bytes(int N, int K, int dtype);
+int ampconv_proj_weight_image(const void *W, int64_t stride_n, int64_t stride_k, int N, int K,
+                              void *image, int dtype, void *stream);
 typedef struct {
-  const float *W;
+  const void *W;
   int64_t stride_n, stride_k;
   int N, K;
   void *image;
 } ampconv_weight_image_t;
-int ampconv_proj_weight_images(int count, const ampconv_weight_image_t *jobs, void *stream);
-int ampconv_proj_rows(const float *A, int64_t lda, int64_t M, int K, const void *wimage, int N,
-                      const float *bias, const int32_t *rowptr, int L, float *out, int64_t ldc,
-                      void *stream);
-size_t ampconv_proj_wgrad_workspace_bytes(int64_t M, int Na, int Nb);
-int ampconv_proj_wgrad(const float *A, int64_t lda, const float *B, int64_t ldb, int64_t M, int Na,
-                       int Nb, const int32_t *rowptr, int L, float *dW, float *colsum,
-                       void *workspace, size_t workspace_bytes, void *stream);
+int ampconv_proj_weight_images(int count, const ampconv_weight_image_t *jobs, int dtype, void *stream);
+int ampconv_proj_rows(const void *A, int64_t lda, int64_t M, int K, const void *wimage, int N,
+                      const void *bias, const int32_t *rowptr, int L, void *out, int64_t ldc,
+                      int dtype, void *stream);
+size_t ampconv_proj_wgrad_workspace_bytes(int64_t M, int Na, int Nb, int dtype);
+int ampconv_proj_wgrad(const void *A, int64_t lda, const void *B, int64_t ldb, int64_t M, int Na,
+                       int Nb, const int32_t *rowptr, int L, void *dW, void *colsum,
+                       void *workspace, size_t workspace_bytes, int dtype, void *stream);
 
 /* ---- GraphSAINT random-walk sampler ("next" row: the step before the hot path) -------------
  * In-tree spec: the reference's vendored PyG sampler, visualization/visualize_graphsaint_subgraphs.py

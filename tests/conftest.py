@@ -11,7 +11,7 @@ if ROOT not in sys.path:
 
 GOLDEN_DIR = os.path.join(ROOT, 'tests', 'golden')
 
-# fp32 tolerance of SURVEY.md section 8c: atol 1e-5, rtol 1e-4 on y, dx, weights;
+# fp32 tolerance of SURVEY.md section 8c: FLAT atol 1e-5, rtol 1e-4 on y, dx, attention weights / outputs;
 # parameter gradients are sums over N*L rows, so their atol scales with the
 # magnitude of the gradient (see assert_close_scaled).
 ATOL, RTOL = 1e-5, 1e-4
@@ -40,17 +40,30 @@ def load_golden(path):
         return {k: z[k] for k in z.files}
 
 
-def assert_close_scaled(got, want, name, atol=ATOL, rtol=RTOL):
-    """allclose with atol scaled by max|want| for accumulated quantities."""
+# tensors whose entries are sums over all N*L node-token rows (the four parameter gradients): their absolute
+# tolerance scales with the magnitude of the gradient.  Everything else (y, dx, attention weights / outputs, logits,
+# embeddings) is held to the FLAT atol of SURVEY.md 8c.
+_ACCUMULATED = ('g_in_proj', 'g_out_proj', 'grad', 'in_proj_weight', 'in_proj_bias', 'out_proj')
+
+
+def assert_close_scaled(got, want, name, atol=ATOL, rtol=RTOL, scaled=None):
+    """allclose at `atol + rtol * |want|`; for accumulated quantities (parameter gradients, by name or `scaled=True`)
+    atol is multiplied by max(1, max|want|).  Prints the achieved maximum error and the share of the tolerance it
+    uses, so the head-room is visible in the test log (pytest -rP)."""
     got = np.asarray(got, dtype=np.float64)
     want = np.asarray(want, dtype=np.float64)
     assert got.shape == want.shape, f'{name}: shape {got.shape} vs {want.shape}'
-    scale = max(1.0, float(np.abs(want).max()) if want.size else 1.0)
+    if scaled is None:
+        scaled = any(k in name for k in _ACCUMULATED)
+    scale = max(1.0, float(np.abs(want).max()) if want.size else 1.0) if scaled else 1.0
     err = np.abs(got - want)
     tol = atol * scale + rtol * np.abs(want)
+    used = float((err / tol).max()) if err.size else 0.0
+    print(f'[tol] {name}: max err {float(err.max()) if err.size else 0.0:.3e}, {100 * used:.1f} % of the tolerance '
+          f'({"scaled" if scaled else "flat"} atol {atol * scale:.1e}, max |want| {float(np.abs(want).max()) if want.size else 0.0:.3e})')
     bad = err > tol
     assert not bad.any(), (f'{name}: {int(bad.sum())}/{bad.size} out of tolerance, '
-                           f'max err {err.max():.3e} (scale {scale:.3e})')
+                           f'max err {err.max():.3e} ({"scaled" if scaled else "flat"} atol {atol * scale:.1e})')
 
 
 @pytest.fixture(scope='session')

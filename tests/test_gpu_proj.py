@@ -1,4 +1,4 @@
-"""Node-phase projection kernels (csrc/proj_gemm.hip) through the C ABI against fp64 products.
+"""Node-phase projection kernels (csrc/proj_gemm.hip, csrc/proj_gemm_bf16.hip) through the C ABI against fp64 products.
 
 What they replace: torch functional.py:5785-5862 (`_in_projection_packed`), :6600 (out-projection) and
 their autograd backward.  Tolerance: the kernels are fp32-grade by construction (operands split exactly
@@ -129,11 +129,177 @@ def test_proj_wgrad_into_row_block_views():
 def test_unsupported_shapes_are_refused_not_miscomputed():
     from ampnet_amd import _lib
     lib = _lib.load()
-    assert lib.ampconv_proj_supported(256, 256) == 1 and lib.ampconv_proj_supported(768, 256) == 1
-    assert lib.ampconv_proj_supported(100, 100) == 1 and lib.ampconv_proj_supported(300, 100) == 1     # padded inside
-    assert lib.ampconv_proj_supported(3, 3) == 0 and lib.ampconv_proj_supported(102, 100) == 0         # not float4 rows
-    assert lib.ampconv_proj_rows(None, 100, 10, 100, None, 100, None, None, 0, None, 100, None) == -1  # null pointers
-    assert lib.ampconv_proj_rows(None, 3, 10, 3, None, 3, None, None, 0, None, 3, None) == -1
+    F32, BF16 = _lib.AMPCONV_F32, _lib.AMPCONV_BF16
+    assert lib.ampconv_proj_supported(256, 256, F32) == 1 and lib.ampconv_proj_supported(768, 256, F32) == 1
+    assert lib.ampconv_proj_supported(100, 100, F32) == 1 and lib.ampconv_proj_supported(300, 100, F32) == 1   # padded inside
+    assert lib.ampconv_proj_supported(3, 3, F32) == 0 and lib.ampconv_proj_supported(102, 100, F32) == 0       # not float4 rows
+    assert lib.ampconv_proj_supported(256, 256, BF16) == 1 and lib.ampconv_proj_supported(24, 72, BF16) == 1
+    assert lib.ampconv_proj_supported(100, 100, BF16) == 0      # bf16 rows move in pieces of 8 elements: library GEMM
+    assert lib.ampconv_proj_supported(256, 256, 7) == 0
+    assert lib.ampconv_proj_rows(None, 100, 10, 100, None, 100, None, None, 0, None, 100, F32, None) == -1  # null pointers
+    assert lib.ampconv_proj_rows(None, 3, 10, 3, None, 3, None, None, 0, None, 3, F32, None) == -1
+    assert lib.ampconv_proj_rows(None, 256, 10, 256, None, 256, None, None, 0, None, 256, BF16, None) == -1
+    assert lib.ampconv_proj_rows(None, 256, 10, 256, None, 256, None, None, 0, None, 256, 7, None) == -2   # dtype
+
+
+# ---- bf16 storage (csrc/proj_gemm_bf16.hip; BASELINE config 5).  One bf16 x bf16 product per element pair is exact in
+# fp32, the sum is fp32, the result is rounded to bf16 ONCE: the bar is half a bf16 ulp (2^-8 relative) of the fp64
+# product of the same bf16 inputs, plus the fp32 accumulation noise.
+def _bf16_close(out, ref, what):
+    err = (out.double() - ref).abs()
+    tol = 2.0 ** -8 * ref.abs() * 1.001 + 2e-5 * float(ref.abs().max()) + 1e-30
+    bad = err > tol
+    assert not bad.any(), f'{what}: {int(bad.sum())}/{bad.numel()} beyond half a bf16 ulp, max err {float(err.max()):.3e}'
+
+
+@pytest.mark.parametrize('M,K,N', [(5, 128, 128), (129, 128, 384), (1000, 256, 768), (4096, 768, 256),
+                                   (20 * 333, 256, 256), (777, 384, 128), (128 * 17, 256, 768),
+                                   # ragged: K not a multiple of 64, N not of 128 (tiles padded inside)
+                                   (260, 64, 192), (37, 8, 24), (333, 72, 40), (700, 200, 104), (501, 24, 72)])
+@pytest.mark.parametrize('transpose', [False, True])
+def test_proj_rows_bf16_matches_fp64(M, K, N, transpose):
+    from ampnet_amd.conv import functional as F_
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(M + K + N)
+    a = torch.randn(M, K, device=dev, generator=g).bfloat16()
+    W = (torch.randn(*((K, N) if transpose else (N, K)), device=dev, generator=g) * 0.1).bfloat16()
+    bias = torch.randn(N, device=dev, generator=g).bfloat16()
+    Wnk = W.t() if transpose else W
+    ref = a.double() @ Wnk.double().t() + bias.double()
+    out = F_.proj_rows(a, F_.proj_image(W, transpose=transpose), bias)
+    assert out.dtype == torch.bfloat16
+    _bf16_close(out, ref, 'rows + bias')
+    out2 = F_.proj_rows(a, F_.proj_image(W, transpose=transpose))
+    assert torch.equal(out2, F_.proj_rows(a, F_.proj_image(W, transpose=transpose)))      # bitwise reproducible
+    _bf16_close(out2, ref - bias.double(), 'rows')
+
+
+def test_proj_rows_bf16_strided_input_and_sliced_weight():
+    from ampnet_amd.conv import functional as F_
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(3)
+    D, M = 128, 300
+    w_in = (torch.randn(3 * D, D, device=dev, generator=g) * 0.1).bfloat16()
+    wide = torch.randn(M, 3 * D, device=dev, generator=g).bfloat16()
+    out = F_.proj_rows(wide[:, D:], F_.proj_image(w_in[D:], transpose=True))      # [M, 2D] @ [2D, D]
+    _bf16_close(out, wide[:, D:].double() @ w_in[D:].double(), 'strided rows')
+    # a row block that starts at an odd element (not 16-byte aligned): copied, not refused
+    out = F_.proj_rows(wide[:, 1:1 + D], F_.proj_image(w_in[:D], transpose=True))
+    _bf16_close(out, wide[:, 1:1 + D].double() @ w_in[:D].double(), 'unaligned rows')
+
+
+@pytest.mark.parametrize('L,empty', [(20, (0, 7, 49)), (1, (3,)), (7, ())])
+def test_proj_rows_bf16_mask_gives_exact_zero_rows(L, empty):
+    from ampnet_amd.conv import functional as F_
+    dev = _dev()
+    n_nodes, K, N = 50, 128, 256
+    rp, has = _rowptr(n_nodes, empty, dev)
+    g = torch.Generator(device=dev).manual_seed(L)
+    a = torch.randn(n_nodes * L, K, device=dev, generator=g).bfloat16()
+    W = (torch.randn(N, K, device=dev, generator=g) * 0.1).bfloat16()
+    bias = torch.randn(N, device=dev, generator=g).bfloat16()
+    out = F_.proj_rows(a, F_.proj_image(W), bias, rp, L).view(n_nodes, L * N)
+    ref = (a.double() @ W.double().t() + bias.double()).view(n_nodes, L * N) * has.to(dev)[:, None]
+    _bf16_close(out, ref, 'masked rows')
+    for n in empty:
+        assert (out[n] == 0).all()
+
+
+@pytest.mark.parametrize('M,Na,Nb', [(37, 128, 128), (20 * 271, 384, 128), (5000, 768, 256), (70001, 256, 256),
+                                     (999, 192, 64), (61, 24, 8), (20 * 40, 200, 104), (31, 256, 256), (20 * 1000, 72, 24)])
+@pytest.mark.parametrize('masked', [False, True])
+def test_proj_wgrad_bf16_matches_fp64(M, Na, Nb, masked):
+    from ampnet_amd.conv import functional as F_
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(M + Na)
+    a = torch.randn(M, Na, device=dev, generator=g).bfloat16()
+    b = torch.randn(M, Nb, device=dev, generator=g).bfloat16()
+    L = 20 if M % 20 == 0 else 1
+    rp = flag = None
+    if masked:
+        rp, has = _rowptr(M // L, (0, 5, M // L - 1), dev)
+        flag = has.to(dev).repeat_interleave(L)[:, None]
+        b = b * flag.to(b.dtype)        # bf16: the PRODUCT is unmasked; the layer's other operand (Obar) is 0 there
+    am = a.double() * flag.double() if masked else a.double()
+    ref_dw, ref_cs = am.t() @ b.double(), am.sum(0)
+    dw = torch.empty(Na, Nb, device=dev, dtype=torch.bfloat16)
+    cs = torch.empty(Na, device=dev, dtype=torch.bfloat16)
+    F_.proj_wgrad(a, b, dw, cs, rp, L)
+    # fp32 partial sums of exact products, ordered fp32 sum over the slices, one rounding: half an ulp + the fp32 noise of a
+    # sum of M terms of size ~1
+    noise = 4e-7 * M ** 0.5
+    err = (dw.double() - ref_dw).abs()
+    assert not (err > 2.0 ** -8 * ref_dw.abs() * 1.001 + noise).any(), float(err.max())
+    err = (cs.double() - ref_cs).abs()
+    assert not (err > 2.0 ** -8 * ref_cs.abs() * 1.001 + noise).any(), float(err.max())
+    dw2, cs2 = torch.empty_like(dw), torch.empty_like(cs)
+    F_.proj_wgrad(a, b, dw2, cs2, rp, L)
+    assert torch.equal(dw, dw2) and torch.equal(cs, cs2)            # fixed slices, ordered sum
+
+
+def test_proj_wgrad_bf16_masked_rows_do_not_leak_into_the_column_sums():
+    """NaN in a row whose node has no in-edge must not reach the (masked) column sums."""
+    from ampnet_amd.conv import functional as F_
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(2)
+    L, n_nodes, D = 20, 40, 256
+    rp, has = _rowptr(n_nodes, (3, 11), dev)
+    a = torch.randn(n_nodes * L, D, device=dev, generator=g).bfloat16()
+    b = torch.randn(n_nodes * L, D, device=dev, generator=g).bfloat16()
+    a[3 * L + 2, 17] = float('nan')
+    a[11 * L:12 * L] = float('inf')
+    b[3 * L:4 * L] = 0
+    b[11 * L:12 * L] = 0
+    dw = torch.empty(D, D, device=dev, dtype=torch.bfloat16)
+    cs = torch.empty(D, device=dev, dtype=torch.bfloat16)
+    F_.proj_wgrad(a, b, dw, cs, rp, L)
+    assert torch.isfinite(cs).all()
+    flag = has.to(dev).repeat_interleave(L)[:, None]
+    ref = torch.where(flag, a.double(), torch.zeros((), dtype=torch.float64, device=dev)).sum(0)
+    assert float((cs.double() - ref).abs().max()) <= 2.0 ** -8 * float(ref.abs().max()) + 1e-4
+
+
+def test_proj_wgrad_bf16_into_row_block_views():
+    from ampnet_amd.conv import functional as F_
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(11)
+    D, M = 128, 999
+    dq = torch.randn(M, D, device=dev, generator=g).bfloat16()
+    dkv = torch.randn(M, 2 * D, device=dev, generator=g).bfloat16()
+    x = torch.randn(M, D, device=dev, generator=g).bfloat16()
+    dw = torch.empty(3 * D, D, device=dev, dtype=torch.bfloat16)
+    db = torch.empty(3 * D, device=dev, dtype=torch.bfloat16)
+    F_.proj_wgrad(dq, x, dw[:D], db[:D])
+    F_.proj_wgrad(dkv, x, dw[D:], db[D:])
+    cat = torch.cat([dq, dkv], 1).double()
+    ref = cat.t() @ x.double()
+    assert float((dw.double() - ref).abs().max()) <= 2.0 ** -8 * float(ref.abs().max()) + 1e-4
+    assert float((db.double() - cat.sum(0)).abs().max()) <= 2.0 ** -8 * float(cat.sum(0).abs().max()) + 1e-4
+
+
+def test_bf16_layer_runs_no_library_gemm(monkeypatch):
+    """BASELINE config 5's storage mode end to end in HIP: with the default 'native' projections a
+    bf16 layer issues no torch GEMM, reduction or cast of its own -- torch.addmm / mm / bmm are made to raise."""
+    from ampnet_amd import AMPConv
+    dev = _dev()
+    torch.manual_seed(9)
+    N, E, L, D, H = 300, 2400, 20, 256, 8
+    layer = AMPConv(D, H).to(dev).to(torch.bfloat16)
+    x = torch.randn(N, L * D, device=dev).bfloat16().requires_grad_(True)
+    dy = torch.randn(N, L * D, device=dev).bfloat16()
+    ei = torch.randint(0, N, (2, E), device=dev)
+
+    def boom(*a, **k):
+        raise AssertionError('library GEMM called in native bf16 mode')
+    for name in ('addmm', 'mm', 'bmm', 'matmul'):
+        monkeypatch.setattr(torch, name, boom)
+    monkeypatch.setattr(torch.Tensor, 'mm', boom)
+    monkeypatch.setattr(torch.Tensor, 'matmul', boom)
+    y = layer(x, ei)
+    y.backward(dy)
+    m = layer.multi_head_attention
+    for t in (y, x.grad, m.in_proj_weight.grad, m.in_proj_bias.grad, m.out_proj.weight.grad, m.out_proj.bias.grad):
+        assert t.dtype == torch.bfloat16 and torch.isfinite(t).all()
 
 
 def test_layer_native_vs_library_gemm_error_table():

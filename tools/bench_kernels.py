@@ -1,6 +1,6 @@
 """Developer micro-benchmark: time each C-ABI edge kernel on a synthetic uniform graph.
 
-    python tools/bench_kernels.py [N E L D H] [--generic] [--bf16] [--mode=exact|bf16x6|bf16x9] [--hub] [--rmat] [--compact]
+    python tools/bench_kernels.py [N E L D H] [--generic] [--bf16] [--hub] [--rmat] [--compact]
 """
 import os
 import sys
@@ -33,10 +33,7 @@ def main():
     N, E, L, D, H = (int(x) for x in args) if len(args) == 5 else (100000, 1000000, 20, 256, 8)
     if '--generic' in sys.argv:
         os.environ['AMPCONV_FORCE_GENERIC'] = '1'
-    dt = 0
-    for a in sys.argv:
-        if a.startswith('--mode='):
-            dt = _lib.PRECISIONS[a.split('=')[1]]
+    dt = _lib.AMPCONV_F32
     dev = torch.device('cuda:0')
     lib = _lib.load()
     dh = D // H

@@ -1,7 +1,7 @@
 """Developer micro-benchmark of the node-phase projection kernels (csrc/proj_gemm.hip) against the
 library GEMMs they replace, at the row count of a workload (default: cfg4, N*L = 2e7 rows, D = 256).
 
-    python tools/bench_proj.py [rows D] [--iters=5]
+    python tools/bench_proj.py [rows D] [--iters=5] [--bf16] [--no-lib] [--only=rows]
 
 Prints per GEMM: ms, fp32-equivalent TFLOP/s (2 M N K / t), bf16 MFMA TFLOP/s actually issued (x6),
 and the max error against an fp64 product on a row sample."""
@@ -42,19 +42,26 @@ def main():
             only = a.split('=')[1]
     dev = torch.device('cuda:0')
     torch.manual_seed(0)
-    x = torch.randn(M, D, device=dev)
-    w_in = torch.randn(3 * D, D, device=dev) * 0.06
-    b_in = torch.randn(3 * D, device=dev) * 0.1
-    w_out = torch.randn(D, D, device=dev) * 0.06
-    qkv = torch.empty(M, 3 * D, device=dev)
+    bf16 = '--bf16' in sys.argv                   # bf16 storage (csrc/proj_gemm_bf16.hip): one product, HBM-bound
+    dt = torch.bfloat16 if bf16 else torch.float32
+    nprod = 1 if bf16 else 6
+    x = torch.empty(M, D, device=dev, dtype=dt)
+    qkv = torch.empty(M, 3 * D, device=dev, dtype=dt)
     for r0 in range(0, M, 1 << 20):
-        qkv[r0:r0 + (1 << 20)] = torch.randn(min(1 << 20, M - r0), 3 * D, device=dev)
+        n = min(1 << 20, M - r0)
+        x[r0:r0 + n] = torch.randn(n, D, device=dev)
+        qkv[r0:r0 + n] = torch.randn(n, 3 * D, device=dev)
+    w_in = (torch.randn(3 * D, D, device=dev) * 0.06).to(dt)
+    b_in = (torch.randn(3 * D, device=dev) * 0.1).to(dt)
+    w_out = (torch.randn(D, D, device=dev) * 0.06).to(dt)
     S = min(M, 4096)
+    es = x.element_size()
 
-    def report(name, t, flops, err=None, terr=None):
+    def report(name, t, flops, err=None, terr=None, nbytes=None):
         if t is None:
             return
-        print(f'{name:34s} {t:8.2f} ms  {flops / t / 1e9:7.1f} TF fp32-equiv  ({6 * flops / t / 1e9:7.0f} TF bf16 issued)'
+        print(f'{name:34s} {t:8.2f} ms  {flops / t / 1e9:7.1f} TF  ({nprod * flops / t / 1e9:7.0f} TF bf16 issued)'
+              + (f'  {nbytes / t / 1e9:6.2f} TB/s' if nbytes else '')
               + (f'  err {err:.2e} (library {terr:.2e})' if err is not None else ''), flush=True)
 
     _timeit = timeit
@@ -69,32 +76,34 @@ def main():
     img = F_.proj_image(w_in)
     t = timeit(lambda: F_.proj_rows(x, img, b_in), iters)
     ref = x[:S].double() @ w_in.double().t() + b_in.double()
-    report('qkv  native', t, 2 * M * D * 3 * D, err(F_.proj_rows(x[:S], img, b_in), ref), err(torch.addmm(b_in, x[:S], w_in.t()), ref))
-    report('qkv  library (addmm)', timeit_lib(lambda: torch.addmm(b_in, x, w_in.t()), iters), 2 * M * D * 3 * D)
+    report('qkv  native', t, 2 * M * D * 3 * D, err(F_.proj_rows(x[:S], img, b_in), ref), err(torch.addmm(b_in, x[:S], w_in.t()), ref),
+           nbytes=M * 4 * D * es)
+    report('qkv  library (addmm)', timeit_lib(lambda: torch.addmm(b_in, x, w_in.t()), iters), 2 * M * D * 3 * D, nbytes=M * 4 * D * es)
     # out-projection [M, D] x [D, D]
     img_o = F_.proj_image(w_out)
-    report('out  native', timeit(lambda: F_.proj_rows(x, img_o, b_in[:D]), iters), 2 * M * D * D)
-    report('out  library (addmm)', timeit_lib(lambda: torch.addmm(b_in[:D], x, w_out.t()), iters), 2 * M * D * D)
+    report('out  native', timeit(lambda: F_.proj_rows(x, img_o, b_in[:D]), iters), 2 * M * D * D, nbytes=M * 2 * D * es)
+    report('out  library (addmm)', timeit_lib(lambda: torch.addmm(b_in[:D], x, w_out.t()), iters), 2 * M * D * D, nbytes=M * 2 * D * es)
     # dX = dQKV Win  [M, 3D] x [3D, D]
     img_t = F_.proj_image(w_in, transpose=True)
     t = timeit(lambda: F_.proj_rows(qkv, img_t), iters)
     ref = qkv[:S].double() @ w_in.double()
-    report('dx   native', t, 2 * M * D * 3 * D, err(F_.proj_rows(qkv[:S], img_t), ref), err(qkv[:S].mm(w_in), ref))
-    report('dx   library (mm)', timeit_lib(lambda: qkv.mm(w_in), iters), 2 * M * D * 3 * D)
+    report('dx   native', t, 2 * M * D * 3 * D, err(F_.proj_rows(qkv[:S], img_t), ref), err(qkv[:S].mm(w_in), ref), nbytes=M * 4 * D * es)
+    report('dx   library (mm)', timeit_lib(lambda: qkv.mm(w_in), iters), 2 * M * D * 3 * D, nbytes=M * 4 * D * es)
     if only == 'rows':
         return
     # dW_in = dQKV^T X  [3D, M] x [M, D]
-    dw, cs = torch.empty(3 * D, D, device=dev), torch.empty(3 * D, device=dev)
+    dw, cs = torch.empty(3 * D, D, device=dev, dtype=dt), torch.empty(3 * D, device=dev, dtype=dt)
     t = timeit(lambda: F_.proj_wgrad(qkv, x, dw, cs), iters)
     Mr = min(M, 1 << 18)
     dwr, csr_ = torch.empty_like(dw), torch.empty_like(cs)
     F_.proj_wgrad(qkv[:Mr], x[:Mr], dwr, csr_)
     ref = qkv[:Mr].double().t() @ x[:Mr].double()
-    report('dWin native (+ colsum)', t, 2 * M * D * 3 * D, err(dwr, ref), err(qkv[:Mr].t().mm(x[:Mr]), ref))
-    report('dWin library (128-way bmm + sum)', timeit_lib(lambda: F_._tn_matmul(qkv, x), iters), 2 * M * D * 3 * D)
-    dwo, cso = torch.empty(D, D, device=dev), torch.empty(D, device=dev)
-    report('dWo  native (+ colsum)', timeit(lambda: F_.proj_wgrad(x, x, dwo, cso), iters), 2 * M * D * D)
-    report('dWo  library', timeit_lib(lambda: F_._tn_matmul(x, x), iters), 2 * M * D * D)
+    report('dWin native (+ colsum)', t, 2 * M * D * 3 * D, err(dwr, ref), err(qkv[:Mr].t().mm(x[:Mr]), ref), nbytes=M * 4 * D * es)
+    report('dWin library (128-way bmm + sum)', timeit_lib(lambda: F_._tn_matmul(qkv, x), iters), 2 * M * D * 3 * D, nbytes=M * 4 * D * es)
+    dwo, cso = torch.empty(D, D, device=dev, dtype=dt), torch.empty(D, device=dev, dtype=dt)
+    x2 = qkv[:, :D].contiguous()
+    report('dWo  native (+ colsum)', timeit(lambda: F_.proj_wgrad(x, x2, dwo, cso), iters), 2 * M * D * D, nbytes=M * 2 * D * es)
+    report('dWo  library', timeit_lib(lambda: F_._tn_matmul(x, x2), iters), 2 * M * D * D, nbytes=M * 2 * D * es)
     print('weight image (4 per step):', f'{timeit(lambda: F_.proj_image(w_in), 20):.4f} ms')
 
 
