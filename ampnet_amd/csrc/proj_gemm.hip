@@ -360,6 +360,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void proj_rows_kernel(RowsArgs a) 
       const float *fl_t = flags + par * BM;
       float *stage = reinterpret_cast<float *>(smem + kBuf + w * 4096);
       const int sr = lane >> 3, sc4 = lane & 7;
+      // the wave's bias entries, ALL before the first store: a load behind a store waits for that store's
+      // acknowledgement as well (vmcnt counts in issue order) -- loaded per sub-tile, each of the eight sub-tiles paid a
+      // store round trip plus an L2 round trip
+      float bj[NTW];
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) {
+        const int col = cur.col0 + (NTW * wn + j) * 32 + fr;
+        bj[j] = (a.bias && (!RAGGED || col < a.N)) ? a.bias[col] : 0.f;
+      }
       auto store_tile = [&](auto ragged) {
 #pragma unroll
         for (int i = 0; i < MTW; ++i) {
@@ -373,10 +382,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void proj_rows_kernel(RowsArgs a) 
 #pragma unroll
           for (int j = 0; j < NTW; ++j) {
             const int colt = cur.col0 + (NTW * wn + j) * 32;
-            const float bj = (a.bias && (!RAGGED || colt + fr < a.N)) ? a.bias[colt + fr] : 0.f;
 #pragma unroll
             for (int e = 0; e < 16; ++e)
-              stage[((e & 3) + 8 * (e >> 2) + 4 * fh) * 32 + fr] = (acc[i][j][e] + bj) * fl[e];
+              stage[((e & 3) + 8 * (e >> 2) + 4 * fh) * 32 + fr] = (acc[i][j][e] + bj[j]) * fl[e];
             float *o = a.out + (cur.row0 + rl0 + sr) * a.ldc + colt + 4 * sc4;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {

@@ -63,17 +63,23 @@ __global__ void weight_image_bf16_kernel(ImageJobsB jobs) {
 // proj_rows_bf16: 128 x BN output tiles per 256-thread workgroup (2 x 2 waves, each 64 x BN/2), two workgroups per
 // CU, PERSISTENT over a strided tile list whose consecutive slots on one XCD are the column tiles of one row tile
 // (its rows come from that XCD's L2 after the first read).  K runs in steps of 32 (two MFMAs per accumulator):
-//   W  step buffers Wb[2] (BN/32 x 2 KiB each): the image's fragments of one step, a linear copy
+//   W  a RING of three step buffers (BN/32 x 2 KiB each): the image's fragments of one step, a linear copy,
+//      requested TWO steps ahead (first version: one step ahead -- 2 400 cycles per step for 2 x 512 cycles of MFMA,
+//      every step waited for the L2 round trip of its own fragments)
 //   A  block buffers Ab[2] (128 rows x 128 bytes): a 64-deep line block of the tile's rows, piece q = rows
 //      8q .. 8q+7 as whole 128-byte lines (8 lines per DMA instruction); LDS slot (row, c) holds the line's 16-byte
 //      chunk c ^ ((row >> 1) & 7), so the fragment read of lane (r, h) -- chunk 2 pp + h of row r -- is conflict-free
 //      for ds_read_b128's lane groups
-// One barrier per step.  Issue order / waits of a wave (kWP, kAP = its DMA pieces per W step / A block):
-//   even step e: wait vmcnt(0), barrier, issue W(e+1) x kWP then A(block+1) x kAP, multiply step e
-//   odd  step o: wait vmcnt(kAP) [W(o) landed, A(block+1) stays in flight], barrier, issue W(o+1) x kWP, multiply step o
-// The last block of a tile requests the first W step / A block of the workgroup's NEXT tile; the store tail
-// waits for them (vmcnt(0)) BEFORE its first store, so the first step of the next tile opens with a bare barrier and
-// the stores retire behind that step's multiplies.
+// = 80 KiB per workgroup at BN = 256: two of them are exactly the CU's LDS (the row flags of the epilogue live in the
+// W buffer the tile's last step has freed).  One barrier per step.  Issue order / waits of a wave (kWP, kAP = its DMA
+// pieces per W step / A block):
+//   even step e: wait vmcnt(kWP)       [W(e), A(block) landed; W(e+1) stays in flight], barrier,
+//                issue W(e+2) x kWP then A(block+1) x kAP, multiply step e
+//   odd  step o: wait vmcnt(kWP + kAP) [W(o) landed; W(o+1), A(block+1) stay in flight], barrier,
+//                issue W(o+2) x kWP, multiply step o
+// The last two steps of a tile request the first two W steps / the first A block of the workgroup's NEXT tile; the
+// store tail waits for them (vmcnt(0)) BEFORE its first store, so the first block of the next tile opens with bare
+// barriers and the stores retire behind its multiplies (the first counted wait after them is two steps later).
 struct RowsArgsB {
   const __bf16 *A;
   int64_t lda;
@@ -99,10 +105,10 @@ __global__ __launch_bounds__(256, 2) void proj_rows_bf16_kernel(RowsArgsB a) {
   constexpr int kAB = BM * 128;                // one A block buffer
   constexpr int kWP = kWB / kFrag / NW;        // W pieces per wave and step
   constexpr int kAP = kAB / kFrag / NW;        // A pieces per wave and block
-  constexpr int oA = 2 * kWB, oF = oA + 2 * kAB;
-  static_assert(kWP >= 1 && kAP == 4 && NW * 4096 <= kAB, "tile / wave shape");
-  __shared__ __attribute__((aligned(16))) char smem[oF + BM * 4];     // ONE object: [Wb0][Wb1][Ab0][Ab1][row flags]
-  float *flags = reinterpret_cast<float *>(smem + oF);
+  constexpr int NWB = 3;                       // W ring
+  constexpr int oA = NWB * kWB;
+  static_assert(kWP >= 1 && kAP == 4 && NW * 4096 <= kAB && BM * 4 <= kWB, "tile / wave shape");
+  __shared__ __attribute__((aligned(16))) char smem[oA + 2 * kAB];     // ONE object: [W ring][Ab0][Ab1]
 
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -144,35 +150,52 @@ __global__ __launch_bounds__(256, 2) void proj_rows_bf16_kernel(RowsArgsB a) {
       arow[jj] = a.A + m * a.lda;
     }
   };
-  auto issue_a = [&](int kb, int abuf) {
+  // ONE DMA piece of an A block / a W step (the main loop hands them out between its MFMAs; the prologue takes whole sets)
+  auto issue_a_piece = [&](int kb, int abuf, int jj) {
     int off = kb * 64 + cg8;
     if (RAGGED) off = off < a.K ? off : 0;
-    const unsigned dst = lds0 + oA + abuf * kAB + w * kFrag;
-#pragma unroll
-    for (int jj = 0; jj < kAP; ++jj) dma16(arow[jj] + off, dst + NW * jj * kFrag);
+    dma16(arow[jj] + off, lds0 + oA + abuf * kAB + (w + NW * jj) * kFrag);
   };
-  auto issue_w = [&](int col0, int step, int wbuf) {
-    const char *src = a.wimg + (size_t)(col0 / 32) * kStepB + (size_t)step * wstep + w * kFrag + lane * 16;
-    const unsigned dst = lds0 + wbuf * kWB + w * kFrag;
-#pragma unroll
-    for (int j = 0; j < kWP; ++j) dma16(src + NW * j * kFrag, dst + NW * j * kFrag);
+  auto issue_w_piece = [&](int col0, int step, int wbuf, int j) {
+    const char *src = a.wimg + (size_t)(col0 / 32) * kStepB + (size_t)step * wstep + (w + NW * j) * kFrag + lane * 16;
+    dma16(src, lds0 + wbuf * kWB + (w + NW * j) * kFrag);
   };
   f32x16 acc[MTW][NTW];
-  auto multiply = [&](auto wbuf_c, auto par_c, int aoff) {       // W buffer and step parity are compile-time
-    constexpr int wbuf = decltype(wbuf_c)::value, par = decltype(par_c)::value;
+  // One 32-deep step: 2 x MTW x NTW MFMAs.  The step's NPc DMA pieces are issued BETWEEN the MFMAs, one every
+  // NM / NPc products (pinned with sched_barrier): issued in one burst behind the barrier -- eight waves at once -- every
+  // piece waits for the address path of all the others (~150 cycles each, in front of the step's first fragment read)
+  auto multiply = [&](auto par_c, int woff, int aoff, auto npc_c, auto &&piece) {
+    constexpr int par = decltype(par_c)::value, NPc = decltype(npc_c)::value;
+    constexpr int NM = 2 * MTW * NTW;
+    i32x4 af[2][MTW], bf[2][NTW];
+    auto fragments = [&](auto p_c) {
+      constexpr int p = decltype(p_c)::value;
 #pragma unroll
-    for (int p = 0; p < 2; ++p) {
-      i32x4 af[MTW], bf[NTW];
-#pragma unroll
-      for (int i = 0; i < MTW; ++i) af[i] = *reinterpret_cast<const i32x4 *>(smem + aoff + ard[2 * par + p] + i * 4096);
+      for (int i = 0; i < MTW; ++i)
+        af[p][i] = *reinterpret_cast<const i32x4 *>(smem + aoff + ard[2 * par + p] + i * 4096);
 #pragma unroll
       for (int j = 0; j < NTW; ++j)
-        bf[j] = *reinterpret_cast<const i32x4 *>(smem + wbuf * kWB + brd + j * kStepB + p * kFrag);
+        bf[p][j] = *reinterpret_cast<const i32x4 *>(smem + woff + brd + j * kStepB + p * kFrag);
+    };
+    fragments(std::integral_constant<int, 0>{});
+    int c = 0;
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
 #pragma unroll
       for (int i = 0; i < MTW; ++i)
 #pragma unroll
-        for (int j = 0; j < NTW; ++j) acc[i][j] = MFMA32(af[i], bf[j], acc[i][j]);
-    }
+        for (int j = 0; j < NTW; ++j) {
+          acc[i][j] = MFMA32(af[p][i], bf[p][j], acc[i][j]);
+          ++c;
+          if (c == NM / 4) fragments(std::integral_constant<int, 1>{});      // second half's fragments, a quarter ahead
+#pragma unroll
+          for (int k = 0; k < NPc; ++k)
+            if (c == k * NM / NPc + 1) {
+              __builtin_amdgcn_sched_barrier(0);
+              piece(k);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+        }
   };
 
   int64_t u = blockIdx.x;
@@ -181,10 +204,20 @@ __global__ __launch_bounds__(256, 2) void proj_rows_bf16_kernel(RowsArgsB a) {
   Tile nxt = tile_of(u + gridDim.x);
   const int KB = a.Kp / 64;
   int ab = 0;                    // A buffer of the block about to be multiplied
+  int wb = 0;                    // W ring slot of the step about to be multiplied
   rebase(cur);
-  issue_w(cur.col0, 0, 0);
-  issue_a(0, 0);
+#pragma unroll
+  for (int j = 0; j < kWP; ++j) issue_w_piece(cur.col0, 0, 0, j);
+#pragma unroll
+  for (int j = 0; j < kWP; ++j) issue_w_piece(cur.col0, 1, 1, j);
+#pragma unroll
+  for (int jj = 0; jj < kAP; ++jj) issue_a_piece(0, 0, jj);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  // W step `st` (counted from the current tile's first step) -> its tile's first column and its step there
+  auto w_col = [&](int st) { return st < 2 * KB ? cur.col0 : (nxt.valid ? nxt.col0 : cur.col0); };
+  auto w_step = [&](int st) { return st < 2 * KB ? st : st - 2 * KB; };
+  auto ring = [](int x) { return x >= NWB ? x - NWB : x; };
 
   for (;;) {
 #pragma unroll
@@ -197,17 +230,24 @@ __global__ __launch_bounds__(256, 2) void proj_rows_bf16_kernel(RowsArgsB a) {
     unsigned braw[NTW];            // requested in the tile's last step, first USED behind the tail's wait
     for (int kb = 0; kb < KB; ++kb) {
       const bool last = kb + 1 == KB;
-      // ---- even step: W in Wb0, A halves 0, 1 of Ab[ab].  (kb == 0: the tail of the previous tile, or the prologue,
-      // has already waited for this step's DMAs)
-      if (kb != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // ---- even step: A halves 0, 1 of Ab[ab].  (kb == 0: the tail of the previous tile, or the prologue, has
+      // already waited for both steps of this block)
+      if (kb != 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kWP) : "memory");
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      issue_w(cur.col0, 2 * kb + 1, 1);
       if (last) rebase(nxt.valid ? nxt : cur);      // past the end of the work list the refill is harmless
-      issue_a(last ? 0 : kb + 1, ab ^ 1);
-      multiply(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, ab * kAB);
-      // ---- odd step: W in Wb1, A halves 2, 3; the A block requested above stays in flight
-      asm volatile("s_waitcnt vmcnt(%0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::"n"(kAP) : "memory");
-      issue_w(last ? (nxt.valid ? nxt.col0 : cur.col0) : cur.col0, last ? 0 : 2 * kb + 2, 0);
+      {
+        const int wc = w_col(2 * kb + 2), ws = w_step(2 * kb + 2), wr = ring(wb + 2), an = last ? 0 : kb + 1;
+        multiply(std::integral_constant<int, 0>{}, wb * kWB, ab * kAB, std::integral_constant<int, kWP + kAP>{},
+                 [&](int k) {
+                   if (k < kWP) issue_w_piece(wc, ws, wr, k);
+                   else issue_a_piece(an, ab ^ 1, k - kWP);
+                 });
+      }
+      wb = ring(wb + 1);
+      // ---- odd step: A halves 2, 3
+      if (kb != 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kWP + kAP) : "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      const int wc1 = w_col(2 * kb + 3), ws1 = w_step(2 * kb + 3), wr1 = ring(wb + 2);
       if (last) {
         // epilogue operands of THIS tile: ordinary loads issued after every DMA of the step; their values pass
         // through an empty asm in the tail, so the compiler's wait for them sits there and not here
@@ -228,18 +268,25 @@ __global__ __launch_bounds__(256, 2) void proj_rows_bf16_kernel(RowsArgsB a) {
           braw[j] = (unsigned)bf16_bits(bp);
         }
       }
-      multiply(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, ab * kAB);
+      multiply(std::integral_constant<int, 1>{}, wb * kWB, ab * kAB, std::integral_constant<int, kWP>{},
+               [&](int k) { issue_w_piece(wc1, ws1, wr1, k); });
+      wb = ring(wb + 1);
       ab ^= 1;
     }
     asm volatile("" : "+v"(rp0), "+v"(rp1));
-    if (a.rowptr) flags[t & (BM - 1)] = rp1 != rp0 ? 1.f : 0.f;     // both halves of the workgroup write the same values
-    // ---- store tail.  Everything this wave has requested (first step of the next tile) must have landed before the
-    // stores go out: the next even step then needs no wait of its own.  C/D register e of lane (col = lane & 31,
-    // hi = lane >> 5) is row (e & 3) + 8 (e >> 2) + 4 hi of a 32 x 32 tile: bias and row mask applied in that layout,
-    // then the tile goes through a wave-private 4 KiB of the A buffer the last block was multiplied from (free once
-    // every wave has passed the barrier; the next tile's block 0 went to the other one) as fp32 and leaves as bf16,
-    // 16 rows x 64 bytes per store instruction.
+    // ---- store tail.  Everything this wave has requested (first block of the next tile) must have landed before the
+    // stores go out: the next block then needs no wait of its own.  The row flags go through the W slot the last step
+    // was multiplied from (ring slot wb + 2: free once every wave has passed the barrier).  C/D register e of lane
+    // (col = lane & 31, hi = lane >> 5) is row (e & 3) + 8 (e >> 2) + 4 hi of a 32 x 32 tile: bias and row mask applied
+    // in that layout, then the tile goes through a wave-private 4 KiB of the A buffer the last block was multiplied
+    // from (the next tile's block 0 went to the other one) as fp32 and leaves as bf16, 16 rows x 64 bytes per store
+    // instruction.
     asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    float *flags = reinterpret_cast<float *>(smem + ring(wb + 2) * kWB);
+    if (a.rowptr) {
+      flags[t & (BM - 1)] = rp1 != rp0 ? 1.f : 0.f;      // both halves of the workgroup write the same values
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
     {
       float *stage = reinterpret_cast<float *>(smem + oA + (ab ^ 1) * kAB + w * 4096);
       const int sr = lane >> 2, sc = lane & 3;

@@ -10,18 +10,20 @@ shape (one-subgraph-per-GPU data parallelism, weak scaling) and the parameter
 gradients are averaged with one RCCL all-reduce per step inside the timed
 region (experiments/cora_benchmark_graphsaint_distributed.py:63-94 as intended).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg4|cfg3|cfg5|cora|tiny] [--dtype f32|bf16] [--gemm native|fp32|bf16x3]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg4|cfg3|cfg3-L1|cfg3-L4|cfg5|cora|ampgcn-default|cfg4-saint|tiny] [--dtype f32|bf16] [--gemm native|fp32|bf16x3]
 
 Prints ONE JSON line on rank 0.  `roofline` prices the dominant kernel against
 the 8 TB/s HBM3E spec peak with durations measured live by HIP events on the
 launch stream over the timed region; `cpu_baseline` is the reference-shaped CPU
 restatement (oracle/ampconv_torch.py) timed on the host cores on a bounded
 sub-sample of the same workload (rank 0, N=1 only).  Beside the headline the line
-carries: `saint` (N > 1: BASELINE config 4 as written -- the resident graph, one
+carries: `saint` (every N: BASELINE config 4 as written -- the resident graph, one
 GraphSAINT subgraph per rank per step -- measured on the same ranks right after
-the full-graph pass), `extra_workloads` (N = 1: configs 3 and 5, a few steps each),
-`alt_gemm` (the same step on the library's fp32 GEMMs) and per-rank kernel and
-all-reduce times, so that one line diagnoses a scaling run.
+the full-graph pass), `extra_workloads` (N = 1: configs 3 and 5, the L = 1 / L = 4
+sweeps of config 3, the Cora-sized config 1/2 shape and the reference's class-default
+layer shape, a few steps each), `alt_gemm` (the same step on the library's fp32 GEMMs),
+`dist` (backend, world size and the number of ranks an all-reduce of ones saw) and
+per-rank kernel and all-reduce times, so that one line diagnoses a scaling run.
 """
 import argparse
 import json
@@ -45,6 +47,13 @@ WORKLOADS = {
              'BASELINE config 5: RMAT (0.57,0.19,0.19,0.05) scale 21 = 2.1M nodes / 40M edges, L=20, D=256, H=8, '
              'bf16 storage'),
     'cora': (2708, 10556, 20, 128, 4, 'BASELINE config 1/2 shape: Cora-sized random graph, L=20, D=128, H=4'),
+    # the L sweeps of config 3 (BASELINE.md section 4 has a roofline row for L = 1)
+    'cfg3-L1': (100_000, 1_000_000, 1, 128, 8, 'BASELINE config 3, L = 1 sweep: 100k nodes / 1M edges, L=1, D=128, H=8'),
+    'cfg3-L4': (100_000, 1_000_000, 4, 128, 8, 'BASELINE config 3, L = 4 sweep: 100k nodes / 1M edges, L=4, D=128, H=8'),
+    # the shape the reference's own scripts instantiate: AMPGCN class defaults (src/ampnet/module/amp_gcn.py:21-35,
+    # experiments/cora_benchmark_graphsaint_distributed.py:58, cora_benchmark_full.py:46) on a config-3-sized graph
+    'ampgcn-default': (100_000, 1_000_000, 40, 100, 2,
+                       'AMPGCN class-default layer shape (L=40, D=100, H=2: amp_gcn.py:21-35) on 100k nodes / 1M edges'),
     'tiny': (2000, 20000, 20, 256, 8, 'smoke-sized graph of the config-4 layer shape'),
     # GraphSAINT batches (BASELINE config 4 as written): the graph and its features stay resident, every step
     # draws one random-walk subgraph per rank (experiments/cora_benchmark_graphsaint.py:80-82,96-116)
@@ -667,22 +676,32 @@ def main():
         out = measure_full(args.workload, args.steps, args.warmup, args, rank, world, dev, dist_on, dt_name, alt=alt)
         side = not args.no_extra and not args.softmax_free and args.dtype is None
         saint_of = {'cfg4': 'cfg4-saint', 'tiny': 'tiny-saint'}
-        if side and dist_on and args.workload in saint_of:
-            # BASELINE config 4 as written, on the same ranks: the mode whose scaling curve can bend
-            # (34 ms steps, sampler read-backs, a 1 MB all-reduce)
+        if side and args.workload in saint_of:
+            # BASELINE config 4 as written, on the same ranks (every N, one rank included): the mode whose scaling curve
+            # can bend (27 ms steps, sampler read-backs, a 1 MB all-reduce)
             s = measure_saint(saint_of[args.workload], max(20, args.steps), max(2, args.warmup), args, rank, world, dev,
                               dist_on, 'f32')
             out['saint'] = {k: s[k] for k in ('value', 'unit', 'ms_per_step', 'steps', 'nodes_avg', 'edges_avg',
                                               'sampler_ms', 'allreduce_ms', 'kernels_ms', 'per_rank_ms')}
             out['saint']['workload'] = s['config']['workload']
-        if side and world == 1 and args.workload == 'cfg4':
-            # the other full-size configurations, driver-observed: a few steps each
+        if side and world == 1 and args.workload in ('cfg4', 'tiny'):
+            # the other configurations, driver-observed: a few steps each (the small ones: more steps, they are
+            # launch-bound and cheap).  `tiny`: the same code path on smoke-sized stand-ins (tests)
+            extra = ((('cfg3', 3), ('cfg5', 3), ('cfg3-L1', 20), ('cfg3-L4', 10), ('cora', 50), ('ampgcn-default', 3))
+                     if args.workload == 'cfg4' else (('cora', 5),))
             out['extra_workloads'] = {
-                w: _brief(measure_full(w, 3, 1, args, rank, world, dev, dist_on, 'bf16' if w == 'cfg5' else 'f32'))
-                for w in ('cfg3', 'cfg5')}
+                w: _brief(measure_full(w, k, 1 if k < 20 else 3, args, rank, world, dev, dist_on,
+                                       'bf16' if w == 'cfg5' else 'f32'))
+                for w, k in extra}
         if world == 1 and not args.no_cpu_baseline and not args.softmax_free and rank == 0:
             N, E, L, D, H, _ = WORKLOADS[args.workload]
             out['cpu_baseline'] = cpu_baseline(L, D, H, E / N)
+    if dist_on:
+        # evidence, in the line itself, that the collective library saw every rank: an all-reduce of ones
+        seen = torch.ones(1, device=dev)
+        dist.all_reduce(seen)
+        out['dist'] = {'backend': dist.get_backend(), 'world_size': dist.get_world_size(),
+                       'ranks_seen': int(seen.item())}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist_on:

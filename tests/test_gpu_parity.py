@@ -573,7 +573,10 @@ def test_random_shapes_mfma_vs_generic(seed, family, dev, monkeypatch):
     monkeypatch.setenv('AMPCONV_FORCE_GENERIC', '1')
     slow = run()
     for name, a, b in zip(['y', 'dx', 'gWin', 'gbin', 'gWo', 'gbo'], fast, slow):
-        assert_close_scaled(a, b, f'{name} (N={N} E={E} L={L} D={D} H={H} kind={kind})')
+        # kind 2: every edge leaves ONE node, whose dx row is a sum over all E edges -- an accumulated quantity like the
+        # parameter gradients (two fp32 summation orders differ by ~1e-6 of its magnitude, 2-3e-5 absolute here)
+        assert_close_scaled(a, b, f'{name} (N={N} E={E} L={L} D={D} H={H} kind={kind})',
+                            scaled=True if (name == 'dx' and kind == 2) else None)
 
 
 @pytest.mark.parametrize('shape', [(900, 9000, 20, 256, 8), (500, 6000, 13, 64, 4), (400, 5000, 20, 64, 4),
@@ -621,7 +624,6 @@ def test_softmax_stats_rejected_where_unsupported(dev):
     assert lib.ampconv_softmax_stats_bytes(1000, 2, 3, 1, _lib.AMPCONV_F32) == 0          # odd dh
     assert lib.ampconv_softmax_stats_bytes(1000, 40, 100, 2, _lib.AMPCONV_F32) == 1000 * 2 * 2 * 48 * 4   # edge_block.hip
     assert lib.ampconv_softmax_stats_bytes(1000, 20, 256, 8, _lib.AMPCONV_BF16) == 0      # HBM-bound: no gain
-    assert lib.ampconv_softmax_stats_bytes(1000, 20, 256, 8, _lib.AMPCONV_F32_BF16X6) == 0
 
 
 @pytest.mark.parametrize('shape', [(260, 2600, 17, 64, 2), (260, 2600, 18, 128, 8), (260, 2600, 19, 96, 3),
@@ -696,7 +698,10 @@ def test_batched_tail_kernels_large_scores(dev, monkeypatch):
     monkeypatch.setenv('AMPCONV_FORCE_GENERIC', '1')
     slow = run()
     for name, a, b in zip(['y', 'dx', 'gWin', 'gWo'], fast, slow):
-        assert_close_scaled(a, b, name, atol=3e-5, rtol=3e-4)      # saturated softmaxes amplify rounding
+        # saturated softmaxes amplify rounding: scores of magnitude ~500 carry an absolute fp32 error of ~3e-5, which is
+        # the RELATIVE error of the probabilities next to a tie; two implementations that round the scores differently
+        # differ by that much of the output's magnitude -- magnitude-scaled tolerance for this cross-check
+        assert_close_scaled(a, b, name, atol=3e-5, rtol=3e-4, scaled=True)
 
 
 @pytest.mark.parametrize('shape', [(300, 3000, 40, 100, 2), (300, 3000, 24, 128, 2)], ids=['L40_dh50', 'L24_dh64'])
@@ -838,6 +843,8 @@ def test_bench_launches_two_ranks(dev):
     saint = out['saint']
     assert saint['steps'] >= 20 and saint['value'] > 0 and saint['nodes_avg'] > 0 and saint['edges_avg'] > 0
     assert saint['sampler_ms'] > 0 and saint['allreduce_ms'] > 0 and len(saint['per_rank_ms']) == 2
+    # the line itself shows that the collective library saw both ranks
+    assert out['dist'] == {'backend': 'gloo', 'world_size': 2, 'ranks_seen': 2}
 
 
 @pytest.mark.parametrize('dtype', ['f32', 'bf16'])
@@ -906,6 +913,31 @@ def test_bench_rccl_path_single_rank(dev):
     assert out['n_gpus'] == 1 and out['value'] > 0
     assert out['allreduce_ms'] > 0 and out['saint']['allreduce_ms'] > 0         # both RCCL all-reduces ran
     assert out['edge_phase_hbm']['frac_of_8TBps'] > 0 and 'traffic_source' in out['roofline']
+    assert out['dist'] == {'backend': 'nccl', 'world_size': 1, 'ranks_seen': 1}
+    # one rank: the side measurements of the default N = 1 line run as well (a Cora-sized stand-in here)
+    assert out['extra_workloads']['cora']['value'] > 0
+
+
+def test_bench_default_line_carries_saint_and_extras_without_a_process_group(dev):
+    """the plain N = 1 run (no process group) measures the GraphSAINT-batch mode and the extra
+    workloads too; stdout stays ONE JSON line."""
+    import json
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_PORT', 'AMPCONV_BENCH_FORCE_DIST'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--workload', 'tiny', '--steps', '2', '--warmup', '1',
+                        '--no-cpu-baseline', '--no-alt-gemm'], env=env, timeout=600, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert 'dist' not in out and out['n_gpus'] == 1
+    assert out['saint']['steps'] >= 20 and out['saint']['value'] > 0 and out['saint']['allreduce_ms'] == 0
+    assert out['extra_workloads']['cora']['ms_per_step'] > 0
 
 
 def test_nt4_kernels_match_round1_tiling(dev, tmp_path):

@@ -1,8 +1,12 @@
 """Developer experiment: do the fp32 projection GEMMs (matrix-pipe bound) and the edge kernels (HBM /
 latency bound, matrix pipe ~50 % busy) overlap when issued on two HIP streams?
 
-    python tools/bench_overlap.py [N E]
-Times (a) the two backward edge passes alone, (b) a set of GEMMs alone, (c) both concurrently."""
+    python tools/bench_overlap.py [N E] [--native] [--edges-first] [--cu-split=64,96,128]
+Times (a) the two backward edge passes alone, (b) a set of GEMMs alone, (c) both concurrently.
+--cu-split=K,...: the same with CU-MASKED streams (hipExtStreamCreateWithCUMask): the projections on K of the 256 CUs,
+the edge passes on the other 256 - K (a power-limited GEMM on fewer CUs holds a higher clock, a
+latency-bound gather on fewer CUs sees more HBM per CU)."""
+import ctypes
 import os
 import sys
 
@@ -72,6 +76,47 @@ def main():
         return e0.elapsed_time(e1) / iters
 
     flop = 2 * N * L * D * D
+    splits = [int(v) for a in sys.argv if a.startswith('--cu-split=') for v in a.split('=')[1].split(',')]
+    if splits:
+        hip = ctypes.CDLL('libamdhip64.so')
+
+        def masked_stream(cus):
+            """Stream restricted to the CUs whose bit is set (bit i: the runtime deals the bits to the shader engines
+            round-robin, so a prefix of the bits is spread evenly over the XCDs)."""
+            words = (ctypes.c_uint32 * 8)(*[sum(1 << b for b in range(32) if 32 * w + b in cus) for w in range(8)])
+            st = ctypes.c_void_p()
+            rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), 8, words)
+            assert rc == 0, rc
+            return torch.cuda.ExternalStream(st.value)
+
+        t_e, t_g = timed(edges), timed(lambda: gemms(4))
+        print(f'N={N} E={E}: whole chip: edge passes {t_e:.2f} ms | 4 projection launches {t_g:.2f} ms | serial {t_e + t_g:.2f} ms')
+        for k in splits:
+            sg, se = masked_stream(set(range(k))), masked_stream(set(range(k, 256)))
+
+            def on(stream, fn):
+                cur = torch.cuda.current_stream()
+                stream.wait_stream(cur)
+                with torch.cuda.stream(stream):
+                    fn()
+                cur.wait_stream(stream)
+            t_em = timed(lambda: on(se, edges))
+            t_gm = timed(lambda: on(sg, lambda: gemms(4)))
+
+            def both():
+                cur = torch.cuda.current_stream()
+                sg.wait_stream(cur)
+                se.wait_stream(cur)
+                with torch.cuda.stream(sg):
+                    gemms(4)
+                with torch.cuda.stream(se):
+                    edges()
+                cur.wait_stream(sg)
+                cur.wait_stream(se)
+            t_b = timed(both)
+            print(f'  projections on {k} CUs {t_gm:.2f} ms alone, edge passes on {256 - k} CUs {t_em:.2f} ms alone | '
+                  f'concurrent {t_b:.2f} ms = {t_b / (t_e + t_g):.3f} x the whole-chip serial sum')
+        return
     t_e = timed(edges)
     for k in (2, 4, 6):
         t_g = timed(lambda: gemms(k))

@@ -168,6 +168,12 @@ int main() {
   run_two("MFMA32 + v_fma (same SIMDs)", 3, 2, 1);
   run_two("MFMA16 + v_cvt (same SIMDs)", 3, 0, 3);
   run_two("MFMA16 + v_exp (same SIMDs)", 3, 0, 5);
+  // does the fp32-input MFMA of one wave (the edge kernels) co-issue with the bf16 MFMA of another
+  // wave (the projections) on the same SIMD, or do the two serialise on the matrix port?
+  run_two("fp32 MFMA16x16x4 (lo) + bf16 MFMA16x16x32 (hi) (same SIMDs)", 3, 7, 0);
+  run_two("fp32 MFMA16x16x4 (lo) + bf16 MFMA32x32x16 (hi) (same SIMDs)", 3, 7, 2);
+  run_two("fp32 16x16x4 chain + 4x4x1 (lo) + bf16 MFMA16x16x32 (hi)", 3, 9, 0);
+  run_two("fp32 16x16x4 chain + 4x4x1 (lo) + bf16 MFMA32x32x16 (hi)", 3, 9, 2);
   run_one<0>(); run_one<4>(); run_one<8>(); run_one<12>(); run_one<16>(); run_one<24>();
   return 0;
 }

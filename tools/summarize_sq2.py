@@ -11,7 +11,7 @@ import re
 import sys
 
 KERNELS = (('fwd', r'\bfwd_(mfma|bf16|split)'), ('bwd_dst', r'\bbwd_dst_(mfma|bf16|split)'), ('bwd_src', r'\bbwd_src_(mfma|bf16|split)'),
-           ('proj_rows', r'proj_rows_kernel'), ('proj_wgrad', r'proj_wgrad_kernel'))
+           ('proj_rows', r'proj_rows_(bf16_)?kernel'), ('proj_wgrad', r'proj_wgrad_(bf16_)?kernel'))
 
 
 def load(path):
@@ -44,6 +44,11 @@ def main():
         clock = c['GRBM_GUI_ACTIVE'] / 8 / t
         wc = c['SQ_WAVE_CYCLES']
         f = lambda n: c.get(n, float('nan')) / wc
+        for n in ('FETCH_SIZE', 'WRITE_SIZE'):          # KiB per launch (MI355X_MICROARCH.md: wide reads count half on gfx950)
+            if n in c:
+                print(f"{k:8s} {n} {c[n] * 1024 / 1e9:.2f} GB per launch" + (' (x2 for 16-byte-per-lane reads)' if n == 'FETCH_SIZE' else ''))
+        if 'SQ_WAVE_CYCLES' not in c:
+            continue
         print(f"{k:8s} {c['_ms']:7.2f} ms clock {clock / 1e9:.2f} GHz | wait {f('SQ_WAIT_ANY'):.2f} issue-stall {f('SQ_WAIT_INST_ANY'):.2f} "
               f"(lds {f('SQ_WAIT_INST_LDS'):.2f}) issuing {f('SQ_ACTIVE_INST_ANY'):.2f} valu {f('SQ_ACTIVE_INST_VALU'):.2f} "
               f"lds {f('SQ_ACTIVE_INST_LDS'):.2f} vmem {f('SQ_ACTIVE_INST_VMEM'):.2f} | mfma_busy "
