@@ -185,7 +185,11 @@ __global__ __launch_bounds__(256, 2) void proj_rows_bf16_kernel(RowsArgsB a) {
       for (int i = 0; i < MTW; ++i)
 #pragma unroll
         for (int j = 0; j < NTW; ++j) {
+#ifdef AMPCONV_PROJ_ABLATE_MFMA        // timing-only developer build: fragments read, nothing multiplied
+          asm volatile("" ::"v"(af[p][i]), "v"(bf[p][j]));
+#else
           acc[i][j] = MFMA32(af[p][i], bf[p][j], acc[i][j]);
+#endif
           ++c;
           if (c == NM / 4) fragments(std::integral_constant<int, 1>{});      // second half's fragments, a quarter ahead
 #pragma unroll
@@ -320,8 +324,12 @@ __global__ __launch_bounds__(256, 2) void proj_rows_bf16_kernel(RowsArgsB a) {
               const float4 v1 = *reinterpret_cast<const float4 *>(stage + row * 32 + 8 * sc + 4);
               const u32x4 pk = {cvt_pk_bf16(v0.x, v0.y), cvt_pk_bf16(v0.z, v0.w), cvt_pk_bf16(v1.x, v1.y),
                                 cvt_pk_bf16(v1.z, v1.w)};
+#ifdef AMPCONV_PROJ_ABLATE_STORES      // timing-only developer build: everything but the global stores
+              asm volatile("" ::"v"(pk));
+#else
               if ((!decltype(ragged_rows)::value || cur.row0 + rl0 + row < a.M) && (!RAGGED || colt + 8 * sc < a.N))
                 *reinterpret_cast<u32x4 *>(a.out + (cur.row0 + rl0 + row) * a.ldc + colt + 8 * sc) = pk;
+#endif
             }
           }
         }
