@@ -47,7 +47,7 @@ __device__ __forceinline__ float ld1(const Rows &r, int64_t off) {
   return r.bf ? bf_lo(reinterpret_cast<const unsigned short *>(r.p)[off]) : reinterpret_cast<const float *>(r.p)[off];
 }
 template <int VEC>
-__device__ __forceinline__ void ldv(float (&out)[VEC], const Rows &r, int64_t off) {
+__device__ __forceinline__ void ldv(float (&out)[VEC], const Rows &r, int off) {
   if (r.bf) {
     const unsigned short *q = reinterpret_cast<const unsigned short *>(r.p) + off;
     if constexpr (VEC == 4) {
@@ -87,6 +87,22 @@ __device__ __forceinline__ void b_rowop_lds(float (&op)[DHP / 4], const float *l
     op[4 * b + 0] = x.x; op[4 * b + 1] = x.y; op[4 * b + 2] = x.z; op[4 * b + 3] = x.w;
   }
 }
+// COLUMN operand of one token row: lane (m = lane & 15) takes the MC = DHP / 16 CONSECUTIVE channels MC m .. MC m + MC - 1
+// (one ds_read_b128 / b64 instead of MC ds_read_b32 at a stride of 16 channels), i.e. MFMA row m of channel tile mc is
+// channel MC m + mc.  A C/D tile [mc] then holds, in lane (n, g), register r: channel MC (4 g + r) + mc -- over (r, mc)
+// the 4 MC consecutive channels from 4 MC g: store_ct writes them as whole vectors.
+template <int DHP>
+__device__ __forceinline__ void b_colop_lds(float (&op)[DHP / 16], const float *lds, int row, int lane) {
+  const int m = lane & 15;
+  if constexpr (DHP == 64) {
+    const float4 x = *reinterpret_cast<const float4 *>(lds + row * DHP + ((m ^ bswz<DHP>(row)) << 2));
+    op[0] = x.x; op[1] = x.y; op[2] = x.z; op[3] = x.w;
+  } else {
+    const float2 x = *reinterpret_cast<const float2 *>(lds + bidx<DHP>(row, 2 * m));
+    op[0] = x.x; op[1] = x.y;
+  }
+}
+
 // ROW operand of token tile t straight from global memory (the unit's fixed side), scaled;
 // token rows >= L and channels >= dh read as zero
 template <int DHP>
@@ -116,12 +132,15 @@ __device__ __forceinline__ void stage_load(Stage<DHP, VEC> &s, const Rows &baseA
                                            int nthreads) {
   using S = Stage<DHP, VEC>;
   const int cv = tid % S::DVP, r0 = tid / S::DVP, RS = nthreads / S::DVP, c = cv * VEC;
+  // 32-bit element offsets from the (wave-uniform) tile base: one offset register per load instead of a 64-bit address
+  // pair per pass and tensor (a tile spans L rows: far below 2^31 elements)
+  const int sA = (int)strideA, sB = (int)strideB;
 #pragma unroll
   for (int i = 0; i < S::NP; ++i) {
     const int j = r0 + i * RS;
     if (j < L && c < dh) {
-      ldv<VEC>(s.v[0][i], baseA, (int64_t)j * strideA + c);
-      ldv<VEC>(s.v[1][i], baseB, (int64_t)j * strideB + c);
+      ldv<VEC>(s.v[0][i], baseA, j * sA + c);
+      ldv<VEC>(s.v[1][i], baseB, j * sB + c);
     }
   }
 }
@@ -149,32 +168,45 @@ __device__ __forceinline__ void stage_store(float *ldsA, float *ldsB, const Stag
   }
 }
 
-// C/D tile [channel tile mc][this wave's token tile] -> global rows of `v` (channels < dh, tokens < L); `bf`: bf16 rows
+// C/D tiles [channel tile mc][this wave's token tile] -> global rows of `v` (channels < dh, tokens < L); `bf`: bf16 rows.
+// Lane (token n = lane & 15, g = lane >> 4), register r of tile mc = channel MC (4 g + r) + mc (b_colop_lds): per r the
+// MC consecutive channels from MC (4 g + r) -- 4 MC consecutive channels per lane in all
 template <int DHP, int VEC>
 __device__ __forceinline__ void store_ct(const ampconv_view_t &v, int64_t node, int h, const f32x4 (&T)[DHP / 16],
                                          float scale, int tile, int L, int dh, int lane, bool bf) {
+  constexpr int MC = DHP / 16;
   const int i = (lane & 15) + 16 * tile, g = lane >> 4;
   if (i >= L) return;
   const int64_t row = node * v.node_stride + (int64_t)h * v.head_stride + (int64_t)i * v.row_stride;
 #pragma unroll
-  for (int mc = 0; mc < DHP / 16; ++mc) {
-    const int c = 4 * g + 16 * mc;
-    const float x0 = T[mc][0] * scale, x1 = T[mc][1] * scale, x2 = T[mc][2] * scale, x3 = T[mc][3] * scale;
+  for (int r = 0; r < 4; ++r) {
+    const int c = MC * (4 * g + r);
+    float x[MC];
+#pragma unroll
+    for (int mc = 0; mc < MC; ++mc) x[mc] = T[mc][r] * scale;
     if (bf) {
       unsigned short *ob = reinterpret_cast<unsigned short *>(v.ptr) + row + c;
-      if constexpr (VEC == 4) {
-        if (c < dh) *reinterpret_cast<uint2 *>(ob) = uint2{pk_bf16(x0, x1), pk_bf16(x2, x3)};
+      if constexpr (MC == 4) {
+        if constexpr (VEC == 4) {
+          if (c < dh) *reinterpret_cast<uint2 *>(ob) = uint2{pk_bf16(x[0], x[1]), pk_bf16(x[2], x[3])};
+        } else {
+          if (c < dh) *reinterpret_cast<unsigned *>(ob) = pk_bf16(x[0], x[1]);
+          if (c + 2 < dh) *reinterpret_cast<unsigned *>(ob + 2) = pk_bf16(x[2], x[3]);
+        }
       } else {
-        if (c < dh) *reinterpret_cast<unsigned *>(ob) = pk_bf16(x0, x1);
-        if (c + 2 < dh) *reinterpret_cast<unsigned *>(ob + 2) = pk_bf16(x2, x3);
+        if (c < dh) *reinterpret_cast<unsigned *>(ob) = pk_bf16(x[0], x[1]);
       }
     } else {
       float *ob = reinterpret_cast<float *>(v.ptr) + row + c;
-      if constexpr (VEC == 4) {
-        if (c < dh) *reinterpret_cast<float4 *>(ob) = make_float4(x0, x1, x2, x3);
+      if constexpr (MC == 4) {
+        if constexpr (VEC == 4) {
+          if (c < dh) *reinterpret_cast<float4 *>(ob) = make_float4(x[0], x[1], x[2], x[3]);
+        } else {
+          if (c < dh) *reinterpret_cast<float2 *>(ob) = make_float2(x[0], x[1]);
+          if (c + 2 < dh) *reinterpret_cast<float2 *>(ob + 2) = make_float2(x[2], x[3]);
+        }
       } else {
-        if (c < dh) *reinterpret_cast<float2 *>(ob) = make_float2(x0, x1);
-        if (c + 2 < dh) *reinterpret_cast<float2 *>(ob + 2) = make_float2(x2, x3);
+        if (c < dh) *reinterpret_cast<float2 *>(ob) = make_float2(x[0], x[1]);
       }
     }
   }
@@ -195,50 +227,50 @@ struct BArgs {
 
 // softmax over the source tokens (MFMA rows of every token tile t < ntok) of one destination-token
 // column; returns m + log2(sum).  S[t][q] = source token 16 t + 4 g + q.
-__device__ __forceinline__ float block_column_softmax(f32x4 (&S)[kMaxTok], int ntok, int L, int g) {
+template <int NT>
+__device__ __forceinline__ float block_column_softmax(f32x4 (&S)[NT], int L, int g) {
   float m = kNegBig;
 #pragma unroll
-  for (int t = 0; t < kMaxTok; ++t)
-    if (t < ntok) {
+  for (int t = 0; t < NT; ++t) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        if (16 * t + 4 * g + q >= L) S[t][q] = kNegBig;
-        m = fmaxf(m, S[t][q]);
-      }
+    for (int q = 0; q < 4; ++q) {
+      if (16 * t + 4 * g + q >= L) S[t][q] = kNegBig;
+      m = fmaxf(m, S[t][q]);
     }
+  }
   m = groups_max(m);
   float l = 0.f;
 #pragma unroll
-  for (int t = 0; t < kMaxTok; ++t)
-    if (t < ntok) {
+  for (int t = 0; t < NT; ++t) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        S[t][q] = fast_exp2(S[t][q] - m);
-        l += S[t][q];
-      }
+    for (int q = 0; q < 4; ++q) {
+      S[t][q] = fast_exp2(S[t][q] - m);
+      l += S[t][q];
     }
+  }
   l = groups_sum(l);
   const float inv = fast_rcp(l);
 #pragma unroll
-  for (int t = 0; t < kMaxTok; ++t)
-    if (t < ntok) {
+  for (int t = 0; t < NT; ++t) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) S[t][q] *= inv;
-    }
+    for (int q = 0; q < 4; ++q) S[t][q] *= inv;
+  }
   return m + __builtin_amdgcn_logf(l);
 }
 
 // ---------------------------------------------------------------- forward
-template <int DHP, int VEC>
-__global__ __launch_bounds__(256) void fwd_block(BArgs a) {
+template <int DHP, int VEC, int NT>
+__global__ __launch_bounds__(64 * NT) void fwd_block(BArgs a) {
   constexpr int KK = DHP / 4, MC = DHP / 16;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x;
+  const int tid = threadIdx.x, lane = tid & 63;
+  constexpr int nthreads = 64 * NT;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int64_t r, onode;
   int h, beg, end, deg;
   if (!map_unit(a.hub, a.ptr, blockIdx.x, a.n_units, a.H, r, onode, h, beg, end, deg)) return;    // block-uniform
-  const int L = a.L, dh = a.dh, ntok = a.ntok, g = lane >> 4;
+  constexpr int ntok = NT;
+  const int L = a.L, dh = a.dh, g = lane >> 4;
   const bool bf = a.bf16 != 0;
   float *Kt = lds, *Vt = lds + 16 * ntok * DHP;
   const int64_t d = a.qidx ? a.qidx[r] : r;
@@ -267,29 +299,26 @@ __global__ __launch_bounds__(256) void fwd_block(BArgs a) {
     if (p + 1 < end) fetch(p + 1);
     __syncthreads();
 
-    f32x4 S[kMaxTok];
+    f32x4 S[NT];
 #pragma unroll
-    for (int t = 0; t < kMaxTok; ++t)
-      if (t < ntok) {
-        float kA[KK];
-        b_rowop_lds<DHP>(kA, Kt, t, lane);
-        S[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NT; ++t) {
+      float kA[KK];
+      b_rowop_lds<DHP>(kA, Kt, t, lane);
+      S[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk) S[t] = MFMA16(kA[kk], qB[kk], S[t]);
+      for (int kk = 0; kk < KK; ++kk) S[t] = MFMA16(kA[kk], qB[kk], S[t]);
+    }
+    block_column_softmax<NT>(S, L, g);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float vA[MC];
+        b_colop_lds<DHP>(vA, Vt, 16 * t + 4 * g + q, lane);
+#pragma unroll
+        for (int mc = 0; mc < MC; ++mc) OT[mc] = MFMA16(vA[mc], S[t][q], OT[mc]);
       }
-    block_column_softmax(S, ntok, L, g);
-#pragma unroll
-    for (int t = 0; t < kMaxTok; ++t)
-      if (t < ntok) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-#pragma unroll
-          for (int mc = 0; mc < MC; ++mc) {
-            const float vA = Vt[bidx<DHP>(16 * t + 4 * g + q, (lane & 15) + 16 * mc)];
-            OT[mc] = MFMA16(vA, S[t][q], OT[mc]);
-          }
-        }
-      }
+    }
     __syncthreads();
   }
   // hub pass: unnormalised partial tile, the combine pass applies 1/deg
@@ -298,16 +327,21 @@ __global__ __launch_bounds__(256) void fwd_block(BArgs a) {
 }
 
 // ---------------------------------------------------------------- backward, destination pass
-template <int DHP, int VEC, bool STATS>
-__global__ __launch_bounds__(256) void bwd_dst_block(BArgs a) {
+#ifndef AMPCONV_BLOCK_BWD_WAVES      // developer A/B switch: minimum waves per SIMD of the two backward kernels
+#define AMPCONV_BLOCK_BWD_WAVES 1
+#endif
+template <int DHP, int VEC, bool STATS, int NT>
+__global__ __launch_bounds__(64 * NT, AMPCONV_BLOCK_BWD_WAVES) void bwd_dst_block(BArgs a) {
   constexpr int KK = DHP / 4, MC = DHP / 16;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x;
+  const int tid = threadIdx.x, lane = tid & 63;
+  constexpr int nthreads = 64 * NT;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int64_t r, onode;
   int h, beg, end, deg;
   if (!map_unit(a.hub, a.ptr, blockIdx.x, a.n_units, a.H, r, onode, h, beg, end, deg)) return;
-  const int L = a.L, dh = a.dh, ntok = a.ntok, g = lane >> 4;
+  constexpr int ntok = NT;
+  const int L = a.L, dh = a.dh, g = lane >> 4;
   const bool bf = a.bf16 != 0;
   float *Kt = lds, *Vt = lds + 16 * ntok * DHP;
   const float inv = deg > 0 ? 1.f / (float)deg : 0.f;       // dO is the gradient of the MEAN
@@ -342,62 +376,60 @@ __global__ __launch_bounds__(256) void bwd_dst_block(BArgs a) {
     if (p + 1 < end) fetch(p + 1);
     __syncthreads();
 
-    f32x4 S[kMaxTok], dP[kMaxTok];
+    f32x4 S[NT], dP[NT];
 #pragma unroll
-    for (int t = 0; t < kMaxTok; ++t)
-      if (t < ntok) {
-        float kA[KK], vA[KK];
-        b_rowop_lds<DHP>(kA, Kt, t, lane);
-        b_rowop_lds<DHP>(vA, Vt, t, lane);
-        S[t] = dP[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < NT; ++t) {
+      float kA[KK], vA[KK];
+      b_rowop_lds<DHP>(kA, Kt, t, lane);
+      b_rowop_lds<DHP>(vA, Vt, t, lane);
+      S[t] = dP[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int kk = 0; kk < KK; ++kk) {
-          S[t] = MFMA16(kA[kk], qB[kk], S[t]);
-          dP[t] = MFMA16(vA[kk], gB[kk], dP[t]);
-        }
+      for (int kk = 0; kk < KK; ++kk) {
+        S[t] = MFMA16(kA[kk], qB[kk], S[t]);
+        dP[t] = MFMA16(vA[kk], gB[kk], dP[t]);
       }
-    const float lse = block_column_softmax(S, ntok, L, g);
+    }
+    const float lse = block_column_softmax<NT>(S, L, g);
     float part = 0.f;
 #pragma unroll
-    for (int t = 0; t < kMaxTok; ++t)
-      if (t < ntok) {
+    for (int t = 0; t < NT; ++t) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) part = fmaf(S[t][q], dP[t][q], part);
-      }
+      for (int q = 0; q < 4; ++q) part = fmaf(S[t][q], dP[t][q], part);
+    }
     const float delta = groups_sum(part);
     if (STATS && g == 0) {                   // all LS columns: the source pass reads every one
       sb[(lane & 15) + 16 * wave] = lse;
       sb[LS + (lane & 15) + 16 * wave] = delta;
     }
 #pragma unroll
-    for (int t = 0; t < kMaxTok; ++t)
-      if (t < ntok) {
+    for (int t = 0; t < NT; ++t) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float dS = S[t][q] * (dP[t][q] - delta);
+      for (int q = 0; q < 4; ++q) {
+        const float dS = S[t][q] * (dP[t][q] - delta);
+        float kC[MC];
+        b_colop_lds<DHP>(kC, Kt, 16 * t + 4 * g + q, lane);
 #pragma unroll
-          for (int mc = 0; mc < MC; ++mc) {
-            const float kC = Kt[bidx<DHP>(16 * t + 4 * g + q, (lane & 15) + 16 * mc)];
-            dQT[mc] = MFMA16(kC, dS, dQT[mc]);
-          }
-        }
+        for (int mc = 0; mc < MC; ++mc) dQT[mc] = MFMA16(kC[mc], dS, dQT[mc]);
       }
+    }
     __syncthreads();
   }
   store_ct<DHP, VEC>(a.O, onode, h, dQT, a.hub.mode == 2 ? 1.f : a.oscale, wave, L, dh, lane, bf && a.hub.mode != 2);
 }
 
 // ---------------------------------------------------------------- backward, source pass (needs the statistics)
-template <int DHP, int VEC>
-__global__ __launch_bounds__(256) void bwd_src_block(BArgs a) {
+template <int DHP, int VEC, int NT>
+__global__ __launch_bounds__(64 * NT, AMPCONV_BLOCK_BWD_WAVES) void bwd_src_block(BArgs a) {
   constexpr int KK = DHP / 4, MC = DHP / 16;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x;
+  const int tid = threadIdx.x, lane = tid & 63;
+  constexpr int nthreads = 64 * NT;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   int64_t s, onode;
   int h, beg, end, deg;
   if (!map_unit(a.hub, a.ptr, blockIdx.x, a.n_units, a.H, s, onode, h, beg, end, deg)) return;
-  const int L = a.L, dh = a.dh, ntok = a.ntok, g = lane >> 4, n = lane & 15;
+  constexpr int ntok = NT;
+  const int L = a.L, dh = a.dh, g = lane >> 4, n = lane & 15;
   const bool bf = a.bf16 != 0;
   float *Qt = lds, *Gt = lds + 16 * ntok * DHP;
 
@@ -412,8 +444,15 @@ __global__ __launch_bounds__(256) void bwd_src_block(BArgs a) {
   Stage<DHP, VEC> st;
   IdxWindow win;
   float inv_next = 0.f;
+  // the edge's softmax statistics (2 LS floats, written by the destination pass at this CSC position) travel with its
+  // tiles: one float per thread, requested an edge ahead and handed to the waves through LDS.  (Round 3 loaded them
+  // from global memory inside the edge's own phase: half of the pass was that wait.)
+  constexpr int LS = 16 * NT;
+  float *sl = lds + 2 * 16 * NT * DHP;
+  float stat_next = 0.f;
   auto fetch = [&](int p) {
     const int64_t d = idxwin_get<true>(win, a.idx, a.cinv, p, end, lane, &inv_next);
+    if (tid < 2 * LS) stat_next = a.stats[((int64_t)p * a.H + h) * (2 * LS) + tid];
     stage_load<DHP, VEC>(st, rows_of(a.Q, d, h, bf), a.Q.row_stride,
                          rows_of(a.dO, d, h, bf), a.dO.row_stride, L, dh, tid, nthreads);
   };
@@ -422,17 +461,17 @@ __global__ __launch_bounds__(256) void bwd_src_block(BArgs a) {
     fetch(beg);
   }
   __syncthreads();
-  const int LS = 16 * ntok;
   const bool colok = n + 16 * wave < L;      // this lane's source token exists
   for (int p = beg; p < end; ++p) {
     stage_store<DHP, VEC>(Qt, Gt, st, a.qscale, inv_next, L, dh, tid, nthreads);
-    const float *sb = a.stats + ((int64_t)p * a.H + h) * (2 * LS);
+    if (tid < 2 * LS) sl[tid] = stat_next;
+    const float *sb = sl;
     if (p + 1 < end) fetch(p + 1);
     __syncthreads();
 
 #pragma unroll
-    for (int t = 0; t < kMaxTok; ++t)
-      if (t < ntok) {                        // destination tokens 16 t + 4 g + q
+    for (int t = 0; t < NT; ++t) {
+      {                                      // destination tokens 16 t + 4 g + q
         const f32x4 l4 = *reinterpret_cast<const f32x4 *>(sb + 16 * t + 4 * g);
         const f32x4 d4 = *reinterpret_cast<const f32x4 *>(sb + LS + 16 * t + 4 * g);
         f32x4 S = f32x4{0.f, 0.f, 0.f, 0.f}, dP = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -450,14 +489,17 @@ __global__ __launch_bounds__(256) void bwd_src_block(BArgs a) {
         for (int q = 0; q < 4; ++q) {
           const float pr = colok ? fast_exp2(S[q] - l4[q]) : 0.f;
           const float dS = pr * (dP[q] - d4[q]);
+          float gC[MC], qC[MC];
+          b_colop_lds<DHP>(gC, Gt, 16 * t + 4 * g + q, lane);
+          b_colop_lds<DHP>(qC, Qt, 16 * t + 4 * g + q, lane);
 #pragma unroll
           for (int mc = 0; mc < MC; ++mc) {
-            const int idx = bidx<DHP>(16 * t + 4 * g + q, n + 16 * mc);
-            dVT[mc] = MFMA16(Gt[idx], pr, dVT[mc]);
-            dKT[mc] = MFMA16(Qt[idx], dS, dKT[mc]);
+            dVT[mc] = MFMA16(gC[mc], pr, dVT[mc]);
+            dKT[mc] = MFMA16(qC[mc], dS, dKT[mc]);
           }
         }
       }
+    }
     __syncthreads();
   }
   store_ct<DHP, VEC>(a.dK, onode, h, dKT, a.hub.mode == 2 ? 1.f : a.oscale, wave, L, dh, lane, bf && a.hub.mode != 2);
@@ -475,16 +517,34 @@ inline int vec_of(const ampconv_view_t *views, int n, int dh, int esize) {
   return vec;
 }
 
-template <typename K4, typename K2>
-int launch_block(const BArgs &a, int dhp, int vec, K4 k64v4, K2 k64v2, K4 k32v4, K2 k32v2, hipStream_t stream) {
+// kernel table: (dhp in {64, 32}) x (vec in {4, 2}) x (ntok 1..4)
+typedef void (*BlockKernel)(BArgs);
+template <template <int, int, int> class F>
+struct KernelTable {
+  template <int DHP, int VEC>
+  static BlockKernel by_ntok(int ntok) {
+    switch (ntok) {
+      case 1: return F<DHP, VEC, 1>::get();
+      case 2: return F<DHP, VEC, 2>::get();
+      case 3: return F<DHP, VEC, 3>::get();
+      default: return F<DHP, VEC, 4>::get();
+    }
+  }
+  static BlockKernel get(int dhp, int vec, int ntok) {
+    if (dhp == 64) return vec == 4 ? by_ntok<64, 4>(ntok) : by_ntok<64, 2>(ntok);
+    return vec == 4 ? by_ntok<32, 4>(ntok) : by_ntok<32, 2>(ntok);
+  }
+};
+template <int DHP, int VEC, int NT> struct FwdK { static BlockKernel get() { return fwd_block<DHP, VEC, NT>; } };
+template <int DHP, int VEC, int NT> struct DstKS { static BlockKernel get() { return bwd_dst_block<DHP, VEC, true, NT>; } };
+template <int DHP, int VEC, int NT> struct DstK { static BlockKernel get() { return bwd_dst_block<DHP, VEC, false, NT>; } };
+template <int DHP, int VEC, int NT> struct SrcK { static BlockKernel get() { return bwd_src_block<DHP, VEC, NT>; } };
+
+int launch_block(const BArgs &a, int dhp, BlockKernel k, hipStream_t stream, int extra_floats = 0) {
   if (a.n_units > INT32_MAX) return AMPCONV_E_BADARG;
   const dim3 grid((unsigned)a.n_units), block(64 * a.ntok);
-  const size_t shmem = (size_t)2 * 16 * a.ntok * dhp * sizeof(float);
-  if (dhp == 64) {
-    if (vec == 4) k64v4<<<grid, block, shmem, stream>>>(a); else k64v2<<<grid, block, shmem, stream>>>(a);
-  } else {
-    if (vec == 4) k32v4<<<grid, block, shmem, stream>>>(a); else k32v2<<<grid, block, shmem, stream>>>(a);
-  }
+  const size_t shmem = ((size_t)2 * 16 * a.ntok * dhp + extra_floats) * sizeof(float);
+  hipLaunchKernelGGL(k, grid, block, shmem, stream, a);
   return ampconv_launch_status();
 }
 
@@ -516,7 +576,7 @@ int ampconv_fwd_edge_block(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
   a.ptr = rowptr; a.idx = col; a.qidx = qidx;
   const ampconv_view_t views[] = {Q, K, V, O};
   const int vec = vec_of(views, 4, a.dh, bf16 ? 2 : 4), dhp = a.dh > 32 ? 64 : 32;
-  return launch_block(a, dhp, vec, fwd_block<64, 4>, fwd_block<64, 2>, fwd_block<32, 4>, fwd_block<32, 2>, stream);
+  return launch_block(a, dhp, KernelTable<FwdK>::get(dhp, vec, a.ntok), stream);
 }
 
 int ampconv_bwd_edge_dst_block(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V, ampconv_view_t dO,
@@ -529,11 +589,8 @@ int ampconv_bwd_edge_dst_block(ampconv_view_t Q, ampconv_view_t K, ampconv_view_
   a.oscale = 1.f / sqrtf((float)a.dh);
   const ampconv_view_t views[] = {Q, K, V, dO, dQ};
   const int vec = vec_of(views, 5, a.dh, bf16 ? 2 : 4), dhp = a.dh > 32 ? 64 : 32;
-  if (sa.stats)
-    return launch_block(a, dhp, vec, bwd_dst_block<64, 4, true>, bwd_dst_block<64, 2, true>,
-                        bwd_dst_block<32, 4, true>, bwd_dst_block<32, 2, true>, stream);
-  return launch_block(a, dhp, vec, bwd_dst_block<64, 4, false>, bwd_dst_block<64, 2, false>,
-                      bwd_dst_block<32, 4, false>, bwd_dst_block<32, 2, false>, stream);
+  return launch_block(a, dhp, sa.stats ? KernelTable<DstKS>::get(dhp, vec, a.ntok) : KernelTable<DstK>::get(dhp, vec, a.ntok),
+                      stream);
 }
 
 int ampconv_bwd_edge_src_block(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V, ampconv_view_t dO,
@@ -548,6 +605,5 @@ int ampconv_bwd_edge_src_block(ampconv_view_t Q, ampconv_view_t K, ampconv_view_
   a.oscale = 0.6931471805599453f;       // dK = ln2 * sum dS^T (Q * log2e / sqrt(dh))
   const ampconv_view_t views[] = {Q, K, V, dO, dK, dV};
   const int vec = vec_of(views, 6, a.dh, bf16 ? 2 : 4), dhp = a.dh > 32 ? 64 : 32;
-  return launch_block(a, dhp, vec, bwd_src_block<64, 4>, bwd_src_block<64, 2>, bwd_src_block<32, 4>,
-                      bwd_src_block<32, 2>, stream);
+  return launch_block(a, dhp, KernelTable<SrcK>::get(dhp, vec, a.ntok), stream, 2 * 16 * a.ntok);
 }

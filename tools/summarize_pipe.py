@@ -14,7 +14,7 @@ import os
 import re
 import sys
 
-KERNELS = (('fwd', r'\bfwd_(mfma|bf16)'), ('bwd_dst', r'\bbwd_dst_(mfma|bf16)'), ('bwd_src', r'\bbwd_src_(mfma|bf16)'))
+KERNELS = (('fwd', r'\bfwd_(mfma|bf16|block)'), ('bwd_dst', r'\bbwd_dst_(mfma|bf16|block)'), ('bwd_src', r'\bbwd_src_(mfma|bf16|block)'))
 
 
 def main():
