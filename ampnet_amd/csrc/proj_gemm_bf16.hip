@@ -15,6 +15,7 @@
 //
 //   proj_rows_bf16   out[M, N] = A[M, K] W^T (+ bias) (* row mask)
 //   proj_wgrad_bf16  dW[Na, Nb] = A[M, Na]^T B[M, Nb], colsum(mask * A)
+#include <stdlib.h>
 #include <type_traits>
 #include "proj_common.h"
 
@@ -602,7 +603,11 @@ struct WgradPlanB {
 };
 inline WgradPlanB wgrad_plan_bf16(int64_t M, int Nap, int Nbp) {       // padded shape (multiples of 128)
   WgradPlanB p;
-  p.T = (Nap % 256 == 0 && Nbp % 256 == 0) ? 256 : 128;
+  static const bool small_t = [] {                        // developer switch: 128 x 128 tiles of four waves, two per CU
+    const char *e = getenv("AMPCONV_PROJ_WGRAD_BF16_T");
+    return e && atoi(e) == 128;
+  }();
+  p.T = (Nap % 256 == 0 && Nbp % 256 == 0 && !small_t) ? 256 : 128;
   const int64_t ntiles = (int64_t)(Nap / p.T) * (Nbp / p.T);
   const int64_t nstages = (M + kRSB - 1) / kRSB;
   // one round of workgroups: slices are dealt to the 8 XCDs in turn and every slice brings `ntiles` workgroups, so

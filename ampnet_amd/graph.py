@@ -41,7 +41,11 @@ class EdgeCSR:
         self.cperm = torch.empty(max(E, 1), **i32)
         self.cinv = torch.empty(max(E, 1), dtype=torch.float32, device=dev)
         status = torch.empty(4, **i32)                   # {bounds flag, dst chunks, src chunks, -}: ONE read-back
-        self._by_edge = torch.empty(max(E, 1), **i32)     # CSC position of every original edge id
+        # CSC position of every original edge id (what csc_positions() derives `spos` from): a by-product of the
+        # one-launch preparation of small graphs (GraphSAINT batches, Cora: saves two launches per step there); big
+        # graphs build it lazily, and only if a pass asks for the statistics hand-off (bf16 storage never does:
+        # 160 MB and a scatter launch per build at BASELINE config 5)
+        self._by_edge = torch.empty(max(E, 1), **i32) if E <= 12288 else None
         with torch.cuda.device(dev):
             ws_bytes = lib.ampconv_csr_workspace_bytes(N, E) if E > 0 else 0
             ws = torch.empty(max(ws_bytes, 1), dtype=torch.uint8, device=dev)
@@ -59,7 +63,8 @@ class EdgeCSR:
                                          self.cperm.data_ptr(), self.cinv.data_ptr(), status.data_ptr(), chunk,
                                          plans[0].data_ptr() if plans[0] is not None else None,
                                          plans[1].data_ptr() if plans[1] is not None else None,
-                                         self._by_edge.data_ptr(), ws.data_ptr(), ws_bytes, _stream())
+                                         self._by_edge.data_ptr() if self._by_edge is not None else None,
+                                         ws.data_ptr(), ws_bytes, _stream())
             _lib.check(rc, 'ampconv_graph_build')
             bad = 0
             if plans[0] is not None or (validate and E > 0):
@@ -96,9 +101,16 @@ class EdgeCSR:
             else:
                 self._spos = torch.empty(max(E, 1), dtype=torch.int32, device=self.device)
                 with torch.cuda.device(self.device):
-                    rc = lib.ampconv_csc_positions_from(self.eperm.data_ptr(), self._by_edge.data_ptr(), E,
-                                                        self._spos.data_ptr(), _stream())
-                _lib.check(rc, 'ampconv_csc_positions_from')
+                    if self._by_edge is not None:
+                        rc = lib.ampconv_csc_positions_from(self.eperm.data_ptr(), self._by_edge.data_ptr(), E,
+                                                            self._spos.data_ptr(), _stream())
+                        _lib.check(rc, 'ampconv_csc_positions_from')
+                    else:
+                        scratch = torch.empty(max(E, 1), dtype=torch.int32, device=self.device)
+                        rc = lib.ampconv_csc_positions(self.eperm.data_ptr(), self.cperm.data_ptr(), E,
+                                                       scratch.data_ptr(), self._spos.data_ptr(), _stream())
+                        _lib.check(rc, 'ampconv_csc_positions')
+                self._by_edge = None                                  # derived once per graph: not kept
         return self._spos
 
     def hub_args(self, side, L, D, n_tiles):

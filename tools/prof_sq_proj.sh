@@ -2,7 +2,7 @@
 # SQ counter passes over tools/bench_proj.py (the node-phase projection kernels); developer tool.
 #   tools/prof_sq_proj.sh <tag> [bench_proj args]
 tag=$1; shift
-out=gpurun_out/sq_r3/$tag
+out=gpurun_out/sq_r4/$tag
 mkdir -p $out
 cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd - >/dev/null
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE \
