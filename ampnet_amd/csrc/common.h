@@ -144,6 +144,20 @@ int ampconv_bwd_edge_src_block(ampconv_view_t Q, ampconv_view_t K, ampconv_view_
                                int L, int D, int H, ampconv_view_t dK, ampconv_view_t dV, HubArgs hub,
                                const float *stats, bool bf16, hipStream_t stream);
 
+// ---- short token sequences (edge_small.hip): L <= 4, one wave per row, VALU only, fp32; views aligned to the lane's
+// vector width.  No softmax statistics.
+bool ampconv_small_supported(int L, int D, int H, const ampconv_view_t *views, int n);
+int ampconv_fwd_edge_small(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V, const int32_t *rowptr,
+                           const int32_t *col, const int32_t *qidx, int64_t n_rows, int L, int D, int H,
+                           ampconv_view_t O, HubArgs hub, hipStream_t stream);
+int ampconv_bwd_edge_dst_small(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V, ampconv_view_t dO,
+                               const int32_t *rowptr, const int32_t *col, int64_t n_rows, int L, int D, int H,
+                               ampconv_view_t dQ, HubArgs hub, hipStream_t stream);
+int ampconv_bwd_edge_src_small(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V, ampconv_view_t dO,
+                               const int32_t *cscptr, const int32_t *crow, const float *cinv, int64_t n_src,
+                               int L, int D, int H, ampconv_view_t dK, ampconv_view_t dV, HubArgs hub,
+                               hipStream_t stream);
+
 // hub.hip
 int ampconv_hub_combine(const void *plan, int64_t n_chunks, const float *P, ampconv_view_t out,
                         const int32_t *ptr_for_mean, int L, int D, int H, float scale, int out_bf16,

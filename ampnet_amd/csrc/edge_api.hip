@@ -10,6 +10,12 @@ bool force_generic() {
   const char *e = std::getenv("AMPCONV_FORCE_GENERIC");
   return e && e[0] == '1';
 }
+// short token sequences (L <= 4) have a family of their own (edge_small.hip); AMPCONV_SMALL=0 sends them to the tile
+// kernels instead (the tests cross-check the two)
+bool small_off() {
+  const char *e = std::getenv("AMPCONV_SMALL");
+  return e && e[0] == '0';
+}
 int check_common(int L, int D, int H, int dtype) {
   if (dtype != AMPCONV_F32 && dtype != AMPCONV_BF16) return AMPCONV_E_DTYPE;
   if (L <= 0 || D <= 0 || H <= 0 || D % H != 0) return AMPCONV_E_BADARG;
@@ -63,6 +69,18 @@ extern "C" int ampconv_fwd_edge(ampconv_view_t Q, ampconv_view_t K, ampconv_view
   }
   // bf16 storage of the other shapes: the workgroup-per-unit kernels widen / round the rows themselves
   if (bf && !ampconv_block_supported(L, D, H, views, 4, true)) return AMPCONV_E_DTYPE;
+  if (!bf && !force_generic() && !small_off() && ampconv_small_supported(L, D, H, views, 4)) {
+    hipStream_t st = (hipStream_t)stream;
+    if (hub_plan && hub_chunks > 0 && hub_ws && !qidx) {      // long segments: main + hub + combine
+      if (int rc = ampconv_fwd_edge_small(Q, K, V, rowptr, col, nullptr, n_rows, L, D, H, O, hub_args(hub_plan, 1), st))
+        return rc;
+      ampconv_view_t P = partial_view(hub_ws, 0, hub_chunks, L, D, H);
+      if (int rc = ampconv_fwd_edge_small(Q, K, V, rowptr, col, nullptr, hub_chunks, L, D, H, P, hub_args(hub_plan, 2), st))
+        return rc;
+      return ampconv_hub_combine(hub_plan, hub_chunks, (const float *)P.ptr, O, rowptr, L, D, H, 1.f, 0, st);
+    }
+    return ampconv_fwd_edge_small(Q, K, V, rowptr, col, qidx, n_rows, L, D, H, O, HubArgs{nullptr, 0}, st);
+  }
   if (!bf && !force_generic() && ampconv_mfma_supported(L, D, H) && ampconv_mfma_views_ok(views, 4)) {
     if (hub_plan && hub_chunks > 0 && hub_ws && !qidx) {      // long segments: main + hub + combine
       HubArgs hm = hub_args(hub_plan, 1), hh = hub_args(hub_plan, 2);
@@ -104,6 +122,7 @@ extern "C" size_t ampconv_softmax_stats_bytes(int64_t E, int L, int D, int H, in
     return ampconv_bf16_supported(L, D, H, nullptr, 0) || !ampconv_block_supported(L, D, H, nullptr, 0, true)
                ? 0 : (size_t)E * H * ampconv_block_stats_floats(L) * sizeof(float);   // workgroup-per-unit kernels
   if (force_generic()) return 0;
+  if (!small_off() && ampconv_small_supported(L, D, H, nullptr, 0)) return 0;      // edge_small.hip keeps none
   if (ampconv_mfma_supported(L, D, H))
     return (size_t)E * H * kStatsPerUnit * sizeof(float);
   if (ampconv_block_supported(L, D, H, nullptr, 0, false))     // shapes of the workgroup-per-unit kernels
@@ -143,6 +162,19 @@ extern "C" int ampconv_bwd_edge_dst(ampconv_view_t Q, ampconv_view_t K, ampconv_
     return ampconv_bwd_edge_dst_bf16(Q, K, V, dObar, rowptr, col, n_rows, L, D, H, dQ, HubArgs{nullptr, 0}, st);
   }
   if (bf && !ampconv_block_supported(L, D, H, views, 5, true)) return AMPCONV_E_DTYPE;
+  if (!bf && !stats && !force_generic() && !small_off() && ampconv_small_supported(L, D, H, views, 5)) {
+    hipStream_t st = (hipStream_t)stream;
+    if (hub_plan && hub_chunks > 0 && hub_ws) {
+      if (int rc = ampconv_bwd_edge_dst_small(Q, K, V, dObar, rowptr, col, n_rows, L, D, H, dQ, hub_args(hub_plan, 1), st))
+        return rc;
+      ampconv_view_t P = partial_view(hub_ws, 0, hub_chunks, L, D, H);
+      if (int rc = ampconv_bwd_edge_dst_small(Q, K, V, dObar, rowptr, col, hub_chunks, L, D, H, P, hub_args(hub_plan, 2), st))
+        return rc;
+      return ampconv_hub_combine(hub_plan, hub_chunks, (const float *)P.ptr, dQ, nullptr, L, D, H,
+                                 1.f / sqrtf((float)(D / H)), 0, st);
+    }
+    return ampconv_bwd_edge_dst_small(Q, K, V, dObar, rowptr, col, n_rows, L, D, H, dQ, HubArgs{nullptr, 0}, st);
+  }
   if (!bf && !force_generic() && ampconv_mfma_supported(L, D, H) && ampconv_mfma_views_ok(views, 5)) {
     if (hub_plan && hub_chunks > 0 && hub_ws) {
       HubArgs hm = hub_args(hub_plan, 1), hh = hub_args(hub_plan, 2);
@@ -219,6 +251,24 @@ extern "C" int ampconv_bwd_edge_src(ampconv_view_t Q, ampconv_view_t K, ampconv_
                                      HubArgs{nullptr, 0}, st);
   }
   if (bf && !(stats && ampconv_block_supported(L, D, H, views, 6, true))) return AMPCONV_E_DTYPE;
+  if (!bf && !stats && !force_generic() && !small_off() && ampconv_small_supported(L, D, H, views, 6)) {
+    hipStream_t st = (hipStream_t)stream;
+    if (hub_plan && hub_chunks > 0 && hub_ws) {
+      if (int rc = ampconv_bwd_edge_src_small(Q, K, V, dObar, cscptr, crow, cinv, n_src, L, D, H, dK, dV,
+                                              hub_args(hub_plan, 1), st))
+        return rc;
+      ampconv_view_t PK = partial_view(hub_ws, 0, hub_chunks, L, D, H);
+      ampconv_view_t PV = partial_view(hub_ws, 1, hub_chunks, L, D, H);
+      if (int rc = ampconv_bwd_edge_src_small(Q, K, V, dObar, cscptr, crow, cinv, hub_chunks, L, D, H, PK, PV,
+                                              hub_args(hub_plan, 2), st))
+        return rc;
+      if (int rc = ampconv_hub_combine(hub_plan, hub_chunks, (const float *)PK.ptr, dK, nullptr, L, D, H,
+                                       0.6931471805599453f, 0, st))
+        return rc;
+      return ampconv_hub_combine(hub_plan, hub_chunks, (const float *)PV.ptr, dV, nullptr, L, D, H, 1.f, 0, st);
+    }
+    return ampconv_bwd_edge_src_small(Q, K, V, dObar, cscptr, crow, cinv, n_src, L, D, H, dK, dV, HubArgs{nullptr, 0}, st);
+  }
   if (!bf && !force_generic() && ampconv_mfma_supported(L, D, H) && ampconv_mfma_views_ok(views, 6)) {
     if (hub_plan && hub_chunks > 0 && hub_ws) {
       HubArgs hm = hub_args(hub_plan, 1), hh = hub_args(hub_plan, 2);
