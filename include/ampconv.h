@@ -242,7 +242,8 @@ int ampconv_masked_colsum(const void *dY, const int32_t *rowptr, int64_t N,
  *                        ordered sum.  `workspace`: proj_wgrad_workspace_bytes(M, Na, Nb, dtype) bytes.
  * Developer switches read from the environment at the first call (A/B measurements; the defaults are the
  * shipped configuration, nothing else keeps state): AMPCONV_PROJ_ROWS=1 (256 x 256 row tiles),
- * AMPCONV_PROJ_WGRAD_TI=128, AMPCONV_PROJ_WGRAD_BF16_T=128 (smaller weight-gradient tiles), and for the edge phase AMPCONV_FORCE_GENERIC=1, AMPCONV_{FWD,DST,SRC}_T4=0,
+ * AMPCONV_PROJ_WGRAD_TI=128, AMPCONV_PROJ_WGRAD_BF16_T=128 (smaller weight-gradient tiles), and for the edge phase AMPCONV_FORCE_GENERIC=1,
+ * AMPCONV_SMALL=0 (L <= 4 on the tile kernels instead of the short-sequence family), AMPCONV_{FWD,DST,SRC}_T4=0,
  * AMPCONV_{FWD,DST,SRC}_NT4=0 (older tilings of the same kernels, kept as cross-checks for the tests),
  * AMPCONV_CSR_SMALL=0 (graph preparation by the multi-launch path).  */
 int ampconv_proj_supported(int N, int K, int dtype);
