@@ -77,9 +77,11 @@ SIGNATURES = {
     'ampconv_proj_weight_image_bytes': (_sz, [_i32, _i32, _i32]),
     'ampconv_proj_weight_image': (_i32, [_vp, _i64, _i64, _i32, _i32, _vp, _i32, _vp]),
     'ampconv_proj_weight_images': (_i32, [_i32, _vp, _i32, _vp]),
-    'ampconv_proj_rows': (_i32, [_vp, _i64, _i64, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i64, _i32, _vp]),
+    'ampconv_proj_rows': (_i32, [_vp, _i64, _i64, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i64, _vp, _i64, _i32, _vp]),
     'ampconv_proj_wgrad_workspace_bytes': (_sz, [_i64, _i32, _i32, _i32]),
-    'ampconv_proj_wgrad': (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _sz, _i32, _vp]),
+    'ampconv_proj_wgrad': (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _sz, _vp, _i64, _i32, _vp]),
+    'ampconv_active_nodes_workspace_bytes': (_sz, [_i64]),
+    'ampconv_active_nodes': (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     'ampconv_segment_mean': (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _vp]),
     'ampconv_mask_rows': (_i32, [_vp, _vp, _i64, _i64, _i32, _vp]),
     'ampconv_masked_colsum': (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, _i32, _vp]),

@@ -100,6 +100,9 @@ def _tn_matmul(a, b, chunks=128):
 # ---- the per-node projections in libampconv.so.  fp32 storage (csrc/proj_gemm.hip): operands split exactly into
 # three bf16 terms, six partial products on v_mfma_f32_32x32x16_bf16, fp32 accumulate; bf16 storage
 # (csrc/proj_gemm_bf16.hip): one product, fp32 accumulate, one rounding on the way out
+NODE_LISTS = os.environ.get('AMPCONV_NODE_LISTS', '1') != '0'      # developer switch (A/B measurements)
+
+
 def _code(dtype):
     return _lib.AMPCONV_BF16 if dtype == torch.bfloat16 else _lib.AMPCONV_F32
 
@@ -146,23 +149,30 @@ def proj_image(W, transpose=False):
     return proj_images([(W, transpose)])[0]
 
 
-def proj_rows(a2, image, bias=None, rowptr=None, L=0):
-    """out[M, N] = (a2[M, K] @ B^T + bias) * [node of the row has an in-edge]  (mask only with rowptr)."""
+def proj_rows(a2, image, bias=None, rowptr=None, L=0, nodes=None, out=None):
+    """out[M, N] = (a2[M, K] @ B^T + bias) * [node of the row has an in-edge]  (mask only with rowptr).
+    nodes = (ids, count[, ptr]) (EdgeCSR.active_nodes): only the L rows of each listed node are computed and written
+    (bf16; the other rows of `out` keep what they hold: uninitialised unless the caller passes `out`)."""
     lib = _lib.load()
     img, N, K, wdt = image
     assert a2.dim() == 2 and a2.size(1) == K and a2.stride(1) == 1 and a2.dtype == wdt
     assert bias is None or bias.dtype == wdt
     a2 = _aligned(a2)
-    out = torch.empty(a2.size(0), N, dtype=wdt, device=a2.device)
+    if out is None:
+        out = torch.empty(a2.size(0), N, dtype=wdt, device=a2.device)
+    assert out.shape == (a2.size(0), N) and out.stride(1) == 1 and out.dtype == wdt
+    ids, cnt = (nodes[0].data_ptr(), nodes[1]) if nodes is not None else (None, 0)
     _lib.check(lib.ampconv_proj_rows(a2.data_ptr(), a2.stride(0), a2.size(0), K, img.data_ptr(), N, _ptr(bias),
-                                     _ptr(rowptr), L, out.data_ptr(), N, _code(wdt), _stream()), 'ampconv_proj_rows')
+                                     _ptr(rowptr), L, out.data_ptr(), out.stride(0), ids, cnt, _code(wdt), _stream()),
+               'ampconv_proj_rows')
     return out
 
 
-def proj_wgrad(a2, b2, dw, colsum=None, rowptr=None, L=0):
+def proj_wgrad(a2, b2, dw, colsum=None, rowptr=None, L=0, nodes=None):
     """dw[Na, Nb] = (mask * a2)^T @ b2 and colsum[Na] = column sums of mask * a2, into caller-owned (views of)
     contiguous tensors of the inputs' dtype; reduction over the rows in fixed slices (bitwise reproducible).
-    bf16: the mask acts on the column sums only (include/ampconv.h)."""
+    bf16: the mask acts on the column sums only (include/ampconv.h).  nodes: the sums run over the L rows of each
+    listed node only (bf16)."""
     lib = _lib.load()
     M, Na = a2.shape
     Nb = b2.size(1)
@@ -170,11 +180,29 @@ def proj_wgrad(a2, b2, dw, colsum=None, rowptr=None, L=0):
     assert a2.dtype == b2.dtype == dw.dtype and (colsum is None or colsum.dtype == a2.dtype)
     a2, b2 = _aligned(a2), _aligned(b2)
     code = _code(a2.dtype)
-    nws = lib.ampconv_proj_wgrad_workspace_bytes(M, Na, Nb, code)
+    ids, cnt = (nodes[0].data_ptr(), nodes[1]) if nodes is not None else (None, 0)
+    nws = lib.ampconv_proj_wgrad_workspace_bytes(cnt * L if nodes is not None else M, Na, Nb, code)
     ws = torch.empty(max(nws, 16) // 4, dtype=torch.float32, device=a2.device)
     _lib.check(lib.ampconv_proj_wgrad(a2.data_ptr(), a2.stride(0), b2.data_ptr(), b2.stride(0), M, Na, Nb,
-                                      _ptr(rowptr), L, dw.data_ptr(), _ptr(colsum), ws.data_ptr(), nws, code,
+                                      _ptr(rowptr), L, dw.data_ptr(), _ptr(colsum), ws.data_ptr(), nws, ids, cnt, code,
                                       _stream()), 'ampconv_proj_wgrad')
+
+
+def _zero_unlisted(t2, nodes, n_nodes, L):
+    """Zero the rows of the nodes a list leaves out (its CSR-shaped `ptr`: include/ampconv.h, ampconv_active_nodes)."""
+    lib = _lib.load()
+    assert t2.is_contiguous()
+    io = _lib.AMPCONV_BF16 if t2.dtype == torch.bfloat16 else _lib.AMPCONV_F32
+    _lib.check(lib.ampconv_mask_rows(t2.data_ptr(), nodes[2].data_ptr(), n_nodes, L * t2.size(1), io, _stream()),
+               'ampconv_mask_rows')
+
+
+def node_lists(csr, dtype, L, native, shared):
+    """The graph's node lists when this call can use them: bf16 projections of a self-attention layer (xq is xkv) with
+    16 <= L <= 128 on a graph where a good share of the nodes has no edge (EdgeCSR.active_nodes), else None."""
+    if not (NODE_LISTS and native and shared and dtype == torch.bfloat16 and 16 <= L <= 128):
+        return None
+    return csr.active_nodes()
 
 
 def edge_forward(Q, K, V, csr, n_rows, L, D, H, out2d, qidx=None, dtype=_lib.AMPCONV_F32):
@@ -220,8 +248,11 @@ class AMPConvFunction(torch.autograd.Function):
             if native:      # every weight image this call and its backward need, in one launch
                 ws = [w_in, w_out] if shared else [w_in[:D], w_in[D:], w_out]
                 imgs = proj_images([(w, False) for w in ws] + [(w, True) for w in ws])
+            lists = node_lists(csr, xq.dtype, L, native, shared and Nq == csr.num_nodes)
             if shared:
-                qkv = (proj_rows(xq2, imgs[0], b_in) if native
+                # (node lists: Q rows matter for nodes with in-edges, K / V rows for nodes with out-edges; the rows of
+                # nodes with neither are never read by an edge pass and stay unwritten)
+                qkv = (proj_rows(xq2, imgs[0], b_in, L=L, nodes=lists and lists['any']) if native
                        else torch.addmm(b_in, xq2, w_in.t()))              # [N*L, 3D]
                 Qv, Kv, Vv = (_view(qkv, i * D, L, dh) for i in range(3))
                 xkv2 = xq2
@@ -238,7 +269,10 @@ class AMPConvFunction(torch.autograd.Function):
                 Kv, Vv = _view(kv, 0, L, dh), _view(kv, D, L, dh)
             obar = torch.empty(Nq * L, D, dtype=xq.dtype, device=xq.device)
             edge_forward(Qv, Kv, Vv, csr, Nq, L, D, H, obar, dtype=dtype)
-            if native:      # bias and the in-degree mask (rows nobody sends to stay exactly 0) in the epilogue
+            if lists:       # the rows of the nodes with in-edges; the others are zeroed without being read
+                y = proj_rows(obar, imgs[1], b_out, L=L, nodes=lists['in'])
+                _zero_unlisted(y, lists['in'], Nq, L)
+            elif native:    # bias and the in-degree mask (rows nobody sends to stay exactly 0) in the epilogue
                 y = proj_rows(obar, imgs[1 if shared else 2], b_out, csr.rowptr, L)
             else:
                 y = torch.addmm(b_out, obar, w_out.t())
@@ -248,6 +282,7 @@ class AMPConvFunction(torch.autograd.Function):
         ctx.set_materialize_grads(False)     # no zero-filled [N*L, 3D] gradient for the qkv side output
         ctx.save_for_backward(xq2, xkv2, w_in, w_out, qkv, kv, obar)
         ctx.csr, ctx.dims, ctx.shared, ctx.dtype, ctx.gemm = csr, (Nq, Nk, L, D, H), shared, dtype, gemm
+        ctx.lists = lists
         ctx.images_t = imgs[len(imgs) // 2:] if imgs else None     # the transposed images, for the input gradients
         ctx.mark_non_differentiable(qkv)
         if kv is not None:
@@ -270,11 +305,16 @@ class AMPConvFunction(torch.autograd.Function):
             native = proj_native(ctx.gemm, dy2.dtype, D)
             # out-projection: rows with no in-edge contribute nothing (their obar is 0, and
             # the bias gradient masks them explicitly)
+            lists = ctx.lists
             if native:
                 dw_out = torch.empty_like(w_out)
                 db_out = torch.empty(D, dtype=dy2.dtype, device=dev)
-                proj_wgrad(dy2, obar, dw_out, db_out, csr.rowptr, L)
-                dobar = proj_rows(dy2, ctx.images_t[-1])
+                if lists:   # the listed nodes ARE the ones that pass the mask; dObar is read for destinations only
+                    proj_wgrad(dy2, obar, dw_out, db_out, L=L, nodes=lists['in'])
+                    dobar = proj_rows(dy2, ctx.images_t[-1], L=L, nodes=lists['in'])
+                else:
+                    proj_wgrad(dy2, obar, dw_out, db_out, csr.rowptr, L)
+                    dobar = proj_rows(dy2, ctx.images_t[-1])
             else:
                 scratch = torch.empty((1 + _lib.COLSUM_BLOCKS) * D, dtype=torch.float32, device=dev)
                 io = _lib.AMPCONV_BF16 if dy2.dtype == torch.bfloat16 else _lib.AMPCONV_F32
@@ -326,7 +366,14 @@ class AMPConvFunction(torch.autograd.Function):
                 # anyway: all three thirds of in_proj_bias.grad are the true sums, as autograd's are)
                 dw_in = torch.empty_like(w_in)
                 db_in = torch.empty(3 * D, dtype=dy2.dtype, device=dev)
-                if shared:
+                if lists:   # the dQKV rows of a node without any edge are zeros (both edge passes wrote them)
+                    proj_wgrad(dqkv, xq2, dw_in, db_in, L=L, nodes=lists['any'])
+                    dxq = dxkv = None
+                    if need_xq:
+                        dxq2 = proj_rows(dqkv, ctx.images_t[0], L=L, nodes=lists['any'])
+                        _zero_unlisted(dxq2, lists['any'], Nq, L)
+                        dxq = dxq2.view(Nq, L * D)
+                elif shared:
                     proj_wgrad(dqkv, xq2, dw_in, db_in)
                     dxq = proj_rows(dqkv, ctx.images_t[0]).view(Nq, L * D) if need_xq else None
                     dxkv = None

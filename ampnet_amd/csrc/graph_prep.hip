@@ -203,6 +203,27 @@ __global__ __launch_bounds__(kSmallT) void csr_small_kernel(SmallArgs a) {
   if (t == 0) a.oob[1 + b] = header[0];              // chunk count beside the bounds flag: one read-back for the host
 }
 
+// node n is listed iff it has an in-edge (which & 1) or an out-edge (which & 2)
+__global__ void active_flags_kernel(const int32_t *__restrict__ rowptr, const int32_t *__restrict__ cscptr, int64_t N,
+                                    int which, int32_t *__restrict__ flag) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n > N) return;
+  bool on = false;
+  if (n < N) {
+    if (which & 1) on = rowptr[n + 1] != rowptr[n];
+    if (which & 2) on = on || cscptr[n + 1] != cscptr[n];
+  }
+  flag[n] = on ? 1 : 0;
+}
+
+__global__ void active_fill_kernel(const int32_t *__restrict__ ptr, int64_t N, int32_t *__restrict__ list,
+                                   int32_t *__restrict__ count) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n < N && ptr[n + 1] != ptr[n]) list[ptr[n]] = (int32_t)n;
+  if (n < 8) list[ptr[N] + n] = 0;                 // the padding the projection kernels read past the end (not used)
+  if (n == 0) *count = ptr[N];
+}
+
 __global__ void plan_counts_kernel(const int32_t *plan_dst, const int32_t *plan_src, int32_t *oob) {
   oob[1] = plan_dst ? plan_dst[0] : 0;
   oob[2] = plan_src ? plan_src[0] : 0;
@@ -325,5 +346,33 @@ extern "C" int ampconv_csc_positions_from(const int32_t *eperm, const int32_t *b
   if (E == 0) return AMPCONV_OK;
   if (!eperm || !by_edge || !spos) return AMPCONV_E_BADARG;
   gather_positions<<<(unsigned)((E + 255) / 256), 256, 0, (hipStream_t)stream>>>(eperm, by_edge, E, spos);
+  return ampconv_launch_status();
+}
+
+extern "C" size_t ampconv_active_nodes_workspace_bytes(int64_t N) {
+  if (N <= 0 || N >= INT32_MAX) return 0;
+  size_t tmp = 0;
+  hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, (int32_t *)nullptr, (int32_t *)nullptr, (int)(N + 1));
+  return align_up((size_t)(N + 1) * sizeof(int32_t)) + align_up(tmp) + kAlign;
+}
+
+extern "C" int ampconv_active_nodes(const int32_t *rowptr, const int32_t *cscptr, int64_t N, int which, int32_t *list,
+                                    int32_t *ptr, int32_t *count, void *workspace, size_t workspace_bytes,
+                                    void *stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (N <= 0 || N >= INT32_MAX || which < 1 || which > 3) return AMPCONV_E_BADARG;
+  if (((which & 1) && !rowptr) || ((which & 2) && !cscptr) || !list || !ptr || !count || !workspace)
+    return AMPCONV_E_BADARG;
+  if (workspace_bytes < ampconv_active_nodes_workspace_bytes(N)) return AMPCONV_E_WORKSPACE;
+  char *ws = (char *)align_up((size_t)workspace);
+  int32_t *flag = (int32_t *)ws;
+  void *tmp = ws + align_up((size_t)(N + 1) * sizeof(int32_t));
+  size_t tmp_bytes = 0;
+  hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, flag, ptr, (int)(N + 1));
+  const unsigned grid = (unsigned)((N + 1 + 255) / 256);
+  active_flags_kernel<<<grid, 256, 0, stream>>>(rowptr, cscptr, N, which, flag);
+  hipError_t err = hipcub::DeviceScan::ExclusiveSum(tmp, tmp_bytes, flag, ptr, (int)(N + 1), stream);
+  if (err != hipSuccess) return (int)err;
+  active_fill_kernel<<<grid, 256, 0, stream>>>(ptr, N, list, count);
   return ampconv_launch_status();
 }

@@ -52,12 +52,21 @@ __global__ __launch_bounds__(256) void gather_segment_sum_kernel(const float *__
       make_float4((a.x + b.x) * sc, (a.y + b.y) * sc, (a.z + b.z) * sc, (a.w + b.w) * sc);
 }
 
+// one wavefront per node (four per workgroup): 16-byte stores where the row allows them
 template <typename T>
-__global__ void mask_rows_kernel(T *__restrict__ Y, const int32_t *__restrict__ rowptr, int64_t N,
-                                 int64_t F) {
-  const int64_t n = blockIdx.x;
-  if (rowptr[n + 1] != rowptr[n]) return;
-  for (int64_t f = threadIdx.x; f < F; f += blockDim.x) Y[n * F + f] = (T)0.f;
+__global__ __launch_bounds__(256) void mask_rows_kernel(T *__restrict__ Y, const int32_t *__restrict__ rowptr, int64_t N,
+                                                        int64_t F) {
+  const int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N || rowptr[n + 1] != rowptr[n]) return;
+  const int lane = threadIdx.x & 63;
+  T *row = Y + n * F;
+  const int64_t bytes = F * (int64_t)sizeof(T);
+  if ((((uintptr_t)Y | (uintptr_t)bytes) & 15) == 0) {
+    for (int64_t i = 16 * lane; i < bytes; i += 1024)
+      *reinterpret_cast<uint4 *>(reinterpret_cast<char *>(row) + i) = make_uint4(0u, 0u, 0u, 0u);
+  } else {
+    for (int64_t f = lane; f < F; f += 64) row[f] = (T)0.f;
+  }
 }
 
 // partial[b, c] = sum over rows n in block b's slice with deg>0, tokens l of dY[n, l, c]
@@ -122,9 +131,9 @@ extern "C" int ampconv_mask_rows(void *Y, const int32_t *rowptr, int64_t N, int6
   if (N == 0 || F == 0) return AMPCONV_OK;
   if (!Y || !rowptr) return AMPCONV_E_BADARG;
   if (dtype == AMPCONV_BF16)
-    mask_rows_kernel<<<(unsigned)N, 256, 0, (hipStream_t)stream>>>((__bf16 *)Y, rowptr, N, F);
+    mask_rows_kernel<<<(unsigned)((N + 3) / 4), 256, 0, (hipStream_t)stream>>>((__bf16 *)Y, rowptr, N, F);
   else
-    mask_rows_kernel<<<(unsigned)N, 256, 0, (hipStream_t)stream>>>((float *)Y, rowptr, N, F);
+    mask_rows_kernel<<<(unsigned)((N + 3) / 4), 256, 0, (hipStream_t)stream>>>((float *)Y, rowptr, N, F);
   return ampconv_launch_status();
 }
 

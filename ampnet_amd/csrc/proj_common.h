@@ -64,8 +64,9 @@ size_t ampconv_proj_weight_image_bytes_bf16(int N, int K);
 bool ampconv_proj_supported_bf16(int N, int K);
 int ampconv_proj_weight_images_bf16(int count, const ampconv_weight_image_t *jobs, hipStream_t stream);
 int ampconv_proj_rows_bf16(const void *A, int64_t lda, int64_t M, int K, const void *wimage, int N, const void *bias,
-                           const int32_t *rowptr, int L, void *out, int64_t ldc, hipStream_t stream);
+                           const int32_t *rowptr, int L, void *out, int64_t ldc, const int32_t *nodes, int64_t n_nodes,
+                           hipStream_t stream);
 size_t ampconv_proj_wgrad_workspace_bytes_bf16(int64_t M, int Na, int Nb);
 int ampconv_proj_wgrad_bf16(const void *A, int64_t lda, const void *B, int64_t ldb, int64_t M, int Na, int Nb,
                             const int32_t *rowptr, int L, void *dW, void *colsum, void *workspace,
-                            size_t workspace_bytes, hipStream_t stream);
+                            size_t workspace_bytes, const int32_t *nodes, int64_t n_nodes, hipStream_t stream);

@@ -713,10 +713,11 @@ extern "C" int ampconv_proj_weight_image(const void *W, int64_t stride_n, int64_
 
 extern "C" int ampconv_proj_rows(const void *A_, int64_t lda, int64_t M, int K, const void *wimage, int N,
                                  const void *bias_, const int32_t *rowptr, int L, void *out_, int64_t ldc,
-                                 int dtype, void *stream) {
+                                 const int32_t *nodes, int64_t n_nodes, int dtype, void *stream) {
   if (dtype == AMPCONV_BF16)
-    return ampconv_proj_rows_bf16(A_, lda, M, K, wimage, N, bias_, rowptr, L, out_, ldc, (hipStream_t)stream);
-  if (dtype != AMPCONV_F32) return AMPCONV_E_DTYPE;
+    return ampconv_proj_rows_bf16(A_, lda, M, K, wimage, N, bias_, rowptr, L, out_, ldc, nodes, n_nodes,
+                                  (hipStream_t)stream);
+  if (dtype != AMPCONV_F32 || nodes) return AMPCONV_E_DTYPE;      // node lists: bf16 storage only
   const float *A = (const float *)A_, *bias = (const float *)bias_;
   float *out = (float *)out_;
   if (M < 0 || !supported_f32(N, K) || lda < K || ldc < N || lda % 4) return AMPCONV_E_BADARG;
@@ -764,11 +765,12 @@ extern "C" size_t ampconv_proj_wgrad_workspace_bytes(int64_t M, int Na, int Nb, 
 
 extern "C" int ampconv_proj_wgrad(const void *A_, int64_t lda, const void *B_, int64_t ldb, int64_t M, int Na,
                                   int Nb, const int32_t *rowptr, int L, void *dW_, void *colsum_,
-                                  void *workspace, size_t workspace_bytes, int dtype, void *stream) {
+                                  void *workspace, size_t workspace_bytes, const int32_t *nodes, int64_t n_nodes,
+                                  int dtype, void *stream) {
   if (dtype == AMPCONV_BF16)
     return ampconv_proj_wgrad_bf16(A_, lda, B_, ldb, M, Na, Nb, rowptr, L, dW_, colsum_, workspace, workspace_bytes,
-                                   (hipStream_t)stream);
-  if (dtype != AMPCONV_F32) return AMPCONV_E_DTYPE;
+                                   nodes, n_nodes, (hipStream_t)stream);
+  if (dtype != AMPCONV_F32 || nodes) return AMPCONV_E_DTYPE;      // node lists: bf16 storage only
   const float *A = (const float *)A_, *B = (const float *)B_;
   float *dW = (float *)dW_, *colsum = (float *)colsum_;
   if (M < 0 || Na <= 0 || Nb <= 0 || Na % 4 || Nb % 4 || lda < Na || ldb < Nb || lda % 4 || ldb % 4)

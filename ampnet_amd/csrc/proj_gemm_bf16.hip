@@ -92,14 +92,20 @@ struct RowsArgsB {
   int L;
   __bf16 *out;
   int64_t ldc;
-  int row_tiles;              // ceil(M / 128)
+  int row_tiles;              // ceil(M / 128); with a node list: ceil(n_nodes / npt)
   int64_t tiles;              // tile slots: row tiles rounded up to 8, times column tiles
   int Kp, Np;                 // K, N padded to multiples of 64 / 128 (= the weight image's shape)
+  // GATHER: only the rows of the listed nodes are multiplied and written (R-MAT graphs: 38-48 % of cfg5's nodes have no
+  // edge at all on the side a product serves; the reference, which works per EDGE, never touches them either).  A tile
+  // covers npt = 128 / L WHOLE nodes (L >= 16: at most 8), row i of tile t = token i % L of node nodes[t npt + i / L]
+  const int32_t *nodes;
+  int64_t n_nodes;
+  int npt;
 };
 
 // RAGGED: K % 64 != 0 or N % BN != 0: line chunks beyond K are fetched from the row's first chunk (finite data times
 // the image's zero padding), columns beyond N are computed on zero weights and not stored
-template <int BN, bool RAGGED>
+template <int BN, bool RAGGED, bool GATHER>
 __global__ __launch_bounds__(256, 2) void proj_rows_bf16_kernel(RowsArgsB a) {
   constexpr int BM = 128, NW = 4, WN = 2, MTW = 2, NTW = BN / 64;
   constexpr int kWB = BN / 32 * kStepB;        // one W step buffer
@@ -108,7 +114,7 @@ __global__ __launch_bounds__(256, 2) void proj_rows_bf16_kernel(RowsArgsB a) {
   constexpr int kAP = kAB / kFrag / NW;        // A pieces per wave and block
   constexpr int NWB = 3;                       // W ring
   constexpr int oA = NWB * kWB;
-  static_assert(kWP >= 1 && kAP == 4 && NW * 4096 <= kAB && BM * 4 <= kWB, "tile / wave shape");
+  static_assert(kWP >= 1 && kAP == 4 && NW * 4096 <= kAB && 2 * BM * 4 <= kWB, "tile / wave shape");
   __shared__ __attribute__((aligned(16))) char smem[oA + 2 * kAB];     // ONE object: [W ring][Ab0][Ab1]
 
   const int t = threadIdx.x, lane = t & 63;
@@ -130,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void proj_rows_bf16_kernel(RowsArgsB a) {
   const int brd = (NTW * wn) * kStepB + lane * 16;
 
   struct Tile {
-    int64_t row0;
+    int64_t row0, rt;
     int col0;
     bool valid;
   };
@@ -138,16 +144,46 @@ __global__ __launch_bounds__(256, 2) void proj_rows_bf16_kernel(RowsArgsB a) {
     Tile tl;
     const int64_t i_x = u / kXcd;
     const int64_t rt = (i_x / nct) * kXcd + u % kXcd;
+    tl.rt = rt;
     tl.row0 = rt * BM;
     tl.col0 = (int)(i_x % nct) * BN;
     tl.valid = u < a.tiles && rt < a.row_tiles;
     return tl;
   };
+  // GATHER: actual row of tile row i (or -1 if the tile has no node there); the tile's node ids are wave-uniform loads
+  // (explicit s_load: hipcc reads a list that might alias the output through the VECTOR memory path, and the wait it
+  // then inserts for those loads -- vmcnt(0) -- would drain this kernel's DMA queue every tile; the scalar path counts on
+  // lgkmcnt.  The list is padded by 8 entries (include/ampconv.h), slots beyond n_nodes are read and not used)
+  auto gather_row = [&](const Tile &tl, int i) -> int64_t {
+    const int64_t k0 = tl.rt * a.npt;
+    int nid[8];
+    {
+      const int32_t *np = a.nodes + k0;
+      asm volatile("s_load_dword %0, %8, 0x0\n\ts_load_dword %1, %8, 0x4\n\ts_load_dword %2, %8, 0x8\n\t"
+                   "s_load_dword %3, %8, 0xc\n\ts_load_dword %4, %8, 0x10\n\ts_load_dword %5, %8, 0x14\n\t"
+                   "s_load_dword %6, %8, 0x18\n\ts_load_dword %7, %8, 0x1c\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&s"(nid[0]), "=&s"(nid[1]), "=&s"(nid[2]), "=&s"(nid[3]), "=&s"(nid[4]), "=&s"(nid[5]), "=&s"(nid[6]),
+                     "=&s"(nid[7])
+                   : "s"(np)
+                   : "memory");
+    }
+    const int k = i / a.L, l = i - k * a.L;
+    int node = nid[0];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) node = k == q ? nid[q] : node;
+    return (k < a.npt && k0 + k < a.n_nodes) ? (int64_t)node * a.L + l : -1;
+  };
   auto rebase = [&](const Tile &tl) {
 #pragma unroll
     for (int jj = 0; jj < kAP; ++jj) {
-      int64_t m = tl.row0 + rbase + 32 * jj;
-      m = m < a.M ? m : a.M - 1;
+      int64_t m;
+      if (GATHER) {
+        m = gather_row(tl, rbase + 32 * jj);
+        m = m >= 0 ? m : 0;                                                     // any valid row (its product is not stored)
+      } else {
+        m = tl.row0 + rbase + 32 * jj;
+        m = m < a.M ? m : a.M - 1;
+      }
       arow[jj] = a.A + m * a.lda;
     }
   };
@@ -288,10 +324,10 @@ __global__ __launch_bounds__(256, 2) void proj_rows_bf16_kernel(RowsArgsB a) {
     // instruction.
     asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     float *flags = reinterpret_cast<float *>(smem + ring(wb + 2) * kWB);
-    if (a.rowptr) {
-      flags[t & (BM - 1)] = rp1 != rp0 ? 1.f : 0.f;      // both halves of the workgroup write the same values
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    }
+    int *rowtab = reinterpret_cast<int *>(flags + BM);        // GATHER: actual output row of every tile row, or -1
+    if (a.rowptr) flags[t & (BM - 1)] = rp1 != rp0 ? 1.f : 0.f;      // both halves of the workgroup write the same values
+    if (GATHER) rowtab[t & (BM - 1)] = (int)gather_row(cur, t & (BM - 1));
+    if (a.rowptr || GATHER) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     {
       float *stage = reinterpret_cast<float *>(smem + oA + (ab ^ 1) * kAB + w * 4096);
       const int sr = lane >> 2, sc = lane & 3;
@@ -328,14 +364,18 @@ __global__ __launch_bounds__(256, 2) void proj_rows_bf16_kernel(RowsArgsB a) {
 #ifdef AMPCONV_PROJ_ABLATE_STORES      // timing-only developer build: everything but the global stores
               asm volatile("" ::"v"(pk));
 #else
-              if ((!decltype(ragged_rows)::value || cur.row0 + rl0 + row < a.M) && (!RAGGED || colt + 8 * sc < a.N))
+              if (GATHER) {
+                const int orow = rowtab[rl0 + row];
+                if (orow >= 0 && (!RAGGED || colt + 8 * sc < a.N))
+                  *reinterpret_cast<u32x4 *>(a.out + (int64_t)orow * a.ldc + colt + 8 * sc) = pk;
+              } else if ((!decltype(ragged_rows)::value || cur.row0 + rl0 + row < a.M) && (!RAGGED || colt + 8 * sc < a.N))
                 *reinterpret_cast<u32x4 *>(a.out + (cur.row0 + rl0 + row) * a.ldc + colt + 8 * sc) = pk;
 #endif
             }
           }
         }
       };
-      if (cur.row0 + BM <= a.M)            // workgroup-uniform: only the last row tile is ragged
+      if (GATHER || cur.row0 + BM <= a.M)  // workgroup-uniform: only the last row tile is ragged (GATHER: the row table masks)
         store_tile(std::false_type{});
       else
         store_tile(std::true_type{});
@@ -375,11 +415,15 @@ struct WgradArgsB {
   const __bf16 *flags;        // [S * rows_per_slice]
   const __bf16 *zrow;         // 512 bytes of zeros
   int want_colsum;
+  // GATHER: the sum runs over the rows of the listed nodes only.  rowmap[mc] = actual row of compact row mc (token mc % L
+  // of node nodes[mc / L]; -1 beyond the list), written with the flags by row_flags_kernel; the 32 entries of a stage
+  // travel with the DMA group issued three stages before that stage's own rows are requested
+  const int32_t *rowmap;      // [S * rows_per_slice + 6 * 32] or null
 };
 
 constexpr int kRSB = 32;      // rows per stage
 
-template <int T>
+template <int T, bool GATHER>
 __global__ __launch_bounds__(T == 256 ? 512 : 256, 2) void proj_wgrad_bf16_kernel(WgradArgsB a) {
   constexpr int NW = T == 256 ? 8 : 4, NTHR = 64 * NW, WI = 2, WJ = NW / WI;
   constexpr int kRow = T * 2;                       // bytes per image row
@@ -391,9 +435,10 @@ __global__ __launch_bounds__(T == 256 ? 512 : 256, 2) void proj_wgrad_bf16_kerne
   constexpr int kPieces = kImg / kFrag;             // pieces per operand and stage: 16 / 8
   constexpr int kPW = 2 * kPieces / NW;             // pieces per wave and stage: 4
   constexpr int CPR = kRow / 16;                    // 16-byte chunks per row: 32 / 16
-  constexpr int oFl = NBUF * kStage;
+  constexpr int oFl = NBUF * kStage;                // per stage slot: 64 B of row flags, 128 B of row map
+  constexpr int kMeta = 192;
   static_assert(kPW == 4 && kPieces % NW == 0 && NTHR / (T / 8) == 16, "tile / wave shape");
-  __shared__ __attribute__((aligned(16))) char smem[oFl + NBUF * 64];
+  __shared__ __attribute__((aligned(16))) char smem[oFl + NBUF * kMeta];
 
   const int t = threadIdx.x, lane = t & 63;
   const int w = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -426,20 +471,44 @@ __global__ __launch_bounds__(T == 256 ? 512 : 256, 2) void proj_wgrad_bf16_kerne
     src[jj] = (isb ? a.B : a.A) + col;
   }
   const int64_t ld[2] = {a.lda, a.ldb};
+  // DMA group g = the rows of stage g, its 32 row flags and (GATHER) the row map of stage g + 3 -- the stage whose rows
+  // are requested three groups later.  Flags and map are ONE instruction (lanes 0..3 / 4..11) into the meta slot g & 3:
+  // [64 B flags of stage g][128 B map of stage g + 3]; so the map of group g sits in slot (g - 3) & 3 = (g + 1) & 3.  Every
+  // wave copies the same bytes to the same place: every wave issues the same number of vector-memory instructions per
+  // group (4 pieces + 1; the waits below are counted).
   auto issue = [&](int s) {
     const int buf = s & (NBUF - 1);
     const unsigned dst = lds0 + buf * kStage + w * kFrag;
+    const int *map = reinterpret_cast<const int *>(smem + oFl + ((s + 1) & (NBUF - 1)) * kMeta + 64);
 #pragma unroll
     for (int jj = 0; jj < kPW; ++jj) {
       const bool isb = jj >= kPW / 2;
-      const int64_t m = mrow[jj] + (int64_t)s * kRSB;
-      const __bf16 *p = (colok[jj] && m < m1) ? src[jj] + m * ld[isb ? 1 : 0] : zsrc;
+      int64_t m = mrow[jj] + (int64_t)s * kRSB;
+      bool rowok = m < m1;
+      if (GATHER) {
+        const int am = map[(int)(mrow[jj] - m0)];       // mrow - m0 = row within the stage
+        rowok = rowok && am >= 0;
+        m = am >= 0 ? am : 0;
+      }
+      const __bf16 *p = (colok[jj] && rowok) ? src[jj] + m * ld[isb ? 1 : 0] : zsrc;
       dma16(p, dst + (isb ? kImg : 0) + NW * (jj % (kPW / 2)) * kFrag);
     }
-    // the stage's 32 row flags (64 bytes): every wave copies the same bytes to the same place, so that every wave
-    // issues the same number of vector-memory instructions per stage (the waits below are counted)
-    if (lane < 4) dma16(a.flags + m0 + (int64_t)s * kRSB + 8 * lane, lds0 + oFl + buf * 64);
+    if (lane < (GATHER ? 12 : 4)) {
+      const char *sp = (!GATHER || lane < 4)
+                           ? reinterpret_cast<const char *>(a.flags + m0 + (int64_t)s * kRSB) + 16 * lane
+                           : reinterpret_cast<const char *>(a.rowmap + m0 + (int64_t)(s + 3) * kRSB) + 16 * (lane - 4);
+      dma16(sp, lds0 + oFl + buf * kMeta);
+    }
   };
+  if (GATHER) {
+    // bootstrap: the maps of stages 0, 1, 2 (the three groups of the prologue), into the slots the pipeline would use
+#pragma unroll
+    for (int g0 = 0; g0 < 3; ++g0)
+      if (lane >= 4 && lane < 12)
+        dma16(reinterpret_cast<const char *>(a.rowmap + m0 + (int64_t)g0 * kRSB) + 16 * (lane - 4),
+              lds0 + oFl + ((g0 + 1) & (NBUF - 1)) * kMeta);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  }
 
   // transposed reads: lane = (h = lane >> 5, gi = (lane >> 4) & 1, q = (lane >> 2) & 3, p = lane & 3) addresses
   // row 8 h + 4 u + q, columns 32 tile + 16 gi + 4 p .. + 3 (u = 0, 1: the two halves of the 8-deep k group)
@@ -486,7 +555,7 @@ __global__ __launch_bounds__(T == 256 ? 512 : 256, 2) void proj_wgrad_bf16_kerne
         for (int j = 0; j < NJW; ++j) acc[i][j] = MFMA32(af[i], bf[j], acc[i][j]);
     }
     if (do_cs) {
-      const char *fl = smem + oFl + (s & (NBUF - 1)) * 64;
+      const char *fl = smem + oFl + (s & (NBUF - 1)) * kMeta;
 #pragma unroll
       for (int rr = 0; rr < 2; ++rr) {
         const int r = 2 * crg + rr;
@@ -535,9 +604,17 @@ __global__ __launch_bounds__(T == 256 ? 512 : 256, 2) void proj_wgrad_bf16_kerne
 // flags[m] = 1.0 if row m < M and (no mask or the row's node has an in-edge) else 0.0, for m < Mpad (a multiple of 8);
 // the first workgroup also clears the zero row
 __global__ __launch_bounds__(256) void row_flags_kernel(const int32_t *__restrict__ rowptr, int L, int64_t M, int64_t Mpad,
-                                                        unsigned short *__restrict__ flags, u32x4 *__restrict__ zrow) {
+                                                        unsigned short *__restrict__ flags, u32x4 *__restrict__ zrow,
+                                                        const int32_t *__restrict__ nodes, int32_t *__restrict__ rowmap) {
   if (blockIdx.x == 0 && threadIdx.x < 32) zrow[threadIdx.x] = u32x4{0u, 0u, 0u, 0u};
   const int64_t m8 = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+  if (rowmap && m8 < Mpad + 6 * 32) {          // the pipeline reads the map up to six stages past a slice's end
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int64_t m = m8 + k;
+      rowmap[m] = m < M ? (int32_t)((int64_t)nodes[m / L] * L + m % L) : -1;
+    }
+  }
   if (m8 >= Mpad) return;
   unsigned f[8];
 #pragma unroll
@@ -545,7 +622,7 @@ __global__ __launch_bounds__(256) void row_flags_kernel(const int32_t *__restric
     const int64_t m = m8 + k;
     bool on = m < M;
     if (on && rowptr) {
-      const int64_t node = m / L;
+      const int64_t node = nodes ? nodes[m / L] : m / L;
       on = rowptr[node + 1] != rowptr[node];
     }
     f[k] = on ? 0x3F80u : 0u;
@@ -647,29 +724,40 @@ int ampconv_proj_weight_images_bf16(int count, const ampconv_weight_image_t *job
 }
 
 int ampconv_proj_rows_bf16(const void *A, int64_t lda, int64_t M, int K, const void *wimage, int N, const void *bias,
-                           const int32_t *rowptr, int L, void *out, int64_t ldc, hipStream_t stream) {
+                           const int32_t *rowptr, int L, void *out, int64_t ldc, const int32_t *nodes, int64_t n_nodes,
+                           hipStream_t stream) {
   if (M < 0 || !ampconv_proj_supported_bf16(N, K) || lda < K || ldc < N || lda % 8 || ldc % 8) return AMPCONV_E_BADARG;
   if (M == 0) return AMPCONV_OK;
   if (!A || !wimage || !out || (uintptr_t)A % 16 || (uintptr_t)wimage % 16 || (uintptr_t)out % 16)
     return AMPCONV_E_BADARG;
   if (rowptr && (L <= 0 || M > 0x7fffffff)) return AMPCONV_E_BADARG;
+  // node list: whole nodes per tile (L in [16, 128]), no mask (list the nodes that pass it), rows addressed as int32
+  if (nodes && (rowptr || L < 16 || L > 128 || n_nodes < 0 || n_nodes * L > M || M > 0x7fffffff)) return AMPCONV_E_BADARG;
+  if (nodes && n_nodes == 0) return AMPCONV_OK;
   const int Np = (N + 127) / 128 * 128, Kp = (K + 63) / 64 * 64;
   const bool ragged = Np != N || Kp != K;
   const int bn = Np % 256 ? 128 : 256;
-  const int64_t rts = (M + 127) / 128;
+  const int npt = nodes ? 128 / L : 0;
+  const int64_t rts = nodes ? (n_nodes + npt - 1) / npt : (M + 127) / 128;
   if (rts > (int64_t)INT32_MAX / 64) return AMPCONV_E_BADARG;
   const int64_t rtp = (rts + 7) / 8 * 8;
   RowsArgsB a{(const __bf16 *)A, lda, M, K, N, (const char *)wimage, (const __bf16 *)bias, rowptr, L, (__bf16 *)out,
-              ldc, (int)rts, rtp * (Np / bn), Kp, Np};
+              ldc, (int)rts, rtp * (Np / bn), Kp, Np, nodes, n_nodes, npt};
   // two workgroups per CU; a multiple of 8 (slot u of a workgroup keeps u % 8, its XCD label)
   int64_t grid = (int64_t)cu_count() * 2 / kXcd * kXcd;
   if (grid < kXcd) grid = kXcd;
   if (grid > a.tiles) grid = a.tiles;
   const unsigned g = (unsigned)grid;
-  if (bn == 256 && !ragged) proj_rows_bf16_kernel<256, false><<<g, 256, 0, stream>>>(a);
-  else if (bn == 256) proj_rows_bf16_kernel<256, true><<<g, 256, 0, stream>>>(a);
-  else if (!ragged) proj_rows_bf16_kernel<128, false><<<g, 256, 0, stream>>>(a);
-  else proj_rows_bf16_kernel<128, true><<<g, 256, 0, stream>>>(a);
+#define ROWS_LAUNCH(BN_, RG_)                                                                    \
+  do {                                                                                           \
+    if (nodes) proj_rows_bf16_kernel<BN_, RG_, true><<<g, 256, 0, stream>>>(a);                  \
+    else proj_rows_bf16_kernel<BN_, RG_, false><<<g, 256, 0, stream>>>(a);                       \
+  } while (0)
+  if (bn == 256 && !ragged) ROWS_LAUNCH(256, false);
+  else if (bn == 256) ROWS_LAUNCH(256, true);
+  else if (!ragged) ROWS_LAUNCH(128, false);
+  else ROWS_LAUNCH(128, true);
+#undef ROWS_LAUNCH
   return ampconv_launch_status();
 }
 
@@ -679,17 +767,21 @@ size_t ampconv_proj_wgrad_workspace_bytes_bf16(int64_t M, int Na, int Nb) {
   if (M < 0 || Na <= 0 || Nb <= 0 || Na % 8 || Nb % 8) return 0;
   const int Nap = (Na + 127) / 128 * 128, Nbp = (Nb + 127) / 128 * 128;
   const WgradPlanB p = wgrad_plan_bf16(M, Nap, Nbp);
-  return (size_t)p.S * ((size_t)Nap * Nbp + Nap) * sizeof(float) + 512 + align16((size_t)p.S * p.rows_per_slice * 2) + 256;
+  // [partials][zero row 512 B][flags + 256 B][row map: (rows + 6 stages) int32, node lists only: sized always]
+  const size_t rows = (size_t)p.S * p.rows_per_slice;
+  return (size_t)p.S * ((size_t)Nap * Nbp + Nap) * sizeof(float) + 512 + align16(rows * 2) + 256 + (rows + 6 * 32) * 4;
 }
 
 int ampconv_proj_wgrad_bf16(const void *A, int64_t lda, const void *B, int64_t ldb, int64_t M, int Na, int Nb,
                             const int32_t *rowptr, int L, void *dW, void *colsum, void *workspace,
-                            size_t workspace_bytes, hipStream_t st) {
+                            size_t workspace_bytes, const int32_t *nodes, int64_t n_nodes, hipStream_t st) {
   if (M < 0 || Na <= 0 || Nb <= 0 || Na % 8 || Nb % 8 || lda < Na || ldb < Nb || lda % 8 || ldb % 8)
     return AMPCONV_E_BADARG;
   if (!dW || (uintptr_t)dW % 16 || (colsum && (uintptr_t)colsum % 16)) return AMPCONV_E_BADARG;
   if (rowptr && L <= 0) return AMPCONV_E_BADARG;
-  if (M == 0) {
+  if (nodes && (L < 16 || n_nodes < 0 || n_nodes * L > M || M > 0x7fffffff)) return AMPCONV_E_BADARG;
+  const int64_t Me = nodes ? n_nodes * L : M;       // rows the sum runs over (workspace sized for M >= Me)
+  if (Me == 0) {
     hipError_t e = hipMemsetAsync(dW, 0, 2 * (size_t)Na * Nb, st);
     if (e == hipSuccess && colsum) e = hipMemsetAsync(colsum, 0, 2 * (size_t)Na, st);
     return e == hipSuccess ? AMPCONV_OK : (int)e;
@@ -697,21 +789,26 @@ int ampconv_proj_wgrad_bf16(const void *A, int64_t lda, const void *B, int64_t l
   if (!A || !B || (uintptr_t)A % 16 || (uintptr_t)B % 16 || !workspace || (uintptr_t)workspace % 16)
     return AMPCONV_E_BADARG;
   const int Nap = (Na + 127) / 128 * 128, Nbp = (Nb + 127) / 128 * 128;
-  const WgradPlanB p = wgrad_plan_bf16(M, Nap, Nbp);
+  const WgradPlanB p = wgrad_plan_bf16(Me, Nap, Nbp);
   const size_t n_all = (size_t)Nap * Nbp + Nap;
   const size_t part_bytes = (size_t)p.S * n_all * sizeof(float);
   const int64_t Mpad = (int64_t)p.S * p.rows_per_slice;
-  if (workspace_bytes < part_bytes + 512 + align16((size_t)Mpad * 2) + 256) return AMPCONV_E_WORKSPACE;
+  const size_t flag_bytes = align16((size_t)Mpad * 2) + 256;
+  if (workspace_bytes < part_bytes + 512 + flag_bytes + (nodes ? ((size_t)Mpad + 6 * 32) * 4 : 0)) return AMPCONV_E_WORKSPACE;
   char *ws = (char *)workspace;
   unsigned short *flags = (unsigned short *)(ws + part_bytes + 512);
   u32x4 *zrow = (u32x4 *)(ws + part_bytes);
-  row_flags_kernel<<<(unsigned)((Mpad / 8 + 255) / 256), 256, 0, st>>>(rowptr, L, M, Mpad, flags, zrow);
-  WgradArgsB a{(const __bf16 *)A, lda, (const __bf16 *)B, ldb, M, Na, Nb, (float *)workspace, p.S, p.rows_per_slice,
-               Nap, Nbp, (const __bf16 *)flags, (const __bf16 *)zrow, colsum ? 1 : 0};
+  int32_t *rowmap = nodes ? (int32_t *)(ws + part_bytes + 512 + flag_bytes) : nullptr;
+  row_flags_kernel<<<(unsigned)(((Mpad + 6 * 32) / 8 + 255) / 256), 256, 0, st>>>(rowptr, L > 0 ? L : 1, Me, Mpad, flags, zrow,
+                                                                                 nodes, rowmap);
+  WgradArgsB a{(const __bf16 *)A, lda, (const __bf16 *)B, ldb, Me, Na, Nb, (float *)workspace, p.S, p.rows_per_slice,
+               Nap, Nbp, (const __bf16 *)flags, (const __bf16 *)zrow, colsum ? 1 : 0, rowmap};
   const int ntiles = (Nap / p.T) * (Nbp / p.T);
   const unsigned grid = (unsigned)(((p.S + 7) / 8 * 8) * ntiles);
-  if (p.T == 256) proj_wgrad_bf16_kernel<256><<<grid, 512, 0, st>>>(a);
-  else proj_wgrad_bf16_kernel<128><<<grid, 256, 0, st>>>(a);
+  if (p.T == 256 && nodes) proj_wgrad_bf16_kernel<256, true><<<grid, 512, 0, st>>>(a);
+  else if (p.T == 256) proj_wgrad_bf16_kernel<256, false><<<grid, 512, 0, st>>>(a);
+  else if (nodes) proj_wgrad_bf16_kernel<128, true><<<grid, 256, 0, st>>>(a);
+  else proj_wgrad_bf16_kernel<128, false><<<grid, 256, 0, st>>>(a);
   wgrad_reduce_bf16_kernel<<<(unsigned)((n_all / 4 + 31) / 32), 256, 0, st>>>(
       (const float *)workspace, p.S, Na, Nb, Nap, Nbp, (unsigned short *)dW, (unsigned short *)colsum);
   return ampconv_launch_status();

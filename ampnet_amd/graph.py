@@ -16,6 +16,10 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# node lists are worth their extra launches when at most this share of the nodes has any edge
+ACTIVE_LIST_FRACTION = 0.85
+
+
 class EdgeCSR:
     """dst-sorted CSR (rowptr, col, eperm) + src-sorted CSC (cscptr, crow, cperm), int32,
     and cinv[p] = 1 / in-degree(crow[p]) (fp32)."""
@@ -112,6 +116,36 @@ class EdgeCSR:
                         _lib.check(rc, 'ampconv_csc_positions')
                 self._by_edge = None                                  # derived once per graph: not kept
         return self._spos
+
+    def active_nodes(self):
+        """{'in' | 'out' | 'any': (ids int32 [count + 8], count, ptr int32 [N + 1])} -- the nodes with at least one
+        in-edge / out-edge / either, for the projections' node lists (include/ampconv.h: ampconv_active_nodes), or None
+        when (nearly) every node has edges.  Built once per graph: three launches of a flag-scan-fill and ONE read-back.
+        The per-node formulation projects every node; the reference's per-edge one (amp_conv.py:36-47) never touches a
+        node that no edge names."""
+        if not hasattr(self, '_active'):
+            lib = _lib.load()
+            N = self.num_nodes
+            self._active = None
+            if N > 0 and self.num_edges > 0 and self.rowptr.data_ptr() != self.cscptr.data_ptr():
+                i32 = dict(dtype=torch.int32, device=self.device)
+                counts = torch.empty(3, **i32)
+                out = {}
+                with torch.cuda.device(self.device):
+                    nws = lib.ampconv_active_nodes_workspace_bytes(N)
+                    ws = torch.empty(nws, dtype=torch.uint8, device=self.device)
+                    for i, (name, which) in enumerate((('in', 1), ('out', 2), ('any', 3))):
+                        ids, ptr = torch.empty(N + 8, **i32), torch.empty(N + 1, **i32)
+                        rc = lib.ampconv_active_nodes(self.rowptr.data_ptr(), self.cscptr.data_ptr(), N, which,
+                                                      ids.data_ptr(), ptr.data_ptr(), counts[i:].data_ptr(),
+                                                      ws.data_ptr(), nws, _stream())
+                        _lib.check(rc, 'ampconv_active_nodes')
+                        out[name] = (ids, ptr)
+                    cnt = counts.tolist()
+                if cnt[2] <= ACTIVE_LIST_FRACTION * N:
+                    self._active = {name: (out[name][0][:c + 8], c, out[name][1])
+                                    for name, c in zip(('in', 'out', 'any'), cnt)}
+        return self._active
 
     def hub_args(self, side, L, D, n_tiles):
         """(plan pointer, n_chunks, workspace tensor) of the 'dst' or 'src' long-segment plan."""

@@ -513,6 +513,9 @@ def measure_full(workload, steps, warmup, args, rank, world, dev, dist_on, dt_na
     ms = timer.summary()
     ar_ms = sum(a.elapsed_time(b) for a, b in ar_ev) / len(ar_ev) if ar_ev else 0.0
     by_rank = _gather_ranks([ms.get(k, 0.0) for k in EDGE_CALLS] + [ar_ms], dev, dist_on)
+    # node lists (bf16 storage, graphs with many edge-less nodes): what the layer's projections actually covered
+    used = next((getattr(c, '_active', None) for _, _, c in graph_cache.items), None)
+    lists = {k: v[1] for k, v in used.items()} if used else None
     del x, dy, ei
     graph_cache.clear()
     torch.cuda.empty_cache()
@@ -536,6 +539,8 @@ def measure_full(workload, steps, warmup, args, rank, world, dev, dist_on, dt_na
     # SURVEY.md 8d names two rooflines: HBM for the edge phase, the matrix pipe for the per-node
     # projections.  FLOPs per step: attention 14 L^2 D per edge, projections 24 L D^2 per node.
     flops_attn, flops_proj = 14 * L * L * D * E, 24 * L * D * D * N
+    if lists:      # in-projection + its two gradients over the nodes with any edge, out-projection + its two over the receivers
+        flops_proj = L * D * D * (18 * lists['any'] + 6 * lists['in'])
     mfma_peak = MFMA_PEAK_TFLOPS[dt_name]
     t_step = dt / steps
     t_hbm, t_mfma = b_alg / (HBM_PEAK_GBS * 1e9), (flops_attn + flops_proj) / (mfma_peak * 1e12)
@@ -586,6 +591,10 @@ def measure_full(workload, steps, warmup, args, rank, world, dev, dist_on, dt_na
     })
     if alt_out is not None:
         out['alt_gemm'] = alt_out
+    if lists:
+        out['node_lists'] = dict(lists, N=N, note='projections run over the listed nodes only (nodes with an in-edge / an '
+                                 'out-edge / either); layer_flops and node_phase_mfma count those rows; the HBM figures keep '
+                                 "SURVEY 8d's all-node bytes")
     return out
 
 

@@ -109,6 +109,16 @@ int ampconv_csc_positions_from(const int32_t *eperm, const int32_t *by_edge, int
 int ampconv_csc_positions(const int32_t *eperm, const int32_t *cperm, int64_t E,
                           int32_t *scratch, int32_t *spos, void *stream);
 
+/* Node lists for the projections' `nodes` argument (below): the ascending ids of the nodes with at least one in-edge
+ * (which = 1), one out-edge (2) or either (3).  list: N + 8 int32 (the entries behind the count are padding the
+ * projection kernels may read); ptr: N + 1 int32, ptr[n + 1] - ptr[n] = 1 iff node n is listed, ptr[N] = the count
+ * -- a CSR-shaped array, so ampconv_mask_rows(Y, ptr, ...) zeroes exactly the rows of the nodes NOT listed;
+ * count: one device int32.  */
+size_t ampconv_active_nodes_workspace_bytes(int64_t N);
+int ampconv_active_nodes(const int32_t *rowptr, const int32_t *cscptr, int64_t N, int which,
+                         int32_t *list, int32_t *ptr, int32_t *count, void *workspace,
+                         size_t workspace_bytes, void *stream);
+
 /* ---- long segments ("hubs": power-law graphs, BASELINE config 5) ---------------------------
  * One wavefront per (row, head) runs as long as its longest segment.  A plan cuts every CSR
  * (or CSC) segment longer than `chunk` edges into chunks; the edge kernels then reduce each
@@ -240,6 +250,14 @@ int ampconv_masked_colsum(const void *dY, const int32_t *rowptr, int64_t N,
  *   proj_wgrad         : dW[Na, Nb] = sum_m (mask_m A[m, :Na])^T B[m, :Nb] and colsum[Na] = sum_m mask_m A[m, :Na]
  *                        (mask as above, rowptr may be NULL; bf16: see above); deterministic: fixed row slices,
  *                        ordered sum.  `workspace`: proj_wgrad_workspace_bytes(M, Na, Nb, dtype) bytes.
+ *   NODE LISTS (`nodes` != NULL, AMPCONV_BF16 only, 16 <= L <= 128; NULL: every row): only the L rows of each of the
+ *   n_nodes listed nodes (ascending node ids < M / L; the array must be readable for 8 entries past n_nodes:
+ *   ampconv_active_nodes makes such lists) are read, multiplied and -- proj_rows -- written; all other rows of
+ *   `out` are left untouched.  proj_wgrad's workspace is then sized for the listed rows:
+ *   proj_wgrad_workspace_bytes(n_nodes * L, ...).  The per-node formulation computes a projection for EVERY node, the reference one per EDGE:
+ *   a node without in-edges needs no Q row and no output row (it is 0), one without out-edges no K / V rows -- on the
+ *   R-MAT graph of BASELINE config 5 that is 48 % of the nodes on either side.  proj_rows with a list takes no mask
+ *   (rowptr must be NULL: list the nodes that pass it); proj_wgrad sums over the listed rows only.
  * Developer switches read from the environment at the first call (A/B measurements; the defaults are the
  * shipped configuration, nothing else keeps state): AMPCONV_PROJ_ROWS=1 (256 x 256 row tiles),
  * AMPCONV_PROJ_WGRAD_TI=128, AMPCONV_PROJ_WGRAD_BF16_T=128 (smaller weight-gradient tiles), and for the edge phase AMPCONV_FORCE_GENERIC=1,
@@ -259,11 +277,12 @@ typedef struct {
 int ampconv_proj_weight_images(int count, const ampconv_weight_image_t *jobs, int dtype, void *stream);
 int ampconv_proj_rows(const void *A, int64_t lda, int64_t M, int K, const void *wimage, int N,
                       const void *bias, const int32_t *rowptr, int L, void *out, int64_t ldc,
-                      int dtype, void *stream);
+                      const int32_t *nodes, int64_t n_nodes, int dtype, void *stream);
 size_t ampconv_proj_wgrad_workspace_bytes(int64_t M, int Na, int Nb, int dtype);
 int ampconv_proj_wgrad(const void *A, int64_t lda, const void *B, int64_t ldb, int64_t M, int Na,
                        int Nb, const int32_t *rowptr, int L, void *dW, void *colsum,
-                       void *workspace, size_t workspace_bytes, int dtype, void *stream);
+                       void *workspace, size_t workspace_bytes, const int32_t *nodes, int64_t n_nodes,
+                       int dtype, void *stream);
 
 /* ---- GraphSAINT random-walk sampler ("next" row: the step before the hot path) -------------
  * In-tree spec: the reference's vendored PyG sampler, visualization/visualize_graphsaint_subgraphs.py

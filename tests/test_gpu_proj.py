@@ -136,10 +136,10 @@ def test_unsupported_shapes_are_refused_not_miscomputed():
     assert lib.ampconv_proj_supported(256, 256, BF16) == 1 and lib.ampconv_proj_supported(24, 72, BF16) == 1
     assert lib.ampconv_proj_supported(100, 100, BF16) == 0      # bf16 rows move in pieces of 8 elements: library GEMM
     assert lib.ampconv_proj_supported(256, 256, 7) == 0
-    assert lib.ampconv_proj_rows(None, 100, 10, 100, None, 100, None, None, 0, None, 100, F32, None) == -1  # null pointers
-    assert lib.ampconv_proj_rows(None, 3, 10, 3, None, 3, None, None, 0, None, 3, F32, None) == -1
-    assert lib.ampconv_proj_rows(None, 256, 10, 256, None, 256, None, None, 0, None, 256, BF16, None) == -1
-    assert lib.ampconv_proj_rows(None, 256, 10, 256, None, 256, None, None, 0, None, 256, 7, None) == -2   # dtype
+    assert lib.ampconv_proj_rows(None, 100, 10, 100, None, 100, None, None, 0, None, 100, None, 0, F32, None) == -1  # null pointers
+    assert lib.ampconv_proj_rows(None, 3, 10, 3, None, 3, None, None, 0, None, 3, None, 0, F32, None) == -1
+    assert lib.ampconv_proj_rows(None, 256, 10, 256, None, 256, None, None, 0, None, 256, None, 0, BF16, None) == -1
+    assert lib.ampconv_proj_rows(None, 256, 10, 256, None, 256, None, None, 0, None, 256, None, 0, 7, None) == -2   # dtype
 
 
 # ---- bf16 storage (csrc/proj_gemm_bf16.hip; BASELINE config 5).  One bf16 x bf16 product per element pair is exact in
@@ -275,6 +275,169 @@ def test_proj_wgrad_bf16_into_row_block_views():
     ref = cat.t() @ x.double()
     assert float((dw.double() - ref).abs().max()) <= 2.0 ** -8 * float(ref.abs().max()) + 1e-4
     assert float((db.double() - cat.sum(0)).abs().max()) <= 2.0 ** -8 * float(cat.sum(0).abs().max()) + 1e-4
+
+
+def _sparse_graph(N, E, n_silent, dev, seed):
+    """E random edges among the first N - n_silent nodes (the last n_silent have no edge at all), plus a few nodes that
+    only send and a few that only receive."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    act = N - n_silent
+    src = torch.randint(0, act // 2, (E,), device=dev, generator=g)           # senders: the first half
+    dst = torch.randint(act // 4, act, (E,), device=dev, generator=g)         # receivers: the last three quarters
+    return torch.stack([src, dst])
+
+
+@pytest.mark.parametrize('N,E,n_silent', [(97, 300, 30), (1000, 2500, 400), (40, 20, 0)])
+def test_active_nodes_lists(N, E, n_silent):
+    from ampnet_amd import EdgeCSR
+    from ampnet_amd import graph as G_
+    dev = _dev()
+    ei = _sparse_graph(N, E, n_silent, dev, N)
+    csr = EdgeCSR(ei, N)
+    old = G_.ACTIVE_LIST_FRACTION
+    G_.ACTIVE_LIST_FRACTION = 1.0
+    try:
+        lists = csr.active_nodes()
+    finally:
+        G_.ACTIVE_LIST_FRACTION = old
+    has_in = torch.zeros(N, dtype=torch.bool, device=dev)
+    has_in[ei[1]] = True
+    has_out = torch.zeros(N, dtype=torch.bool, device=dev)
+    has_out[ei[0]] = True
+    for name, has in (('in', has_in), ('out', has_out), ('any', has_in | has_out)):
+        ids, cnt, ptr = lists[name]
+        ref = has.nonzero().flatten().int()
+        assert cnt == ref.numel() and ids.numel() == cnt + 8
+        assert torch.equal(ids[:cnt], ref)
+        assert torch.equal(ptr[1:] - ptr[:-1], has.int()) and int(ptr[0]) == 0
+
+
+@pytest.mark.parametrize('L', [16, 20, 33, 64, 128])
+@pytest.mark.parametrize('K,N', [(256, 768), (768, 256), (256, 256), (72, 40)])
+def test_proj_rows_bf16_node_list(L, K, N):
+    """Listed nodes: bitwise the rows of the full product; every other row of `out` untouched."""
+    from ampnet_amd.conv import functional as F_
+    dev = _dev()
+    n_nodes = 61
+    g = torch.Generator(device=dev).manual_seed(L + K)
+    keep = torch.rand(n_nodes, device=dev, generator=g) < 0.55
+    keep[0], keep[-1] = True, False
+    ids = torch.cat([keep.nonzero().flatten().int(), torch.zeros(8, dtype=torch.int32, device=dev)])
+    cnt = int(keep.sum())
+    a = torch.randn(n_nodes * L, K, device=dev, generator=g).bfloat16()
+    W = (torch.randn(N, K, device=dev, generator=g) * 0.1).bfloat16()
+    bias = torch.randn(N, device=dev, generator=g).bfloat16()
+    img = F_.proj_image(W)
+    full = F_.proj_rows(a, img, bias)
+    out = torch.full((n_nodes * L, N), 7.0, dtype=torch.bfloat16, device=dev)
+    F_.proj_rows(a, img, bias, L=L, nodes=(ids, cnt), out=out)
+    rows = keep.repeat_interleave(L)
+    assert torch.equal(out[rows], full[rows])
+    assert (out[~rows] == 7.0).all()
+    # a list of every node = the plain call; an empty list writes nothing
+    every = torch.arange(n_nodes + 8, dtype=torch.int32, device=dev)
+    assert torch.equal(F_.proj_rows(a, img, bias, L=L, nodes=(every, n_nodes)), full)
+    out.fill_(7.0)
+    F_.proj_rows(a, img, bias, L=L, nodes=(ids, 0), out=out)
+    assert (out == 7.0).all()
+    # into a column block of a wider matrix (the layer's Q | K | V thirds)
+    wide = torch.full((n_nodes * L, N + 128), 7.0, dtype=torch.bfloat16, device=dev)
+    F_.proj_rows(a, img, bias, L=L, nodes=(ids, cnt), out=wide[:, 128:])
+    assert torch.equal(wide[:, 128:][rows], full[rows]) and (wide[:, :128] == 7.0).all()
+
+
+@pytest.mark.parametrize('L,n_nodes', [(16, 50), (20, 700), (20, 4001), (48, 333), (128, 70)])
+@pytest.mark.parametrize('Na,Nb', [(256, 256), (768, 256), (72, 24)])
+def test_proj_wgrad_bf16_node_list(L, n_nodes, Na, Nb):
+    """Sum over the listed nodes' rows only: NaN in every other row must not matter; fp64 reference over those rows."""
+    from ampnet_amd.conv import functional as F_
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(L + n_nodes + Na)
+    keep = torch.rand(n_nodes, device=dev, generator=g) < 0.5
+    keep[1], keep[-1] = True, True
+    keep[0] = False
+    ids = torch.cat([keep.nonzero().flatten().int(), torch.zeros(8, dtype=torch.int32, device=dev)])
+    cnt = int(keep.sum())
+    rows = keep.repeat_interleave(L)
+    a = torch.randn(n_nodes * L, Na, device=dev, generator=g).bfloat16()
+    b = torch.randn(n_nodes * L, Nb, device=dev, generator=g).bfloat16()
+    a[~rows] = float('nan')
+    b[~rows] = float('nan')
+    dw = torch.empty(Na, Nb, device=dev, dtype=torch.bfloat16)
+    cs = torch.empty(Na, device=dev, dtype=torch.bfloat16)
+    F_.proj_wgrad(a, b, dw, cs, L=L, nodes=(ids, cnt))
+    ad, bd = a[rows].double(), b[rows].double()
+    ref_dw, ref_cs = ad.t() @ bd, ad.sum(0)
+    noise = 4e-7 * (cnt * L) ** 0.5
+    err = (dw.double() - ref_dw).abs()
+    assert not (err > 2.0 ** -8 * ref_dw.abs() * 1.001 + noise).any(), float(err.max())      # (NaN compares False: checked next)
+    assert torch.isfinite(dw).all() and torch.isfinite(cs).all()
+    err = (cs.double() - ref_cs).abs()
+    assert not (err > 2.0 ** -8 * ref_cs.abs() * 1.001 + noise).any(), float(err.max())
+    dw2, cs2 = torch.empty_like(dw), torch.empty_like(cs)
+    F_.proj_wgrad(a, b, dw2, cs2, L=L, nodes=(ids, cnt))
+    assert torch.equal(dw, dw2) and torch.equal(cs, cs2)
+    # the compacted rows through the plain kernel: the same sum (slice boundaries differ: not bitwise)
+    dw3, cs3 = torch.empty_like(dw), torch.empty_like(cs)
+    F_.proj_wgrad(a[rows].contiguous(), b[rows].contiguous(), dw3, cs3)
+    assert float((dw3.double() - dw.double()).abs().max()) <= 2.0 ** -7 * float(ref_dw.abs().max()) + noise
+
+
+def test_proj_node_list_argument_checks():
+    from ampnet_amd import _lib
+    lib = _lib.load()
+    dev = _dev()
+    F32, BF16 = _lib.AMPCONV_F32, _lib.AMPCONV_BF16
+    x = torch.zeros(64 * 20, 256, device=dev, dtype=torch.bfloat16)
+    ids = torch.zeros(72, dtype=torch.int32, device=dev)
+    from ampnet_amd.conv import functional as F_
+    img = F_.proj_image(torch.zeros(256, 256, device=dev, dtype=torch.bfloat16))[0]
+    rp = torch.zeros(65, dtype=torch.int32, device=dev)
+
+    def rows(L, rowptr, dtype, n):
+        return lib.ampconv_proj_rows(x.data_ptr(), 256, x.size(0), 256, img.data_ptr(), 256, None,
+                                     None if rowptr is None else rowptr.data_ptr(), L, x.data_ptr(), 256,
+                                     ids.data_ptr(), n, dtype, None)
+    assert rows(20, None, F32, 4) == -2          # fp32 storage takes no list
+    assert rows(20, rp, BF16, 4) == -1           # list and mask together
+    assert rows(8, None, BF16, 4) == -1          # L < 16
+    assert rows(200, None, BF16, 4) == -1        # L > 128
+    assert rows(20, None, BF16, 65) == -1        # more listed nodes than the matrix has
+
+
+def test_bf16_layer_node_lists_match_the_full_projections():
+    """The layer on a graph where 40 % of the nodes have no edge: with node lists (default) and without
+    (AMPCONV_NODE_LISTS=0 semantics) the outputs and every gradient agree -- bitwise on the rows, to the slice order on
+    the weight gradients."""
+    from ampnet_amd import AMPConv
+    from ampnet_amd.conv import functional as F_
+    dev = _dev()
+    torch.manual_seed(4)
+    N, E, L, D, H = 500, 3000, 20, 256, 8
+    ei = _sparse_graph(N, E, 200, dev, 1)
+    layer = AMPConv(D, H).to(dev).to(torch.bfloat16)
+    x0 = torch.randn(N, L * D, device=dev).bfloat16()
+    dy = torch.randn(N, L * D, device=dev).bfloat16()
+    res = []
+    for on in (True, False):
+        old = F_.NODE_LISTS
+        F_.NODE_LISTS = on
+        try:
+            x = x0.clone().requires_grad_(True)
+            layer.zero_grad()
+            y = layer(x, ei)
+            y.backward(dy)
+            m = layer.multi_head_attention
+            res.append([y.detach(), x.grad] + [p.grad.clone() for p in (m.in_proj_weight, m.in_proj_bias,
+                                                                          m.out_proj.weight, m.out_proj.bias)])
+        finally:
+            F_.NODE_LISTS = old
+    from ampnet_amd import graph_cache
+    assert graph_cache.get(ei, N).active_nodes() is not None          # the list path really ran
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    for a, b in zip(res[0][2:], res[1][2:]):
+        assert torch.isfinite(a).all()
+        assert float((a.double() - b.double()).abs().max()) <= 2.0 ** -7 * float(b.double().abs().max()) + 1e-6
 
 
 def test_bf16_layer_runs_no_library_gemm(monkeypatch):
