@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('AMPCONV_LIB_PATH', os.path.join(_HERE, 'libampconv.so'))   # override: dev A/B builds
 
-EXPECTED_ABI = 103          # AMPCONV_VERSION of include/ampconv.h this binding was written against
+EXPECTED_ABI = 104          # AMPCONV_VERSION of include/ampconv.h this binding was written against
 
 AMPCONV_F32 = 0
 AMPCONV_BF16 = 1
@@ -77,9 +77,10 @@ SIGNATURES = {
     'ampconv_proj_weight_image_bytes': (_sz, [_i32, _i32, _i32]),
     'ampconv_proj_weight_image': (_i32, [_vp, _i64, _i64, _i32, _i32, _vp, _i32, _vp]),
     'ampconv_proj_weight_images': (_i32, [_i32, _vp, _i32, _vp]),
-    'ampconv_proj_rows': (_i32, [_vp, _i64, _i64, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i64, _vp, _i64, _i32, _vp]),
+    'ampconv_proj_rows': (_i32, [_vp, _i64, _i64, _i32, _vp, _i32, _vp, _vp, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _i32, _vp]),
     'ampconv_proj_wgrad_workspace_bytes': (_sz, [_i64, _i32, _i32, _i32]),
-    'ampconv_proj_wgrad': (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _sz, _vp, _i64, _i32, _vp]),
+    'ampconv_proj_wgrad': (_i32, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _sz, _vp, _i64, _vp, _vp, _i32, _vp]),
+    'ampconv_absmax': (_i32, [_vp, _i64, _i64, _i32, _i32, _vp, _i32, _vp]),
     'ampconv_active_nodes_workspace_bytes': (_sz, [_i64]),
     'ampconv_active_nodes': (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     'ampconv_segment_mean': (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _vp]),

@@ -101,6 +101,31 @@ def _tn_matmul(a, b, chunks=128):
 # three bf16 terms, six partial products on v_mfma_f32_32x32x16_bf16, fp32 accumulate; bf16 storage
 # (csrc/proj_gemm_bf16.hip): one product, fp32 accumulate, one rounding on the way out
 NODE_LISTS = os.environ.get('AMPCONV_NODE_LISTS', '1') != '0'      # developer switch (A/B measurements)
+# fp32 storage: two scaled fp16 planes, three products (include/ampconv.h "SCALED MODE"); '0': three bf16 planes, six
+PROJ_SCALED = os.environ.get('AMPCONV_PROJ_SCALED', '1') != '0'
+# ... for operands of at least this many elements: the mode costs five more (tiny) launches per layer call -- two
+# maxima in the forward pass, two in the backward, one for the weights -- which a Cora-sized step (0.6 ms) feels and a
+# GraphSAINT batch (24 ms) does not
+PROJ_SCALED_MIN_ELEMENTS = 1 << 24
+
+
+def absmax(t2, out=None, reset=False):
+    """Largest finite magnitude of a 2-D tensor with contiguous rows, as a one-element device tensor (no host sync):
+    the scale source of the fp32 projections' two-plane mode.  `out`: merge into an existing maximum (reset: zero it
+    first)."""
+    lib = _lib.load()
+    t2 = _aligned(t2)
+    if out is None:
+        out, reset = torch.empty(1, dtype=torch.float32, device=t2.device), True
+    _lib.check(lib.ampconv_absmax(t2.data_ptr(), t2.stride(0), t2.size(0), t2.size(1), _code(t2.dtype), out.data_ptr(),
+                                  1 if reset else 0, _stream()), 'ampconv_absmax')
+    return out
+
+
+def _zero(scalar):
+    """Zero a one-element fp32 device tensor on the current stream (the receiving end of proj_rows' out_amax)."""
+    _lib.check(_lib.load().ampconv_absmax(None, 0, 0, 0, _lib.AMPCONV_F32, scalar.data_ptr(), 1, _stream()),
+               'ampconv_absmax')
 
 
 def _code(dtype):
@@ -149,10 +174,12 @@ def proj_image(W, transpose=False):
     return proj_images([(W, transpose)])[0]
 
 
-def proj_rows(a2, image, bias=None, rowptr=None, L=0, nodes=None, out=None):
+def proj_rows(a2, image, bias=None, rowptr=None, L=0, nodes=None, out=None, amax=None, out_amax=None):
     """out[M, N] = (a2[M, K] @ B^T + bias) * [node of the row has an in-edge]  (mask only with rowptr).
     nodes = (ids, count[, ptr]) (EdgeCSR.active_nodes): only the L rows of each listed node are computed and written
-    (bf16; the other rows of `out` keep what they hold: uninitialised unless the caller passes `out`)."""
+    (bf16; the other rows of `out` keep what they hold: uninitialised unless the caller passes `out`).
+    amax (fp32 storage): one-element tensor, the operand's largest finite magnitude or a bound of it (absmax) -> the
+    two-plane scaled kernels; out_amax: a zeroed one-element tensor that receives the output's."""
     lib = _lib.load()
     img, N, K, wdt = image
     assert a2.dim() == 2 and a2.size(1) == K and a2.stride(1) == 1 and a2.dtype == wdt
@@ -163,16 +190,16 @@ def proj_rows(a2, image, bias=None, rowptr=None, L=0, nodes=None, out=None):
     assert out.shape == (a2.size(0), N) and out.stride(1) == 1 and out.dtype == wdt
     ids, cnt = (nodes[0].data_ptr(), nodes[1]) if nodes is not None else (None, 0)
     _lib.check(lib.ampconv_proj_rows(a2.data_ptr(), a2.stride(0), a2.size(0), K, img.data_ptr(), N, _ptr(bias),
-                                     _ptr(rowptr), L, out.data_ptr(), out.stride(0), ids, cnt, _code(wdt), _stream()),
-               'ampconv_proj_rows')
+                                     _ptr(rowptr), L, out.data_ptr(), out.stride(0), ids, cnt, _ptr(amax), _ptr(out_amax),
+                                     _code(wdt), _stream()), 'ampconv_proj_rows')
     return out
 
 
-def proj_wgrad(a2, b2, dw, colsum=None, rowptr=None, L=0, nodes=None):
+def proj_wgrad(a2, b2, dw, colsum=None, rowptr=None, L=0, nodes=None, amax=None):
     """dw[Na, Nb] = (mask * a2)^T @ b2 and colsum[Na] = column sums of mask * a2, into caller-owned (views of)
     contiguous tensors of the inputs' dtype; reduction over the rows in fixed slices (bitwise reproducible).
     bf16: the mask acts on the column sums only (include/ampconv.h).  nodes: the sums run over the L rows of each
-    listed node only (bf16)."""
+    listed node only (bf16).  amax = (a2's, b2's) largest finite magnitudes (fp32 storage: scaled two-plane kernels)."""
     lib = _lib.load()
     M, Na = a2.shape
     Nb = b2.size(1)
@@ -184,7 +211,8 @@ def proj_wgrad(a2, b2, dw, colsum=None, rowptr=None, L=0, nodes=None):
     nws = lib.ampconv_proj_wgrad_workspace_bytes(cnt * L if nodes is not None else M, Na, Nb, code)
     ws = torch.empty(max(nws, 16) // 4, dtype=torch.float32, device=a2.device)
     _lib.check(lib.ampconv_proj_wgrad(a2.data_ptr(), a2.stride(0), b2.data_ptr(), b2.stride(0), M, Na, Nb,
-                                      _ptr(rowptr), L, dw.data_ptr(), _ptr(colsum), ws.data_ptr(), nws, ids, cnt, code,
+                                      _ptr(rowptr), L, dw.data_ptr(), _ptr(colsum), ws.data_ptr(), nws, ids, cnt,
+                                      _ptr(amax[0]) if amax else None, _ptr(amax[1]) if amax else None, code,
                                       _stream()), 'ampconv_proj_wgrad')
 
 
@@ -249,19 +277,30 @@ class AMPConvFunction(torch.autograd.Function):
                 ws = [w_in, w_out] if shared else [w_in[:D], w_in[D:], w_out]
                 imgs = proj_images([(w, False) for w in ws] + [(w, True) for w in ws])
             lists = node_lists(csr, xq.dtype, L, native, shared and Nq == csr.num_nodes)
+            # fp32 storage: operand maxima for the scaled two-plane products, device-side.  am = [x (query side), the
+            # in-projection's output (K | V side: an upper bound of |Obar|, a mean of convex combinations of V rows),
+            # x (key/value side)]; inputs are measured by one pass, outputs recorded by the product that writes them
+            am = None
+            if native and PROJ_SCALED and xq.dtype == torch.float32 and xq2.numel() >= PROJ_SCALED_MIN_ELEMENTS:
+                am = torch.empty(3, dtype=torch.float32, device=xq.device)
+                absmax(xq2, am[0:1], reset=True)
+                _zero(am[1:2])
+            sl = (lambda i: am[i:i + 1]) if am is not None else (lambda i: None)
             if shared:
                 # (node lists: Q rows matter for nodes with in-edges, K / V rows for nodes with out-edges; the rows of
                 # nodes with neither are never read by an edge pass and stay unwritten)
-                qkv = (proj_rows(xq2, imgs[0], b_in, L=L, nodes=lists and lists['any']) if native
-                       else torch.addmm(b_in, xq2, w_in.t()))              # [N*L, 3D]
+                qkv = (proj_rows(xq2, imgs[0], b_in, L=L, nodes=lists and lists['any'], amax=sl(0), out_amax=sl(1))
+                       if native else torch.addmm(b_in, xq2, w_in.t()))              # [N*L, 3D]
                 Qv, Kv, Vv = (_view(qkv, i * D, L, dh) for i in range(3))
                 xkv2 = xq2
                 kv = None
             else:
                 xkv2 = xkv.contiguous().view(Nk * L, D)
                 if native:
-                    qkv = proj_rows(xq2, imgs[0], b_in[:D])
-                    kv = proj_rows(xkv2, imgs[1], b_in[D:])
+                    if am is not None:
+                        absmax(xkv2, am[2:3], reset=True)
+                    qkv = proj_rows(xq2, imgs[0], b_in[:D], amax=sl(0))
+                    kv = proj_rows(xkv2, imgs[1], b_in[D:], amax=sl(2), out_amax=sl(1))
                 else:
                     qkv = torch.addmm(b_in[:D], xq2, w_in[:D].t())         # [Nq*L, D]
                     kv = torch.addmm(b_in[D:], xkv2, w_in[D:].t())         # [Nk*L, 2D]
@@ -273,7 +312,7 @@ class AMPConvFunction(torch.autograd.Function):
                 y = proj_rows(obar, imgs[1], b_out, L=L, nodes=lists['in'])
                 _zero_unlisted(y, lists['in'], Nq, L)
             elif native:    # bias and the in-degree mask (rows nobody sends to stay exactly 0) in the epilogue
-                y = proj_rows(obar, imgs[1 if shared else 2], b_out, csr.rowptr, L)
+                y = proj_rows(obar, imgs[1 if shared else 2], b_out, csr.rowptr, L, amax=sl(1))
             else:
                 y = torch.addmm(b_out, obar, w_out.t())
                 io = _lib.AMPCONV_BF16 if y.dtype == torch.bfloat16 else _lib.AMPCONV_F32
@@ -282,7 +321,7 @@ class AMPConvFunction(torch.autograd.Function):
         ctx.set_materialize_grads(False)     # no zero-filled [N*L, 3D] gradient for the qkv side output
         ctx.save_for_backward(xq2, xkv2, w_in, w_out, qkv, kv, obar)
         ctx.csr, ctx.dims, ctx.shared, ctx.dtype, ctx.gemm = csr, (Nq, Nk, L, D, H), shared, dtype, gemm
-        ctx.lists = lists
+        ctx.lists, ctx.amax = lists, am
         ctx.images_t = imgs[len(imgs) // 2:] if imgs else None     # the transposed images, for the input gradients
         ctx.mark_non_differentiable(qkv)
         if kv is not None:
@@ -305,7 +344,13 @@ class AMPConvFunction(torch.autograd.Function):
             native = proj_native(ctx.gemm, dy2.dtype, D)
             # out-projection: rows with no in-edge contribute nothing (their obar is 0, and
             # the bias gradient masks them explicitly)
-            lists = ctx.lists
+            lists, am = ctx.lists, ctx.amax
+            ag = None           # maxima of the gradients that are operands: [dY, dQ(KV), dKV]
+            if am is not None:
+                ag = torch.empty(3, dtype=torch.float32, device=dev)
+                absmax(dy2, ag[0:1], reset=True)
+            sl = (lambda t, i: t[i:i + 1]) if am is not None else (lambda t, i: None)
+            pair = (lambda a, b: (a, b)) if am is not None else (lambda a, b: None)
             if native:
                 dw_out = torch.empty_like(w_out)
                 db_out = torch.empty(D, dtype=dy2.dtype, device=dev)
@@ -313,8 +358,8 @@ class AMPConvFunction(torch.autograd.Function):
                     proj_wgrad(dy2, obar, dw_out, db_out, L=L, nodes=lists['in'])
                     dobar = proj_rows(dy2, ctx.images_t[-1], L=L, nodes=lists['in'])
                 else:
-                    proj_wgrad(dy2, obar, dw_out, db_out, csr.rowptr, L)
-                    dobar = proj_rows(dy2, ctx.images_t[-1])
+                    proj_wgrad(dy2, obar, dw_out, db_out, csr.rowptr, L, amax=pair(sl(ag, 0), sl(am, 1)))
+                    dobar = proj_rows(dy2, ctx.images_t[-1], amax=sl(ag, 0))
             else:
                 scratch = torch.empty((1 + _lib.COLSUM_BLOCKS) * D, dtype=torch.float32, device=dev)
                 io = _lib.AMPCONV_BF16 if dy2.dtype == torch.bfloat16 else _lib.AMPCONV_F32
@@ -374,14 +419,19 @@ class AMPConvFunction(torch.autograd.Function):
                         _zero_unlisted(dxq2, lists['any'], Nq, L)
                         dxq = dxq2.view(Nq, L * D)
                 elif shared:
-                    proj_wgrad(dqkv, xq2, dw_in, db_in)
-                    dxq = proj_rows(dqkv, ctx.images_t[0]).view(Nq, L * D) if need_xq else None
+                    if am is not None:
+                        absmax(dqkv, ag[1:2], reset=True)
+                    proj_wgrad(dqkv, xq2, dw_in, db_in, amax=pair(sl(ag, 1), sl(am, 0)))
+                    dxq = proj_rows(dqkv, ctx.images_t[0], amax=sl(ag, 1)).view(Nq, L * D) if need_xq else None
                     dxkv = None
                 else:
-                    proj_wgrad(dqkv, xq2, dw_in[:D], db_in[:D])
-                    proj_wgrad(dkv, xkv2, dw_in[D:], db_in[D:])
-                    dxq = proj_rows(dqkv, ctx.images_t[0]).view(Nq, L * D) if need_xq else None
-                    dxkv = proj_rows(dkv, ctx.images_t[1]).view(Nk, L * D) if need_xkv else None
+                    if am is not None:
+                        absmax(dqkv, ag[1:2], reset=True)
+                        absmax(dkv, ag[2:3], reset=True)
+                    proj_wgrad(dqkv, xq2, dw_in[:D], db_in[:D], amax=pair(sl(ag, 1), sl(am, 0)))
+                    proj_wgrad(dkv, xkv2, dw_in[D:], db_in[D:], amax=pair(sl(ag, 2), sl(am, 2)))
+                    dxq = proj_rows(dqkv, ctx.images_t[0], amax=sl(ag, 1)).view(Nq, L * D) if need_xq else None
+                    dxkv = proj_rows(dkv, ctx.images_t[1], amax=sl(ag, 2)).view(Nk, L * D) if need_xkv else None
             elif shared:
                 dw_in = _tn_matmul(dqkv, xq2)
                 if db_v is not None:

@@ -23,6 +23,16 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {   // v_cvt_p
 __device__ __forceinline__ float lo_as_f32(unsigned h) { return __builtin_bit_cast(float, h << 16); }
 __device__ __forceinline__ float hi_as_f32(unsigned h) { return __builtin_bit_cast(float, h & 0xFFFF0000u); }
 
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned cvt_pk_f16(float a, float b) {    // v_cvt_pk_f16_f32 (RNE)
+  f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+}
+#define MFMA32H(a, b, c)                                                                                         \
+  __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(proj::f16x8, a), __builtin_bit_cast(proj::f16x8, b), \
+                                         (c), 0, 0, 0)
+
 #define MFMA32(a, b, c)                                                                                          \
   __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(proj::bf16x8, a), __builtin_bit_cast(proj::bf16x8, b), \
                                           (c), 0, 0, 0)

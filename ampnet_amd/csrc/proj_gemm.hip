@@ -15,6 +15,15 @@
 // of the product itself; bf16 x bf16 products are exact in the fp32 accumulator).  Six MFMAs of 16x the
 // fp32 rate = 2.7x the fp32 peak, and bf16 MFMAs co-execute with the VALU work of the split.
 //
+// SCALED MODE (the caller passes the largest finite magnitude of each fp32 operand, ampconv_absmax / proj_rows'
+// out_absmax): x' = x * 2^(14 - floor(log2 max)) fits fp16's range, x' = h1 + h2 with h1 = fp16(x'), h2 = fp16(x' - h1)
+// (2 x 11 bits + the sign of the remainder: |x' - h1 - h2| <= 2^-22 |x'|; an element below 2^-17 of the tensor's
+// maximum has a subnormal remainder, absolute error <= 2^-25 in scaled units = 2^-39 of the maximum), and a product is
+// the fp32 sum of THREE v_mfma_f32_32x32x16_f16 partial products a1 b1 + a1 b2 + a2 b1 (dropped: a2 b2 <= 2^-22 |a b|);
+// the power-of-two scales leave through the epilogue, exactly.  Measured against fp64 the result is as close as the
+// six-product one (half the accumulator roundings) and closer than the library's fp32 GEMM; half the
+// matrix instructions, two thirds of the split and LDS work.
+//
 // Two kernels:
 //   proj_rows  out[M, N] = A[M, K] W^T (+ bias) (* row mask)      A fp32 rows, split on the way into LDS;
 //              W pre-split ONCE into an image of ready MFMA fragments (ampconv_proj_weight_image) that is
@@ -29,7 +38,31 @@
 namespace {
 using namespace proj;
 
-constexpr int kTile3 = 3 * kFrag;    // the three planes of one (32-row tile, 16-deep k step)
+// HP = false: three bf16 planes, six products (exact split, any range); true: two fp16 planes of the SCALED operand,
+// three products
+template <bool HP>
+struct Pl {
+  static constexpr int NP = HP ? 2 : 3;           // planes
+  static constexpr int NQ = HP ? 3 : 6;           // partial products, smallest first: planes (PA[q], PB[q])
+  static constexpr int kTile = NP * kFrag;        // the planes of one (32-row tile, 16-deep k step)
+};
+__device__ constexpr int kPA[2][6] = {{2, 1, 0, 1, 0, 0}, {1, 0, 0, 0, 0, 0}};
+__device__ constexpr int kPB[2][6] = {{0, 1, 2, 0, 1, 0}, {0, 1, 0, 0, 0, 0}};
+template <bool HP>
+__device__ __forceinline__ f32x16 mfma_p(const i32x4 &a, const i32x4 &b, const f32x16 &c) {
+  if constexpr (HP) return MFMA32H(a, b, c);
+  else return MFMA32(a, b, c);
+}
+
+// scale of a tensor whose largest finite magnitude is `amax`: 2^(14 - floor(log2 amax)), so that the scaled maximum
+// lies in [2^14, 2^15) (fp16: finite below 2^16); exponent field clamped to [15, 254] (zero / subnormal maxima take
+// 2^126, a non-finite one -- never produced by ampconv_absmax -- 2^-113)
+__device__ __forceinline__ float plane_scale(float amax) {
+  int e = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 0xFFu);
+  e = e < 15 ? 15 : (e > 254 ? 254 : e);
+  return __builtin_bit_cast(float, (unsigned)(268 - e) << 23);
+}
+__device__ __forceinline__ float plane_unscale(float amax) { return 1.f / plane_scale(amax); }     // exact: a power of two
 
 // (x0, x1) -> packed bf16 pairs of the three planes; x == h1 + h2 + h3 exactly
 struct Pair3 {
@@ -43,27 +76,30 @@ __device__ __forceinline__ Pair3 split_pair(float x0, float x1) {
   return Pair3{(int)a, (int)b, (int)cvt_pk_bf16(s0, s1)};
 }
 
-// six partial products, smallest first
-__device__ __forceinline__ f32x16 mfma6(const i32x4 (&a)[3], const i32x4 (&b)[3], f32x16 c) {
-  c = MFMA32(a[2], b[0], c);
-  c = MFMA32(a[1], b[1], c);
-  c = MFMA32(a[0], b[2], c);
-  c = MFMA32(a[1], b[0], c);
-  c = MFMA32(a[0], b[1], c);
-  c = MFMA32(a[0], b[0], c);
-  return c;
+// (x0, x1) * s -> packed fp16 pairs of the two planes (h3 unused)
+__device__ __forceinline__ Pair3 split_pair_h(float x0, float x1, float s) {
+  x0 *= s;
+  x1 *= s;
+  const unsigned a = cvt_pk_f16(x0, x1);
+  const f16x2 av = __builtin_bit_cast(f16x2, a);
+  const float r0 = x0 - (float)av[0], r1 = x1 - (float)av[1];
+  return Pair3{(int)a, (int)cvt_pk_f16(r0, r1), 0};
+}
+template <bool HP>
+__device__ __forceinline__ Pair3 split_pair_t(float x0, float x1, float s) {
+  if constexpr (HP) return split_pair_h(x0, x1, s);
+  else return split_pair(x0, x1);
 }
 
-// the same six products for a ROW of accumulators that share the A fragment, plane-pair major: consecutive MFMAs go to
+// the partial products for a ROW of accumulators that share the A fragment, plane-pair major: consecutive MFMAs go to
 // different accumulators (a dependent 32x32x16 waits ~25 % of its own length for the previous result: K = 768 row
-// product 40.7 -> 38.3 ms) and every accumulator still receives its products in mfma6's order (bit-identical results)
-template <int NJ>
-__device__ __forceinline__ void mfma6_row(const i32x4 (&a)[3], const i32x4 (&b)[NJ][3], f32x16 (&c)[NJ]) {
-  constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+// product 40.7 -> 38.3 ms); every accumulator receives its products smallest first
+template <bool HP, int NJ>
+__device__ __forceinline__ void mfma_row(const i32x4 (&a)[3], const i32x4 (&b)[NJ][3], f32x16 (&c)[NJ]) {
 #pragma unroll
-  for (int q = 0; q < 6; ++q)
+  for (int q = 0; q < Pl<HP>::NQ; ++q)
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) c[j] = MFMA32(a[PA[q]], b[j][PB[q]], c[j]);
+    for (int j = 0; j < NJ; ++j) c[j] = mfma_p<HP>(a[kPA[HP][q]], b[j][kPB[HP][q]], c[j]);
 }
 
 #ifdef AMPCONV_PROJ_STAMPS
@@ -85,10 +121,12 @@ __device__ unsigned long long g_proj_stamps[8 * 4096];
 
 // ---------------------------------------------------------------------------------------------------
 // weight image: for k step ks (16 deep), 32-column tile n32 of the OUTPUT, plane p:
-//   fragment (ks * N/32 + n32) * 3 + p,  1 KiB, lane l = (r = l & 31, h = l >> 5) holds plane p of
+//   fragment (ks * N/32 + n32) * NP + p,  1 KiB, lane l = (r = l & 31, h = l >> 5) holds plane p of
 //   B[n32 * 32 + r][ks * 16 + 8 h + 0..7]      with B[n][k] = W[n * stride_n + k * stride_k]
-// i.e. exactly the B operand of v_mfma_f32_32x32x16_bf16, in lane order; the fragments of one k step and one
+// i.e. exactly the B operand of v_mfma_f32_32x32x16_{bf16,f16}, in lane order; the fragments of one k step and one
 // block of columns are contiguous, so a stage is one linear LDS-DMA copy.
+// An fp32 image holds BOTH forms: [three bf16 planes: Np Kp 6 bytes][two fp16 planes of the scaled weight: Np Kp 4 bytes]
+// [512 bytes: 64 partial maxima and, at [64], the weight's largest finite magnitude, which the scaled kernels read back]
 struct ImageJob {
   const float *W;
   int64_t sn, sk;
@@ -98,6 +136,49 @@ struct ImageJob {
 struct ImageJobs {
   ImageJob j[8];
 };
+__host__ __device__ inline size_t image_half_offset(int N, int K) {
+  return (size_t)((N + 127) / 128 * 128) * (size_t)((K + 31) / 32 * 32) * 6;
+}
+__host__ __device__ inline size_t image_amax_offset(int N, int K) {
+  return (size_t)((N + 127) / 128 * 128) * (size_t)((K + 31) / 32 * 32) * 10;
+}
+__device__ __forceinline__ float finite_abs(float x) {          // |x|, or 0 for NaN / infinity
+  const float a = __builtin_fabsf(x);
+  return a < __builtin_inff() ? a : 0.f;
+}
+// 64 workgroups per weight, each the largest finite magnitude of its share, read in memory order; no atomics (nothing to
+// zero first): the partial maxima go to the image's trailer [64 floats], weight_image_kernel folds them ([64] = the result)
+constexpr int kAmaxParts = 64;
+__global__ __launch_bounds__(256) void weight_absmax_kernel(ImageJobs jobs) {
+  const ImageJob jb = jobs.j[blockIdx.y];
+  __shared__ float red[4];
+  const bool kfast = jb.sk == 1;                              // which index walks memory fastest
+  const int inner = kfast ? jb.K : jb.N;
+  const int64_t si = kfast ? jb.sn : jb.sk;                   // stride of the slow index
+  const int64_t total = (int64_t)jb.N * jb.K;
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)kAmaxParts * 256) {
+    const int64_t o = i / inner;
+    m = fmaxf(m, finite_abs(jb.W[o * si + (i - o * inner) * (kfast ? jb.sk : jb.sn)]));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    reinterpret_cast<float *>(jb.img + image_amax_offset(jb.N, jb.K))[blockIdx.x] =
+        fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+__device__ __forceinline__ float folded_amax(const char *trailer) {
+  const float4 *p = reinterpret_cast<const float4 *>(trailer);
+  float m = 0.f;
+#pragma unroll
+  for (int i = 0; i < kAmaxParts / 4; ++i) {
+    const float4 v = p[i];
+    m = fmaxf(fmaxf(m, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+  }
+  return m;
+}
 __global__ void weight_image_kernel(ImageJobs jobs) {
   const ImageJob jb = jobs.j[blockIdx.y];
   // the image covers the PADDED shape (columns to a multiple of 128, depth to a multiple of 32): zeros beyond N and K
@@ -106,20 +187,28 @@ __global__ void weight_image_kernel(ImageJobs jobs) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= Np * k8s) return;
   const int n = idx / k8s, k8 = idx - n * k8s;
+  const float wmax = folded_amax(jb.img + image_amax_offset(jb.N, jb.K));
+  if (idx == 0) reinterpret_cast<float *>(jb.img + image_amax_offset(jb.N, jb.K))[kAmaxParts] = wmax;
+  const float sw = plane_scale(wmax);
   float x[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j)
     x[j] = (n < jb.N && 8 * k8 + j < jb.K) ? jb.W[(int64_t)n * jb.sn + (int64_t)(8 * k8 + j) * jb.sk] : 0.f;
-  i32x4 pl[3];
+  i32x4 pl[3], ph[2];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const Pair3 q = split_pair(x[2 * t], x[2 * t + 1]);
     pl[0][t] = q.h1; pl[1][t] = q.h2; pl[2][t] = q.h3;
+    const Pair3 qh = split_pair_h(x[2 * t], x[2 * t + 1], sw);
+    ph[0][t] = qh.h1; ph[1][t] = qh.h2;
   }
   const int ks = k8 >> 1, h = k8 & 1, n32 = n >> 5, r = n & 31;
   char *dst = jb.img + ((size_t)(ks * (Np / 32) + n32) * 3) * kFrag + (32 * h + r) * 16;
 #pragma unroll
   for (int p = 0; p < 3; ++p) *reinterpret_cast<i32x4 *>(dst + p * kFrag) = pl[p];
+  dst = jb.img + image_half_offset(jb.N, jb.K) + ((size_t)(ks * (Np / 32) + n32) * 2) * kFrag + (32 * h + r) * 16;
+#pragma unroll
+  for (int p = 0; p < 2; ++p) *reinterpret_cast<i32x4 *>(dst + p * kFrag) = ph[p];
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -149,12 +238,16 @@ struct RowsArgs {
   int row_tiles;              // ceil(M / BM)
   int64_t tiles;              // tile slots: row tiles rounded up to 8, times column tiles
   int Kp, Np;                 // K, N padded to multiples of 32 / 128 (= the weight image's shape)
+  // scaled mode (HP): largest finite magnitudes of A and of the weight (device floats); the output's may be recorded
+  const float *amax_a, *amax_w;
+  float *out_amax;            // or null: atomic max over this launch's outputs (the caller zeroes it), scaled mode only
 };
 
 // RAGGED: K % 32 != 0 or N % BN != 0 (e.g. the reference's default embed_dim = 100): row loads beyond K read as zero,
 // columns beyond N are computed on the image's zero padding and not stored
-template <int BM, int BN, int WM, int WN, bool RAGGED>
+template <int BM, int BN, int WM, int WN, bool RAGGED, bool HP>
 __global__ __launch_bounds__(64 * WM * WN, 2) void proj_rows_kernel(RowsArgs a) {
+  constexpr int kNP = Pl<HP>::NP, kTile3 = Pl<HP>::kTile;
   constexpr int NW = WM * WN, NTHR = 64 * NW;
   constexpr int MTB = BM / 32, NTB = BN / 32;          // 32-row / 32-column tiles per workgroup
   constexpr int MTW = MTB / WM, NTW = NTB / WN;        // ... per wave
@@ -187,6 +280,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void proj_rows_kernel(RowsArgs a) 
   const int brd = (NTW * wn) * kTile3 + lane * 16;
   const size_t wstep = (size_t)(a.Np / 32) * kTile3;           // bytes of one k step of the whole image
   const unsigned lds0 = (unsigned)(uintptr_t)(lds_char *)smem;
+  // scaled mode: operand scale, and what undoes it and the weight's in the epilogue (two exact factors: their product
+  // could leave the fp32 range)
+  const float sa = HP ? plane_scale(*a.amax_a) : 1.f;
+  const float ua = HP ? 1.f / sa : 1.f, uw = HP ? plane_unscale(*a.amax_w) : 1.f;
+  float omax = 0.f;                     // largest finite |output| this thread has stored
 
   // tile slot u -> (row tile, column tile).  Workgroups b, b + 8, ... share an XCD (round-robin dispatch, speed
   // only): consecutive slots of one XCD are the column tiles of ONE row tile, whose rows then come from its L2
@@ -253,11 +351,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void proj_rows_kernel(RowsArgs a) 
 #pragma unroll
     for (int i = 0; i < NLH; ++i) {
       const float4 v = x[decltype(half)::value][i];
-      const Pair3 p0 = split_pair(v.x, v.y), p1 = split_pair(v.z, v.w);
+      const Pair3 p0 = split_pair_t<HP>(v.x, v.y, sa), p1 = split_pair_t<HP>(v.z, v.w, sa);
       char *d = base + i * kWStep;
       *reinterpret_cast<i32x2 *>(d) = i32x2{p0.h1, p1.h1};
       *reinterpret_cast<i32x2 *>(d + kFrag) = i32x2{p0.h2, p1.h2};
-      *reinterpret_cast<i32x2 *>(d + 2 * kFrag) = i32x2{p0.h3, p1.h3};
+      if (kNP == 3) *reinterpret_cast<i32x2 *>(d + 2 * kFrag) = i32x2{p0.h3, p1.h3};
     }
   };
   f32x16 acc[MTW][NTW];
@@ -267,7 +365,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void proj_rows_kernel(RowsArgs a) 
 #pragma unroll
     for (int j = 0; j < NTW; ++j)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) bf[j][p] = *reinterpret_cast<const i32x4 *>(bb + brd + j * kTile3 + p * kFrag);
+      for (int p = 0; p < kNP; ++p) bf[j][p] = *reinterpret_cast<const i32x4 *>(bb + brd + j * kTile3 + p * kFrag);
     // accumulator rows in groups of G so that consecutive MFMAs are at least four accumulators apart (mfma6_row)
     constexpr int G = NTW >= 4 ? 1 : (4 / NTW < MTW ? 4 / NTW : MTW);
     static_assert(MTW % G == 0, "accumulator rows are taken in groups");
@@ -277,17 +375,17 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void proj_rows_kernel(RowsArgs a) 
 #pragma unroll
       for (int ii = 0; ii < G; ++ii)
 #pragma unroll
-        for (int p = 0; p < 3; ++p) af[ii][p] = *reinterpret_cast<const i32x4 *>(bb + ard + (i + ii) * kTile3 + p * kFrag);
+        for (int p = 0; p < kNP; ++p) af[ii][p] = *reinterpret_cast<const i32x4 *>(bb + ard + (i + ii) * kTile3 + p * kFrag);
       if constexpr (G == 1) {
-        mfma6_row<NTW>(af[0], bf, acc[i]);
+        mfma_row<HP, NTW>(af[0], bf, acc[i]);
       } else {
-        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
-        for (int q = 0; q < 6; ++q)
+        for (int q = 0; q < Pl<HP>::NQ; ++q)
 #pragma unroll
           for (int ii = 0; ii < G; ++ii)
 #pragma unroll
-            for (int j = 0; j < NTW; ++j) acc[i + ii][j] = MFMA32(af[ii][PA[q]], bf[j][PB[q]], acc[i + ii][j]);
+            for (int j = 0; j < NTW; ++j)
+              acc[i + ii][j] = mfma_p<HP>(af[ii][kPA[HP][q]], bf[j][kPB[HP][q]], acc[i + ii][j]);
       }
     }
   };
@@ -384,13 +482,17 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void proj_rows_kernel(RowsArgs a) 
             const int colt = cur.col0 + (NTW * wn + j) * 32;
 #pragma unroll
             for (int e = 0; e < 16; ++e)
-              stage[((e & 3) + 8 * (e >> 2) + 4 * fh) * 32 + fr] = (acc[i][j][e] + bj[j]) * fl[e];
+              stage[((e & 3) + 8 * (e >> 2) + 4 * fh) * 32 + fr] =
+                  ((HP ? acc[i][j][e] * ua * uw : acc[i][j][e]) + bj[j]) * fl[e];
             float *o = a.out + (cur.row0 + rl0 + sr) * a.ldc + colt + 4 * sc4;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
               const float4 v = *reinterpret_cast<const float4 *>(stage + (sr + 8 * g) * 32 + 4 * sc4);
-              if ((!decltype(ragged)::value || cur.row0 + rl0 + sr + 8 * g < a.M) && (!RAGGED || colt + 4 * sc4 < a.N))
+              if ((!decltype(ragged)::value || cur.row0 + rl0 + sr + 8 * g < a.M) && (!RAGGED || colt + 4 * sc4 < a.N)) {
                 *reinterpret_cast<float4 *>(o + (int64_t)(8 * g) * a.ldc) = v;
+                if (HP && a.out_amax)
+                  omax = fmaxf(fmaxf(omax, fmaxf(finite_abs(v.x), finite_abs(v.y))), fmaxf(finite_abs(v.z), finite_abs(v.w)));
+              }
             }
           }
         }
@@ -406,6 +508,11 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void proj_rows_kernel(RowsArgs a) 
     u += gridDim.x;
     nxt = tile_of(u + gridDim.x);
     par ^= 1;
+  }
+  if (HP && a.out_amax) {                 // one atomic per wave and launch; non-negative floats order as their bits
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) omax = fmaxf(omax, __shfl_xor(omax, o));
+    if (lane == 0) atomicMax(reinterpret_cast<unsigned *>(a.out_amax), __builtin_bit_cast(unsigned, omax));
   }
   PSTAMP_FLUSH(blockIdx.x);
 }
@@ -432,17 +539,19 @@ struct WgradArgs {
   int S;
   int64_t rows_per_slice;     // multiple of 16
   int Nap, Nbp;               // Na, Nb padded to multiples of 128: the shape the tiles and the partial slabs cover
+  const float *amax_a, *amax_b;   // scaled mode (HP): largest finite magnitudes of A and B (device floats)
 };
 
 constexpr int kRS = 16;       // rows per stage
 
 // RAGGED: Na or Nb not a multiple of the tile (the reference's default embed_dim = 100): columns beyond them load as 0
-template <int TI, int TJ, int WI, int WJ, bool MASK, bool RAGGED>
+template <int TI, int TJ, int WI, int WJ, bool MASK, bool RAGGED, bool HP>
 __global__ __launch_bounds__(64 * WI * WJ, 2) void proj_wgrad_kernel(WgradArgs a) {
+  constexpr int kNP = Pl<HP>::NP;
   constexpr int NW = WI * WJ, NTHR = 64 * NW;
   constexpr int kRowA = TI * 2, kRowB = TJ * 2;             // bytes per image row
   constexpr int kPlaneA = kRS * kRowA, kPlaneB = kRS * kRowB;
-  constexpr int kStage = 3 * (kPlaneA + kPlaneB);
+  constexpr int kStage = kNP * (kPlaneA + kPlaneB);
   constexpr int NIW = TI / 32 / WI, NJW = TJ / 32 / WJ;     // 32-column tiles of A / B per wave
   constexpr int kColsA4 = TI / 4, kColsB4 = TJ / 4;         // float4 per tile row
   constexpr int kRowsA = NTHR / kColsA4, kRowsB = NTHR / kColsB4;   // rows covered by one load of the workgroup
@@ -477,13 +586,13 @@ __global__ __launch_bounds__(64 * WI * WJ, 2) void proj_wgrad_kernel(WgradArgs a
 #pragma unroll
   for (int i = 0; i < NLB; ++i) {
     const int r = rb + kRowsB * i;
-    wb[i] = 3 * kPlaneA + r * kRowB + ((8 * cb) ^ ((r & 3) << 6));
+    wb[i] = kNP * kPlaneA + r * kRowB + ((8 * cb) ^ ((r & 3) << 6));
   }
   // transposed reads: lane = (h = lane >> 5, gi = (lane >> 4) & 1, q = (lane >> 2) & 3, p = lane & 3) addresses
   // row 8 h + 4 u + q, columns 32 tile + 16 gi + 4 p .. + 3 (u = 0, 1: the two halves of the 8-deep k group)
   const int fh = lane >> 5, gi = (lane >> 4) & 1, q = (lane >> 2) & 3, pp = lane & 3, fr = lane & 31;
   const int rdA = (8 * fh + q) * kRowA + (q << 6) + 32 * gi + 8 * pp;       // ^ (tile & 3) << 6, + (tile >> 2) << 8
-  const int rdB = 3 * kPlaneA + (8 * fh + q) * kRowB + (q << 6) + 32 * gi + 8 * pp;
+  const int rdB = kNP * kPlaneA + (8 * fh + q) * kRowB + (q << 6) + 32 * gi + 8 * pp;
 
   f32x16 acc[NIW][NJW];
 #pragma unroll
@@ -493,6 +602,8 @@ __global__ __launch_bounds__(64 * WI * WJ, 2) void proj_wgrad_kernel(WgradArgs a
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
   float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
+  // scaled mode: the partial tiles are in scaled units (wgrad_reduce_kernel undoes both scales); the column sums are not
+  const float sa = HP ? plane_scale(*a.amax_a) : 1.f, sb = HP ? plane_scale(*a.amax_b) : 1.f;
 
   float4 xa[NLA], xb[NLB];
   auto load_stage = [&](int s) {
@@ -525,19 +636,19 @@ __global__ __launch_bounds__(64 * WI * WJ, 2) void proj_wgrad_kernel(WgradArgs a
 #pragma unroll
     for (int i = 0; i < NLA; ++i) {
       cs.x += xa[i].x; cs.y += xa[i].y; cs.z += xa[i].z; cs.w += xa[i].w;
-      const Pair3 p0 = split_pair(xa[i].x, xa[i].y), p1 = split_pair(xa[i].z, xa[i].w);
+      const Pair3 p0 = split_pair_t<HP>(xa[i].x, xa[i].y, sa), p1 = split_pair_t<HP>(xa[i].z, xa[i].w, sa);
       char *d = buf + wa[i];
       *reinterpret_cast<i32x2 *>(d) = i32x2{p0.h1, p1.h1};
       *reinterpret_cast<i32x2 *>(d + kPlaneA) = i32x2{p0.h2, p1.h2};
-      *reinterpret_cast<i32x2 *>(d + 2 * kPlaneA) = i32x2{p0.h3, p1.h3};
+      if (kNP == 3) *reinterpret_cast<i32x2 *>(d + 2 * kPlaneA) = i32x2{p0.h3, p1.h3};
     }
 #pragma unroll
     for (int i = 0; i < NLB; ++i) {
-      const Pair3 p0 = split_pair(xb[i].x, xb[i].y), p1 = split_pair(xb[i].z, xb[i].w);
+      const Pair3 p0 = split_pair_t<HP>(xb[i].x, xb[i].y, sb), p1 = split_pair_t<HP>(xb[i].z, xb[i].w, sb);
       char *d = buf + wb[i];
       *reinterpret_cast<i32x2 *>(d) = i32x2{p0.h1, p1.h1};
       *reinterpret_cast<i32x2 *>(d + kPlaneB) = i32x2{p0.h2, p1.h2};
-      *reinterpret_cast<i32x2 *>(d + 2 * kPlaneB) = i32x2{p0.h3, p1.h3};
+      if (kNP == 3) *reinterpret_cast<i32x2 *>(d + 2 * kPlaneB) = i32x2{p0.h3, p1.h3};
     }
     if (s + 1 < ns) load_stage(s + 1);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -547,7 +658,7 @@ __global__ __launch_bounds__(64 * WI * WJ, 2) void proj_wgrad_kernel(WgradArgs a
       const int jt = NJW * wj + j;
       const char *r0 = buf + ((rdB + ((jt >> 2) << 8)) ^ ((jt & 3) << 6));
 #pragma unroll
-      for (int p = 0; p < 3; ++p) bf[j][p] = tr_frag(r0 + p * kPlaneB, r0 + p * kPlaneB + 4 * kRowB);
+      for (int p = 0; p < kNP; ++p) bf[j][p] = tr_frag(r0 + p * kPlaneB, r0 + p * kPlaneB + 4 * kRowB);
     }
     // two accumulator rows per round (their A fragments live together): consecutive MFMAs are 2 NJW accumulators apart
     static_assert(NIW % 2 == 0, "accumulator rows are taken in pairs");
@@ -559,15 +670,15 @@ __global__ __launch_bounds__(64 * WI * WJ, 2) void proj_wgrad_kernel(WgradArgs a
         const int it = NIW * wi + i + ii;
         const char *r0 = buf + ((rdA + ((it >> 2) << 8)) ^ ((it & 3) << 6));
 #pragma unroll
-        for (int p = 0; p < 3; ++p) af[ii][p] = tr_frag(r0 + p * kPlaneA, r0 + p * kPlaneA + 4 * kRowA);
+        for (int p = 0; p < kNP; ++p) af[ii][p] = tr_frag(r0 + p * kPlaneA, r0 + p * kPlaneA + 4 * kRowA);
       }
-      constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
 #pragma unroll
-      for (int q = 0; q < 6; ++q)
+      for (int q = 0; q < Pl<HP>::NQ; ++q)
 #pragma unroll
         for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-          for (int j = 0; j < NJW; ++j) acc[i + ii][j] = MFMA32(af[ii][PA[q]], bf[j][PB[q]], acc[i + ii][j]);
+          for (int j = 0; j < NJW; ++j)
+            acc[i + ii][j] = mfma_p<HP>(af[ii][kPA[HP][q]], bf[j][kPB[HP][q]], acc[i + ii][j]);
     }
   }
 
@@ -602,8 +713,11 @@ __global__ __launch_bounds__(64 * WI * WJ, 2) void proj_wgrad_kernel(WgradArgs a
 // out[e] = sum over the slices of part[s][e]; e < n_dw goes to dW, the rest to colsum.  256 threads = 32 float4
 // elements x 8 slice phases: phase g adds slices g, g + 8, ... in order (four loads in flight), the eight phase sums
 // meet in LDS and are added in a fixed order -- bitwise reproducible, and S / 8 dependent load rounds instead of S
+// (scaled mode: amax_a / amax_b non-null, the dW part leaves through the two exact inverse scales)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restrict__ part, int S, int Na, int Nb, int Nap,
-                                                           int Nbp, float *__restrict__ dW, float *__restrict__ colsum) {
+                                                           int Nbp, float *__restrict__ dW, float *__restrict__ colsum,
+                                                           const float *__restrict__ amax_a,
+                                                           const float *__restrict__ amax_b) {
   __shared__ float4 red[8][32];
   const int el = threadIdx.x & 31, g = threadIdx.x >> 5;
   const int64_t n_dw = (int64_t)Nap * Nbp, n_all = n_dw + Nap;        // the slabs cover the padded shape
@@ -634,6 +748,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float *__restri
     }
     if (e < n_dw) {
       const int i = (int)(e / Nbp), j = (int)(e - (int64_t)i * Nbp);
+      if (amax_a) {
+        const float ua = plane_unscale(*amax_a), ub = plane_unscale(*amax_b);
+        acc.x = acc.x * ua * ub; acc.y = acc.y * ua * ub; acc.z = acc.z * ua * ub; acc.w = acc.w * ua * ub;
+      }
       if (i < Na && j < Nb) *reinterpret_cast<float4 *>(dW + (size_t)i * Nb + j) = acc;
     } else if (colsum && e - n_dw < Na) {
       *reinterpret_cast<float4 *>(colsum + (e - n_dw)) = acc;
@@ -674,7 +792,7 @@ inline WgradPlan wgrad_plan(int64_t M, int Nap, int Nbp) {       // padded shape
 extern "C" size_t ampconv_proj_weight_image_bytes(int N, int K, int dtype) {
   if (dtype == AMPCONV_BF16) return ampconv_proj_weight_image_bytes_bf16(N, K);
   if (dtype != AMPCONV_F32 || N <= 0 || K <= 0) return 0;
-  return (size_t)((N + 127) / 128 * 128) * (size_t)((K + 31) / 32 * 32) * 6;      // padded shape, three bf16 planes
+  return image_amax_offset(N, K) + 512;      // padded shape: three bf16 planes, two fp16 planes, the weight's maximum
 }
 
 static bool supported_f32(int N, int K) { return N > 0 && K > 0 && N % 4 == 0 && K % 4 == 0; }
@@ -701,6 +819,7 @@ extern "C" int ampconv_proj_weight_images(int count, const ampconv_weight_image_
     const int total = ((w.N + 127) / 128 * 128) * (((w.K + 31) / 32 * 32) / 8);
     most = total > most ? total : most;
   }
+  weight_absmax_kernel<<<dim3(kAmaxParts, count), 256, 0, (hipStream_t)stream>>>(js);
   weight_image_kernel<<<dim3((most + 255) / 256, count), 256, 0, (hipStream_t)stream>>>(js);
   return ampconv_launch_status();
 }
@@ -713,11 +832,15 @@ extern "C" int ampconv_proj_weight_image(const void *W, int64_t stride_n, int64_
 
 extern "C" int ampconv_proj_rows(const void *A_, int64_t lda, int64_t M, int K, const void *wimage, int N,
                                  const void *bias_, const int32_t *rowptr, int L, void *out_, int64_t ldc,
-                                 const int32_t *nodes, int64_t n_nodes, int dtype, void *stream) {
-  if (dtype == AMPCONV_BF16)
+                                 const int32_t *nodes, int64_t n_nodes, const float *a_absmax, float *out_absmax,
+                                 int dtype, void *stream) {
+  if (dtype == AMPCONV_BF16) {
+    if (a_absmax || out_absmax) return AMPCONV_E_DTYPE;           // scaled mode: fp32 storage only
     return ampconv_proj_rows_bf16(A_, lda, M, K, wimage, N, bias_, rowptr, L, out_, ldc, nodes, n_nodes,
                                   (hipStream_t)stream);
+  }
   if (dtype != AMPCONV_F32 || nodes) return AMPCONV_E_DTYPE;      // node lists: bf16 storage only
+  if (out_absmax && !a_absmax) return AMPCONV_E_BADARG;           // recorded by the scaled kernels only
   const float *A = (const float *)A_, *bias = (const float *)bias_;
   float *out = (float *)out_;
   if (M < 0 || !supported_f32(N, K) || lda < K || ldc < N || lda % 4) return AMPCONV_E_BADARG;
@@ -737,7 +860,10 @@ extern "C" int ampconv_proj_rows(const void *A_, int64_t lda, int64_t M, int K, 
   const int64_t rts = (M + bm - 1) / bm;
   if (rts > (int64_t)INT32_MAX / 64) return AMPCONV_E_BADARG;
   const int64_t rtp = (rts + 7) / 8 * 8;
-  RowsArgs a{A, lda, M, K, N, (const char *)wimage, bias, rowptr, L, out, ldc, (int)rts, rtp * (Np / bn), Kp, Np};
+  const bool hp = a_absmax != nullptr;                 // scaled two-plane mode: the image's fp16 half and its maximum
+  const char *img = (const char *)wimage;
+  RowsArgs a{A, lda, M, K, N, hp ? img + image_half_offset(N, K) : img, bias, rowptr, L, out, ldc, (int)rts,
+             rtp * (Np / bn), Kp, Np, a_absmax, (const float *)(img + image_amax_offset(N, K)) + kAmaxParts, out_absmax};
   const int n_cu = cu_count();
   // a multiple of 8: slot u of a workgroup keeps u % 8 (its XCD label), so "my next slot is invalid" means "nothing
   // further for me" only then (a.tiles is a multiple of 8 by construction)
@@ -746,12 +872,77 @@ extern "C" int ampconv_proj_rows(const void *A_, int64_t lda, int64_t M, int K, 
   if (grid > a.tiles) grid = a.tiles;
   hipStream_t st = (hipStream_t)stream;
   const unsigned g = (unsigned)grid;
-  if (shape == 0 && !ragged) proj_rows_kernel<128, 256, 2, 2, false><<<g, 256, 0, st>>>(a);
-  else if (shape == 0) proj_rows_kernel<128, 256, 2, 2, true><<<g, 256, 0, st>>>(a);
-  else if (shape == 1 && !ragged) proj_rows_kernel<256, 256, 2, 4, false><<<g, 512, 0, st>>>(a);
-  else if (shape == 1) proj_rows_kernel<256, 256, 2, 4, true><<<g, 512, 0, st>>>(a);
-  else if (!ragged) proj_rows_kernel<128, 128, 2, 2, false><<<g, 256, 0, st>>>(a);
-  else proj_rows_kernel<128, 128, 2, 2, true><<<g, 256, 0, st>>>(a);
+#define ROWS_LAUNCH(BM_, BN_, WM_, WN_, NT_)                                                          \
+  do {                                                                                                \
+    if (hp && ragged) proj_rows_kernel<BM_, BN_, WM_, WN_, true, true><<<g, NT_, 0, st>>>(a);          \
+    else if (hp) proj_rows_kernel<BM_, BN_, WM_, WN_, false, true><<<g, NT_, 0, st>>>(a);              \
+    else if (ragged) proj_rows_kernel<BM_, BN_, WM_, WN_, true, false><<<g, NT_, 0, st>>>(a);          \
+    else proj_rows_kernel<BM_, BN_, WM_, WN_, false, false><<<g, NT_, 0, st>>>(a);                     \
+  } while (0)
+  if (shape == 0) ROWS_LAUNCH(128, 256, 2, 2, 256);
+  else if (shape == 1) ROWS_LAUNCH(256, 256, 2, 4, 512);
+  else ROWS_LAUNCH(128, 128, 2, 2, 256);
+#undef ROWS_LAUNCH
+  return ampconv_launch_status();
+}
+
+// largest finite magnitude of X[M, K] (row stride ld), merged into *out by an atomic max: zero it first (reset != 0
+// does) or let several calls accumulate.  NaN and infinities are skipped: they propagate through the products by
+// themselves, in the rows they sit in.
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void absmax_kernel(const T *__restrict__ X, int64_t ld, int64_t M, int K4,
+                                                     float *__restrict__ out) {
+  // K4 = 16-byte pieces per row; a workgroup walks pieces blockIdx.x * 256 + t, + gridDim.x * 256, ...
+  constexpr int EPP = 16 / sizeof(T);
+  const int64_t total = M * K4;
+  float m = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t row = i / K4;
+    const int c = (int)(i - row * K4);
+    const uint4 raw = *reinterpret_cast<const uint4 *>(X + row * ld + (int64_t)c * EPP);
+    if constexpr (sizeof(T) == 4) {
+      m = fmaxf(m, fmaxf(fmaxf(finite_abs(__builtin_bit_cast(float, raw.x)), finite_abs(__builtin_bit_cast(float, raw.y))),
+                         fmaxf(finite_abs(__builtin_bit_cast(float, raw.z)), finite_abs(__builtin_bit_cast(float, raw.w)))));
+    } else {
+      const unsigned u[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        m = fmaxf(m, fmaxf(finite_abs(lo_as_f32(u[k])), finite_abs(hi_as_f32(u[k]))));
+    }
+  }
+  __shared__ float red[4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    atomicMax(reinterpret_cast<unsigned *>(out), __builtin_bit_cast(unsigned, m));
+  }
+}
+}  // namespace
+
+extern "C" int ampconv_absmax(const void *X, int64_t ld, int64_t M, int K, int dtype, float *out, int reset,
+                              void *stream) {
+  if (dtype != AMPCONV_F32 && dtype != AMPCONV_BF16) return AMPCONV_E_DTYPE;
+  const int epp = dtype == AMPCONV_F32 ? 4 : 8;
+  if (!out || M < 0 || K < 0 || K % epp || ld < K || ld % epp) return AMPCONV_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (reset) {
+    const hipError_t e = hipMemsetAsync(out, 0, sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+  }
+  if (M == 0 || K == 0) return AMPCONV_OK;
+  if (!X || (uintptr_t)X % 16) return AMPCONV_E_BADARG;
+  const int64_t pieces = M * (K / epp);
+  int64_t grid = (pieces + 255) / 256;
+  const int64_t cap = (int64_t)cu_count() * 16;         // eight loads per thread and more: the atomics stay few
+  if (grid > cap) grid = cap;
+  if (dtype == AMPCONV_F32)
+    absmax_kernel<float><<<(unsigned)grid, 256, 0, st>>>((const float *)X, ld, M, K / epp, out);
+  else
+    absmax_kernel<unsigned short><<<(unsigned)grid, 256, 0, st>>>((const unsigned short *)X, ld, M, K / epp, out);
   return ampconv_launch_status();
 }
 
@@ -766,10 +957,13 @@ extern "C" size_t ampconv_proj_wgrad_workspace_bytes(int64_t M, int Na, int Nb, 
 extern "C" int ampconv_proj_wgrad(const void *A_, int64_t lda, const void *B_, int64_t ldb, int64_t M, int Na,
                                   int Nb, const int32_t *rowptr, int L, void *dW_, void *colsum_,
                                   void *workspace, size_t workspace_bytes, const int32_t *nodes, int64_t n_nodes,
-                                  int dtype, void *stream) {
-  if (dtype == AMPCONV_BF16)
+                                  const float *a_absmax, const float *b_absmax, int dtype, void *stream) {
+  if (dtype == AMPCONV_BF16) {
+    if (a_absmax || b_absmax) return AMPCONV_E_DTYPE;             // scaled mode: fp32 storage only
     return ampconv_proj_wgrad_bf16(A_, lda, B_, ldb, M, Na, Nb, rowptr, L, dW_, colsum_, workspace, workspace_bytes,
                                    nodes, n_nodes, (hipStream_t)stream);
+  }
+  if ((a_absmax != nullptr) != (b_absmax != nullptr)) return AMPCONV_E_BADARG;      // both operands or neither
   if (dtype != AMPCONV_F32 || nodes) return AMPCONV_E_DTYPE;      // node lists: bf16 storage only
   const float *A = (const float *)A_, *B = (const float *)B_;
   float *dW = (float *)dW_, *colsum = (float *)colsum_;
@@ -790,21 +984,28 @@ extern "C" int ampconv_proj_wgrad(const void *A_, int64_t lda, const void *B_, i
   const WgradPlan p = wgrad_plan(M, Nap, Nbp);
   const size_t n_all = (size_t)Nap * Nbp + Nap;
   if (workspace_bytes < (size_t)p.S * n_all * sizeof(float)) return AMPCONV_E_WORKSPACE;
-  WgradArgs a{A, lda, B, ldb, M, Na, Nb, rowptr, L, (float *)workspace, p.S, p.rows_per_slice, Nap, Nbp};
+  WgradArgs a{A, lda, B, ldb, M, Na, Nb, rowptr, L, (float *)workspace, p.S, p.rows_per_slice, Nap, Nbp, a_absmax,
+              b_absmax};
+  const bool hp = a_absmax != nullptr;
   const int ntiles = (Nap / p.ti) * (Nbp / p.tj);
   const unsigned grid = (unsigned)(((p.S + 7) / 8 * 8) * ntiles);
 #define WGRAD_LAUNCH(TI_, TJ_, WI_, WJ_, NT_)                                                              \
   do {                                                                                                     \
-    if (rowptr && ragged) proj_wgrad_kernel<TI_, TJ_, WI_, WJ_, true, true><<<grid, NT_, 0, st>>>(a);       \
-    else if (rowptr) proj_wgrad_kernel<TI_, TJ_, WI_, WJ_, true, false><<<grid, NT_, 0, st>>>(a);           \
-    else if (ragged) proj_wgrad_kernel<TI_, TJ_, WI_, WJ_, false, true><<<grid, NT_, 0, st>>>(a);           \
-    else proj_wgrad_kernel<TI_, TJ_, WI_, WJ_, false, false><<<grid, NT_, 0, st>>>(a);                      \
+    if (hp) {                                                                                              \
+      if (rowptr && ragged) proj_wgrad_kernel<TI_, TJ_, WI_, WJ_, true, true, true><<<grid, NT_, 0, st>>>(a);      \
+      else if (rowptr) proj_wgrad_kernel<TI_, TJ_, WI_, WJ_, true, false, true><<<grid, NT_, 0, st>>>(a);          \
+      else if (ragged) proj_wgrad_kernel<TI_, TJ_, WI_, WJ_, false, true, true><<<grid, NT_, 0, st>>>(a);          \
+      else proj_wgrad_kernel<TI_, TJ_, WI_, WJ_, false, false, true><<<grid, NT_, 0, st>>>(a);                     \
+    } else if (rowptr && ragged) proj_wgrad_kernel<TI_, TJ_, WI_, WJ_, true, true, false><<<grid, NT_, 0, st>>>(a); \
+    else if (rowptr) proj_wgrad_kernel<TI_, TJ_, WI_, WJ_, true, false, false><<<grid, NT_, 0, st>>>(a);           \
+    else if (ragged) proj_wgrad_kernel<TI_, TJ_, WI_, WJ_, false, true, false><<<grid, NT_, 0, st>>>(a);           \
+    else proj_wgrad_kernel<TI_, TJ_, WI_, WJ_, false, false, false><<<grid, NT_, 0, st>>>(a);                      \
   } while (0)
   if (p.ti == 256) WGRAD_LAUNCH(256, 256, 2, 4, 512);
   else if (p.tj == 256) WGRAD_LAUNCH(128, 256, 2, 2, 256);
   else WGRAD_LAUNCH(128, 128, 2, 2, 256);
 #undef WGRAD_LAUNCH
   wgrad_reduce_kernel<<<(unsigned)((n_all / 4 + 31) / 32), 256, 0, st>>>((const float *)workspace, p.S, Na, Nb, Nap, Nbp,
-                                                                         dW, colsum);
+                                                                         dW, colsum, a_absmax, b_absmax);
   return ampconv_launch_status();
 }

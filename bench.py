@@ -600,15 +600,17 @@ def measure_full(workload, steps, warmup, args, rank, world, dev, dist_on, dt_na
 
 def _node_phase_mfma(flops_proj, t_node, dt_name, gemm):
     """The node phase against ITS roofline (SURVEY.md 8d: the matrix pipe).  24 L D^2 per node of fp32-equivalent FLOPs;
-    the native fp32 projections issue six bf16 MFMA products per fp32 product, the bf16-storage ones one.  None for the
+    the native fp32 projections issue three fp16 MFMA products per fp32 product (scaled two-plane mode; six bf16 ones
+    with AMPCONV_PROJ_SCALED=0), the bf16-storage ones one.  None for the
     library fp32 GEMMs (they run on the fp32 pipe: `layer_flops`)."""
     if t_node <= 0 or not (dt_name == 'bf16' or gemm == 'native'):
         return None
-    issue = 6 if dt_name == 'f32' else 1
+    from ampnet_amd.conv import functional as F_
+    issue = (3 if F_.PROJ_SCALED else 6) if dt_name == 'f32' else 1      # (every bench workload that reports this is large)
     peak = MFMA_PEAK_TFLOPS['bf16']
-    return {'bound': 'mfma', 'flops_fp32_equivalent': flops_proj, 'bf16_products_per_fp32_product': issue,
+    return {'bound': 'mfma', 'flops_fp32_equivalent': flops_proj, 'matrix_products_per_fp32_product': issue,
             'achieved_TFLOPs_fp32_equivalent': flops_proj / t_node / 1e12,
-            'achieved_TFLOPs_bf16_issued': issue * flops_proj / t_node / 1e12, 'peak_TFLOPs': peak,
+            'achieved_TFLOPs_16bit_issued': issue * flops_proj / t_node / 1e12, 'peak_TFLOPs': peak,
             'frac': issue * flops_proj / t_node / 1e12 / peak,
             'note': 'lower bound of the rate: node_phase_ms also holds the CSR build and glue; DESIGN.md 4a: power-limited'}
 

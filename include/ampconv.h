@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define AMPCONV_VERSION 103
+#define AMPCONV_VERSION 104
 
 enum {
   AMPCONV_OK = 0,
@@ -258,6 +258,15 @@ int ampconv_masked_colsum(const void *dY, const int32_t *rowptr, int64_t N,
  *   a node without in-edges needs no Q row and no output row (it is 0), one without out-edges no K / V rows -- on the
  *   R-MAT graph of BASELINE config 5 that is 48 % of the nodes on either side.  proj_rows with a list takes no mask
  *   (rowptr must be NULL: list the nodes that pass it); proj_wgrad sums over the listed rows only.
+ *   SCALED MODE (AMPCONV_F32 only; `a_absmax` (+ `b_absmax` for proj_wgrad) != NULL: device floats holding the largest
+ *   finite magnitude of the operand, or any upper bound of it within a few binades): the operands are scaled by a power
+ *   of two into fp16's range and split into TWO fp16 planes, a product is three fp16 matrix products instead of six bf16
+ *   ones -- as close to the fp64 result as the six-product form on operands whose elements lie within 2^17 of the
+ *   maximum, absolute error <= 2^-39 of the maximum per element below that (csrc/proj_gemm.hip); the
+ *   weight's scale is part of its image.  NULL: the six-product form, exact split at any range.  ampconv_absmax
+ *   computes such a maximum (one pass over X[M, K], row stride ld; merged into *out by atomic max, `reset` zeroes it
+ *   first; NaN and infinities are skipped); proj_rows in this mode records the maximum of what it WRITES into `out_absmax` (may be
+ *   NULL; atomic max, the caller zeroes it) -- the next product's operand then needs no pass of its own.
  * Developer switches read from the environment at the first call (A/B measurements; the defaults are the
  * shipped configuration, nothing else keeps state): AMPCONV_PROJ_ROWS=1 (256 x 256 row tiles),
  * AMPCONV_PROJ_WGRAD_TI=128, AMPCONV_PROJ_WGRAD_BF16_T=128 (smaller weight-gradient tiles), and for the edge phase AMPCONV_FORCE_GENERIC=1,
@@ -277,12 +286,15 @@ typedef struct {
 int ampconv_proj_weight_images(int count, const ampconv_weight_image_t *jobs, int dtype, void *stream);
 int ampconv_proj_rows(const void *A, int64_t lda, int64_t M, int K, const void *wimage, int N,
                       const void *bias, const int32_t *rowptr, int L, void *out, int64_t ldc,
-                      const int32_t *nodes, int64_t n_nodes, int dtype, void *stream);
+                      const int32_t *nodes, int64_t n_nodes, const float *a_absmax,
+                      float *out_absmax, int dtype, void *stream);
 size_t ampconv_proj_wgrad_workspace_bytes(int64_t M, int Na, int Nb, int dtype);
 int ampconv_proj_wgrad(const void *A, int64_t lda, const void *B, int64_t ldb, int64_t M, int Na,
                        int Nb, const int32_t *rowptr, int L, void *dW, void *colsum,
                        void *workspace, size_t workspace_bytes, const int32_t *nodes, int64_t n_nodes,
-                       int dtype, void *stream);
+                       const float *a_absmax, const float *b_absmax, int dtype, void *stream);
+int ampconv_absmax(const void *X, int64_t ld, int64_t M, int K, int dtype, float *out, int reset,
+                   void *stream);
 
 /* ---- GraphSAINT random-walk sampler ("next" row: the step before the hot path) -------------
  * In-tree spec: the reference's vendored PyG sampler, visualization/visualize_graphsaint_subgraphs.py

@@ -121,15 +121,19 @@ def test_long_segment_chunk_follows_the_graph_size(monkeypatch):
     assert _lib.hub_chunk(100) == 256 and _lib.hub_chunk(40_000_000) == 256
 
 
-def test_bench_node_phase_roofline_object():
-    """`node_phase_mfma` of the bench line: six bf16 products per fp32 product for the native fp32 projections, one for
-    bf16 storage, none for the library fp32 GEMMs (they run on the fp32 pipe)."""
+def test_bench_node_phase_roofline_object(monkeypatch):
+    """`node_phase_mfma` of the bench line: three fp16 products per fp32 product for the native fp32 projections (six
+    bf16 ones with the scaled mode switched off), one for bf16 storage, none for the library fp32 GEMMs (they run on
+    the fp32 pipe)."""
     import bench
+    from ampnet_amd.conv import functional as F_
     flops = 24 * 20 * 256 * 256 * 1_000_000
-    o = bench._node_phase_mfma(flops, 0.1725, 'f32', 'native')
-    assert o['bound'] == 'mfma' and o['bf16_products_per_fp32_product'] == 6 and o['peak_TFLOPs'] == 2500.0
-    assert abs(o['achieved_TFLOPs_bf16_issued'] - 6 * flops / 0.1725 / 1e12) < 1e-6
-    assert abs(o['frac'] - o['achieved_TFLOPs_bf16_issued'] / 2500.0) < 1e-12
-    assert bench._node_phase_mfma(flops, 0.12, 'bf16', 'native')['bf16_products_per_fp32_product'] == 1
+    for scaled, n in ((True, 3), (False, 6)):
+        monkeypatch.setattr(F_, 'PROJ_SCALED', scaled)
+        o = bench._node_phase_mfma(flops, 0.1725, 'f32', 'native')
+        assert o['bound'] == 'mfma' and o['matrix_products_per_fp32_product'] == n and o['peak_TFLOPs'] == 2500.0
+        assert abs(o['achieved_TFLOPs_16bit_issued'] - n * flops / 0.1725 / 1e12) < 1e-6
+        assert abs(o['frac'] - o['achieved_TFLOPs_16bit_issued'] / 2500.0) < 1e-12
+    assert bench._node_phase_mfma(flops, 0.12, 'bf16', 'native')['matrix_products_per_fp32_product'] == 1
     assert bench._node_phase_mfma(flops, 0.24, 'f32', 'fp32') is None
     assert bench._node_phase_mfma(flops, 0.0, 'f32', 'native') is None

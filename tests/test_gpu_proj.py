@@ -136,10 +136,107 @@ def test_unsupported_shapes_are_refused_not_miscomputed():
     assert lib.ampconv_proj_supported(256, 256, BF16) == 1 and lib.ampconv_proj_supported(24, 72, BF16) == 1
     assert lib.ampconv_proj_supported(100, 100, BF16) == 0      # bf16 rows move in pieces of 8 elements: library GEMM
     assert lib.ampconv_proj_supported(256, 256, 7) == 0
-    assert lib.ampconv_proj_rows(None, 100, 10, 100, None, 100, None, None, 0, None, 100, None, 0, F32, None) == -1  # null pointers
-    assert lib.ampconv_proj_rows(None, 3, 10, 3, None, 3, None, None, 0, None, 3, None, 0, F32, None) == -1
-    assert lib.ampconv_proj_rows(None, 256, 10, 256, None, 256, None, None, 0, None, 256, None, 0, BF16, None) == -1
-    assert lib.ampconv_proj_rows(None, 256, 10, 256, None, 256, None, None, 0, None, 256, None, 0, 7, None) == -2   # dtype
+    assert lib.ampconv_proj_rows(None, 100, 10, 100, None, 100, None, None, 0, None, 100, None, 0, None, None, F32, None) == -1  # null pointers
+    assert lib.ampconv_proj_rows(None, 3, 10, 3, None, 3, None, None, 0, None, 3, None, 0, None, None, F32, None) == -1
+    assert lib.ampconv_proj_rows(None, 256, 10, 256, None, 256, None, None, 0, None, 256, None, 0, None, None, BF16, None) == -1
+    assert lib.ampconv_proj_rows(None, 256, 10, 256, None, 256, None, None, 0, None, 256, None, 0, None, None, 7, None) == -2   # dtype
+
+
+# ---- fp32 storage, scaled two-plane mode (include/ampconv.h "SCALED MODE"): same bar as the six-product kernels
+@pytest.mark.parametrize('M,K,N', [(5, 128, 128), (1000, 256, 768), (4096, 768, 256), (20 * 333, 256, 256),
+                                   (777, 384, 128), (260, 100, 300), (333, 100, 100), (37, 4, 12)])
+@pytest.mark.parametrize('magnitude', [1.0, 3e-7, 2e4])
+def test_proj_rows_scaled_matches_fp64(M, K, N, magnitude):
+    from ampnet_amd.conv import functional as F_
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(M + K + N)
+    a = torch.randn(M, K, device=dev, generator=g) * magnitude
+    W = torch.randn(N, K, device=dev, generator=g) * 0.1
+    bias = torch.randn(N, device=dev, generator=g) * magnitude
+    img = F_.proj_image(W)
+    ref = a.double() @ W.double().t() + bias.double()
+    am = F_.absmax(a)
+    assert float(am) == float(a.abs().max())
+    om = torch.zeros(1, device=dev)
+    out = F_.proj_rows(a, img, bias, amax=am, out_amax=om)
+    assert _err(out, ref) < 1e-6
+    assert float(om) == float(out.abs().max())                      # the recorded maximum of what was written
+    assert torch.equal(out, F_.proj_rows(a, img, bias, amax=am))      # bitwise reproducible
+    # an upper bound of the maximum within a few binades serves as well
+    assert _err(F_.proj_rows(a, img, bias, amax=am * 50), ref) < 1e-6
+    # six-product form on the same inputs (twice the accumulator roundings: 1.07e-6 at K = 768 on one of these seeds)
+    assert _err(F_.proj_rows(a, img, bias), ref) < 2e-6
+
+
+def test_proj_rows_scaled_wide_range_rows_and_nonfinite():
+    """Rows 2^-16 of the tensor's maximum keep fp32-level RELATIVE accuracy; NaN / infinity stay in their rows."""
+    from ampnet_amd.conv import functional as F_
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(7)
+    M, K, N = 512, 256, 256
+    a = torch.randn(M, K, device=dev, generator=g)
+    a *= torch.exp2(-torch.arange(M, device=dev) % 17).float()[:, None]       # row scales 1 ... 2^-16
+    W = torch.randn(N, K, device=dev, generator=g) * 0.1
+    img = F_.proj_image(W)
+    ref = a.double() @ W.double().t()
+    out = F_.proj_rows(a, img, amax=F_.absmax(a))
+    rel = (out.double() - ref).abs().amax(1) / ref.abs().amax(1)
+    assert float(rel.max()) < 2e-6, float(rel.max())
+    a[3, 5] = float('nan')
+    a[9, 0] = float('inf')
+    am = F_.absmax(a)
+    assert torch.isfinite(am).all()                                   # skipped by the maximum
+    out = F_.proj_rows(a, img, amax=am)
+    assert torch.isnan(out[3]).all() and not torch.isfinite(out[9]).any()
+    keep = torch.ones(M, dtype=torch.bool, device=dev)
+    keep[3] = keep[9] = False
+    assert torch.isfinite(out[keep]).all()
+    assert float(((out.double() - ref).abs().amax(1) / ref.abs().amax(1))[keep].max()) < 2e-6
+
+
+@pytest.mark.parametrize('M,Na,Nb', [(37, 128, 128), (20 * 271, 384, 128), (5000, 768, 256), (70001, 256, 256),
+                                     (999, 100, 100), (20 * 40, 300, 100)])
+@pytest.mark.parametrize('masked', [False, True])
+def test_proj_wgrad_scaled_matches_fp64(M, Na, Nb, masked):
+    from ampnet_amd.conv import functional as F_
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(M + Na)
+    a = torch.randn(M, Na, device=dev, generator=g) * 1e-4           # gradients are small
+    b = torch.randn(M, Nb, device=dev, generator=g) * 3.0
+    L = 20 if M % 20 == 0 else 1
+    rp = flag = None
+    if masked:
+        rp, has = _rowptr(M // L, (0, 5, M // L - 1), dev)
+        flag = has.to(dev).repeat_interleave(L)[:, None]
+    am = a.double() * flag.double() if masked else a.double()
+    ref_dw, ref_cs = am.t() @ b.double(), am.sum(0)
+    dw, cs = torch.empty(Na, Nb, device=dev), torch.empty(Na, device=dev)
+    amax = (F_.absmax(a), F_.absmax(b))
+    F_.proj_wgrad(a, b, dw, cs, rp, L, amax=amax)
+    lib_err = _err((a * flag.float() if masked else a).t() @ b, ref_dw)
+    assert _err(dw, ref_dw) <= 2 * lib_err + 1e-7, (_err(dw, ref_dw), lib_err)
+    assert float((cs.double() - ref_cs).abs().max()) <= 1e-6 * float(am.abs().sum(0).max()) + 1e-12
+    dw2, cs2 = torch.empty_like(dw), torch.empty_like(cs)
+    F_.proj_wgrad(a, b, dw2, cs2, rp, L, amax=amax)
+    assert torch.equal(dw, dw2) and torch.equal(cs, cs2)
+    F_.proj_wgrad(a, b, dw2, cs2, rp, L)                              # six-product form: the same bar
+    assert _err(dw2, ref_dw) <= 2 * lib_err + 1e-7
+
+
+def test_absmax_strided_bf16_and_merge():
+    from ampnet_amd.conv import functional as F_
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(1)
+    wide = torch.randn(3000, 768, device=dev, generator=g)
+    wide[17, 300] = -77.5
+    wide[5, 700] = 1e9                                                # outside the column block below
+    assert float(F_.absmax(wide[:, 256:512])) == 77.5
+    m = F_.absmax(wide[:, :256])
+    F_.absmax(wide[:, 512:], out=m)                                   # merged into an existing maximum
+    assert float(m) == 1e9
+    h = wide[:, :256].bfloat16()
+    assert float(F_.absmax(h)) == float(h.float().abs().max())
+    assert float(F_.absmax(torch.zeros(8, 4, device=dev))) == 0.0
 
 
 # ---- bf16 storage (csrc/proj_gemm_bf16.hip; BASELINE config 5).  One bf16 x bf16 product per element pair is exact in
@@ -397,7 +494,7 @@ def test_proj_node_list_argument_checks():
     def rows(L, rowptr, dtype, n):
         return lib.ampconv_proj_rows(x.data_ptr(), 256, x.size(0), 256, img.data_ptr(), 256, None,
                                      None if rowptr is None else rowptr.data_ptr(), L, x.data_ptr(), 256,
-                                     ids.data_ptr(), n, dtype, None)
+                                     ids.data_ptr(), n, None, None, dtype, None)
     assert rows(20, None, F32, 4) == -2          # fp32 storage takes no list
     assert rows(20, rp, BF16, 4) == -1           # list and mask together
     assert rows(8, None, BF16, 4) == -1          # L < 16
