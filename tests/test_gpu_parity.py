@@ -77,6 +77,20 @@ def test_golden_single_layer(path, dev):
 
 
 @pytest.mark.parametrize('path', SINGLE, ids=[os.path.basename(p)[:-4] for p in SINGLE])
+def test_golden_single_layer_scaled_projections(path, dev, monkeypatch):
+    # the fp32 projections' scaled two-plane mode (three fp16 products; what every large workload runs: functional.
+    # PROJ_SCALED_MIN_ELEMENTS) forced onto the golden vectors' small graphs: same vectors, same tolerance
+    from ampnet_amd.conv import functional as F_
+    monkeypatch.setattr(F_, 'PROJ_SCALED_MIN_ELEMENTS', 0)
+    calls = []
+    real = F_.absmax
+    monkeypatch.setattr(F_, 'absmax', lambda *a, **k: calls.append(1) or real(*a, **k))
+    g = load_golden(path)
+    _check_single(g, dev)
+    assert calls or int(g['D']) % 4, 'the scaled mode did not run'
+
+
+@pytest.mark.parametrize('path', SINGLE, ids=[os.path.basename(p)[:-4] for p in SINGLE])
 def test_golden_gemm_library_fp32(path, dev):
     # the projections on the library's fp32 GEMMs (gemm_precision='fp32': what serves bf16 storage and
     # embed_dim % 128 != 0, and round 2's only path) against the same vectors; the default 'native' mode
@@ -223,10 +237,14 @@ def test_edge_cases(dev):
                                    (1500, 9000, 20, 128, 8), (500, 4000, 7, 24, 3),
                                    (800, 6000, 13, 64, 2), (800, 6000, 17, 64, 4), (600, 5000, 3, 32, 2)],
                          ids=['cora_like', 'cfg4_like', 'cfg3_like', 'odd', 'L13_dh32', 'L17_dh16', 'L3_dh16'])
-def test_seeded_vs_oracle(shape, dev):
-    """Larger seeded graphs (uniform + one hub + isolated nodes) against the numpy oracle."""
+@pytest.mark.parametrize('scaled', [False, True], ids=['six_products', 'scaled_planes'])
+def test_seeded_vs_oracle(shape, scaled, dev, monkeypatch):
+    """Larger seeded graphs (uniform + one hub + isolated nodes) against the numpy oracle, the fp32 projections in
+    both forms (six bf16 products: what graphs of this size run by default; scaled two-plane: what large ones run)."""
     from ampnet_amd import AMPConv
+    from ampnet_amd.conv import functional as F_
     from oracle.ampconv_numpy import AMPConvOracle
+    monkeypatch.setattr(F_, 'PROJ_SCALED_MIN_ELEMENTS', 0 if scaled else 1 << 62)
     N, E, L, D, H = shape
     torch.manual_seed(11)
     layer = AMPConv(D, H).to(dev)
@@ -771,6 +789,15 @@ def test_message_aggregate_gradients_match_fused(dev):
     assert (yb[3] == 0).all()
     for name, a, b in zip(['dx', 'g_in_w', 'g_in_b', 'g_out_w', 'g_out_b'], ga, gb):
         assert_close_scaled(b.cpu().numpy(), a.cpu().numpy(), name + ' (message+aggregate vs fused)')
+
+
+def test_message_aggregate_gradients_scaled_projections(dev, monkeypatch):
+    """The same with the fp32 projections' scaled two-plane mode forced on (the pre-gathered x_i / x_j path measures two
+    input maxima and records the K | V projection's)."""
+    from ampnet_amd.conv import functional as F_
+    monkeypatch.setattr(F_, 'PROJ_SCALED_MIN_ELEMENTS', 0)
+    test_message_aggregate_gradients_match_fused(dev)
+    test_message_matches_per_edge_reference(dev)
 
 
 def test_retain_attention_auto(dev, monkeypatch):
