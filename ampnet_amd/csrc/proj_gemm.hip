@@ -323,13 +323,27 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void proj_rows_kernel(RowsArgs a) 
       rp[i] = a.A + m * a.lda + 4 * c;
     }
   };
-  float4 x[2][NLH];                     // one 32-deep line block of the thread's rows: [half][row]
+  // Row loads are inline assembly, their waits counted by hand: hipcc's wait bookkeeping does not see the LDS-DMA
+  // pieces (also assembly), so the wait it would put in front of the first use of an ordinary load -- "all my loads but
+  // the n youngest" -- also drains every DMA piece issued since: a full L2 round trip in the even step, in plain sight
+  // once the products per step were halved (in-kernel stamps: even step 3306 cycles, odd step 1885).
+  f32x4 x[2][NLH];                      // one 32-deep line block of the thread's rows: [half][row]
+  auto gload = [](const float *p) {
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+  };
+// behind a wait: the values of half H are used after this point only
+#define ROWS_LANDED(H)                                                   \
+  do {                                                                   \
+    _Pragma("unroll") for (int i_ = 0; i_ < NLH; ++i_) asm volatile("" : "+v"(x[H][i_])); \
+  } while (0)
   auto load_rows = [&]() {
 #pragma unroll
     for (int i = 0; i < NLH; ++i) {
       if (!RAGGED) {
-        x[0][i] = *reinterpret_cast<const float4 *>(rp[i]);
-        x[1][i] = *reinterpret_cast<const float4 *>(rp[i] + 16);
+        x[0][i] = gload(rp[i]);
+        x[1][i] = gload(rp[i] + 16);
       } else {
         // The even step waits for the weight DMAs with a COUNTED vmcnt (2 * NLH younger row loads stay in flight), so
         // the number of vector-memory instructions a wave issues here must not depend on K: a conditional load is
@@ -337,20 +351,22 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void proj_rows_kernel(RowsArgs a) 
         // count would then cover this wave's DMA pieces only by luck.  Load unconditionally from an in-bounds address
         // (the row's first float4 where the column lies beyond K) and zero by select.
         const bool in0 = kpos < a.K, in1 = kpos + 16 < a.K;
-        const float4 v0 = *reinterpret_cast<const float4 *>(in0 ? rp[i] : rp[i] - kpos);
-        const float4 v1 = *reinterpret_cast<const float4 *>(in1 ? rp[i] + 16 : rp[i] - kpos);
-        x[0][i] = make_float4(in0 ? v0.x : 0.f, in0 ? v0.y : 0.f, in0 ? v0.z : 0.f, in0 ? v0.w : 0.f);
-        x[1][i] = make_float4(in1 ? v1.x : 0.f, in1 ? v1.y : 0.f, in1 ? v1.z : 0.f, in1 ? v1.w : 0.f);
+        // (zeroed by select where the VALUES are first used, split_rows: nothing may touch the registers before the wait)
+        x[0][i] = gload(in0 ? rp[i] : rp[i] - kpos);
+        x[1][i] = gload(in1 ? rp[i] + 16 : rp[i] - kpos);
       }
       rp[i] += 32;
     }
     kpos += 32;
   };
-  auto split_rows = [&](auto half, int buf) {       // `half` is a compile-time constant: x stays in registers
+  // (kcol: RAGGED only, the column of the thread's float4 in the block being split: beyond K it reads as zero)
+  auto split_rows = [&](auto half, int buf, int kcol) {       // `half` is a compile-time constant: x stays in registers
     char *base = smem + buf * kBuf + wdst;
+    const bool inb = !RAGGED || kcol + 16 * decltype(half)::value < a.K;
 #pragma unroll
     for (int i = 0; i < NLH; ++i) {
-      const float4 v = x[decltype(half)::value][i];
+      f32x4 v = x[decltype(half)::value][i];
+      if (RAGGED) v = inb ? v : f32x4{0.f, 0.f, 0.f, 0.f};
       const Pair3 p0 = split_pair_t<HP>(v.x, v.y, sa), p1 = split_pair_t<HP>(v.z, v.w, sa);
       char *d = base + i * kWStep;
       *reinterpret_cast<i32x2 *>(d) = i32x2{p0.h1, p1.h1};
@@ -400,8 +416,10 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void proj_rows_kernel(RowsArgs a) 
   rebase(cur);
   dma_step(cur, 0, 0);
   load_rows();
-  split_rows(std::integral_constant<int, 0>{}, 0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  ROWS_LANDED(0);
+  ROWS_LANDED(1);
+  split_rows(std::integral_constant<int, 0>{}, 0, kpos - 32);
 
   for (;;) {
 #pragma unroll
@@ -427,7 +445,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void proj_rows_kernel(RowsArgs a) 
       PSTAMP(1);
       dma_step(cur, 2 * kb + 1, 1);
       compute(0);
-      split_rows(std::integral_constant<int, 1>{}, 1);
+      split_rows(std::integral_constant<int, 1>{}, 1, kpos - 32);       // (its half landed with the last full wait)
       const bool last = kb + 1 == KB;
       if (last) rebase(nxt);
       const bool request = !last || nxt.valid;      // workgroup-uniform
@@ -445,8 +463,12 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void proj_rows_kernel(RowsArgs a) 
       PSTAMP(3);
       dma_step(last ? (nxt.valid ? nxt : cur) : cur, last ? 0 : 2 * kb + 2, 0);
       compute(1);
-      split_rows(std::integral_constant<int, 0>{}, 0);
+      // the row block requested in the even step (older than this step's DMA pieces, which stay in flight)
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPieces / NW) : "memory");
+      ROWS_LANDED(0);
+      split_rows(std::integral_constant<int, 0>{}, 0, kpos - 32);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      ROWS_LANDED(1);
       PSTAMP(4);
     }
     // store tail.  C/D register e of lane (col = lane & 31, hi = lane >> 5) is row (e & 3) + 8 (e >> 2) + 4 hi of a
@@ -605,38 +627,51 @@ __global__ __launch_bounds__(64 * WI * WJ, 2) void proj_wgrad_kernel(WgradArgs a
   // scaled mode: the partial tiles are in scaled units (wgrad_reduce_kernel undoes both scales); the column sums are not
   const float sa = HP ? plane_scale(*a.amax_a) : 1.f, sb = HP ? plane_scale(*a.amax_b) : 1.f;
 
-  float4 xa[NLA], xb[NLB];
-  auto load_stage = [&](int s) {
+  // rows of TWO stages ahead live in registers (set = stage & 1): at three products per stage a stage lasts ~0.7 us, less
+  // than a trip to HBM, and with one stage in flight the kernel waited for its loads (dWin 31.0 ms at cfg4's shape).  The
+  // row flag (slice end / mask) is applied where the rows are split, not where they are requested: a multiply right
+  // behind the load would wait for it there
+  // (the 128 x 256 shape -- Na an odd multiple of 128 against Nb a multiple of 256, no layer shape of the benchmarks --
+  // has no registers left for a second set: one stage ahead there)
+  constexpr int NSET = (TI == 128 && TJ == 256) ? 1 : 2;
+  float4 xa[NSET][NLA], xb[NSET][NLB];
+  float fa[NSET][NLA];
+  auto load_stage = [&](int s, auto set_c) {
+    constexpr int set = decltype(set_c)::value;
     const int64_t mb = m0 + (int64_t)s * kRS;
 #pragma unroll
     for (int i = 0; i < NLA; ++i) {
       const int64_t m = mb + ra + kRowsA * i;
       const int64_t mc = m < m1 ? m : m1 - 1;
-      if (!RAGGED || ti * TI + 4 * ca < a.Na) xa[i] = *reinterpret_cast<const float4 *>(pa + mc * a.lda);
-      else xa[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!RAGGED || ti * TI + 4 * ca < a.Na) xa[set][i] = *reinterpret_cast<const float4 *>(pa + mc * a.lda);
+      else xa[set][i] = make_float4(0.f, 0.f, 0.f, 0.f);
       float f = m < m1 ? 1.f : 0.f;
       if (MASK) {
         const int64_t node = mc / a.L;
         f = a.rowptr[node + 1] != a.rowptr[node] ? f : 0.f;
       }
-      if (MASK || s == ns - 1) { xa[i].x *= f; xa[i].y *= f; xa[i].z *= f; xa[i].w *= f; }
+      fa[set][i] = f;
     }
 #pragma unroll
     for (int i = 0; i < NLB; ++i) {
       const int64_t m = mb + rb + kRowsB * i;
       const int64_t mc = m < m1 ? m : m1 - 1;
-      if (!RAGGED || tj * TJ + 4 * cb < a.Nb) xb[i] = *reinterpret_cast<const float4 *>(pb + mc * a.ldb);
-      else xb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!RAGGED || tj * TJ + 4 * cb < a.Nb) xb[set][i] = *reinterpret_cast<const float4 *>(pb + mc * a.ldb);
+      else xb[set][i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
-  load_stage(0);
+  load_stage(0, std::integral_constant<int, 0>{});
+  if (NSET == 2 && ns > 1) load_stage(1, std::integral_constant<int, NSET - 1>{});
 
-  for (int s = 0; s < ns; ++s) {
+  auto stage = [&](int s, auto set_c) {
+    constexpr int set = decltype(set_c)::value;
     char *buf = smem + (s & 1) * kStage;
 #pragma unroll
     for (int i = 0; i < NLA; ++i) {
-      cs.x += xa[i].x; cs.y += xa[i].y; cs.z += xa[i].z; cs.w += xa[i].w;
-      const Pair3 p0 = split_pair_t<HP>(xa[i].x, xa[i].y, sa), p1 = split_pair_t<HP>(xa[i].z, xa[i].w, sa);
+      float4 v = xa[set][i];
+      if (MASK || s >= ns - 1) { const float f = fa[set][i]; v.x *= f; v.y *= f; v.z *= f; v.w *= f; }
+      cs.x += v.x; cs.y += v.y; cs.z += v.z; cs.w += v.w;
+      const Pair3 p0 = split_pair_t<HP>(v.x, v.y, sa), p1 = split_pair_t<HP>(v.z, v.w, sa);
       char *d = buf + wa[i];
       *reinterpret_cast<i32x2 *>(d) = i32x2{p0.h1, p1.h1};
       *reinterpret_cast<i32x2 *>(d + kPlaneA) = i32x2{p0.h2, p1.h2};
@@ -644,13 +679,14 @@ __global__ __launch_bounds__(64 * WI * WJ, 2) void proj_wgrad_kernel(WgradArgs a
     }
 #pragma unroll
     for (int i = 0; i < NLB; ++i) {
-      const Pair3 p0 = split_pair_t<HP>(xb[i].x, xb[i].y, sb), p1 = split_pair_t<HP>(xb[i].z, xb[i].w, sb);
+      const float4 v = xb[set][i];
+      const Pair3 p0 = split_pair_t<HP>(v.x, v.y, sb), p1 = split_pair_t<HP>(v.z, v.w, sb);
       char *d = buf + wb[i];
       *reinterpret_cast<i32x2 *>(d) = i32x2{p0.h1, p1.h1};
       *reinterpret_cast<i32x2 *>(d + kPlaneB) = i32x2{p0.h2, p1.h2};
       if (kNP == 3) *reinterpret_cast<i32x2 *>(d + 2 * kPlaneB) = i32x2{p0.h3, p1.h3};
     }
-    if (s + 1 < ns) load_stage(s + 1);
+    if (s + NSET < ns) load_stage(s + NSET, set_c);
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     i32x4 bf[NJW][3];
 #pragma unroll
@@ -680,6 +716,10 @@ __global__ __launch_bounds__(64 * WI * WJ, 2) void proj_wgrad_kernel(WgradArgs a
           for (int j = 0; j < NJW; ++j)
             acc[i + ii][j] = mfma_p<HP>(af[ii][kPA[HP][q]], bf[j][kPB[HP][q]], acc[i + ii][j]);
     }
+  };
+  for (int s = 0; s < ns; s += NSET) {
+    stage(s, std::integral_constant<int, 0>{});
+    if (NSET == 2 && s + 1 < ns) stage(s + 1, std::integral_constant<int, NSET - 1>{});
   }
 
   // partial tile of this slice
@@ -1009,3 +1049,11 @@ extern "C" int ampconv_proj_wgrad(const void *A_, int64_t lda, const void *B_, i
                                                                          dW, colsum, a_absmax, b_absmax);
   return ampconv_launch_status();
 }
+
+#ifdef AMPCONV_PROJ_STAMPS
+// diagnostic build only (tools/stamp_proj.py)
+extern "C" int ampconv_debug_read_proj_stamps(unsigned long long *out, int n) {
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_proj_stamps), sizeof(unsigned long long) * (size_t)n);
+}
+#endif

@@ -19,8 +19,10 @@ x = torch.randn(M, D, device=dev)
 w_in = torch.randn(3 * D, D, device=dev) * 0.06
 b_in = torch.randn(3 * D, device=dev)
 img = F_.proj_image(w_in)
+scaled = '--scaled' in sys.argv                 # the two-plane kernels (three products per step instead of six)
+amax = F_.absmax(x) if scaled else None
 for _ in range(3):
-    F_.proj_rows(x, img, b_in)
+    F_.proj_rows(x, img, b_in, amax=amax)
 torch.cuda.synchronize()
 raw = ctypes.CDLL(os.environ['AMPCONV_LIB_PATH'])
 buf = (ctypes.c_ulonglong * (8 * 4096))()
@@ -33,7 +35,7 @@ tot = a.sum()
 variant = int(os.environ.get('AMPCONV_PROJ_ROWS', '0'))
 bm, bn, waves = {0: (128, 256, 4), 1: (256, 256, 8), 2: (128, 128, 4)}[variant]
 blocks = (M / bm) * (3 * D / bn) * (D / 32) / len(a)
-mfma = 2 * (bm // 32) * (bn // 32) * 6 // waves
+mfma = 2 * (bm // 32) * (bn // 32) * (3 if scaled else 6) // waves
 print(f'shape {variant} ({bm} x {bn}, {waves} waves): {len(a)} workgroups, {blocks:.0f} 32-deep line blocks each, '
       f'{a.sum(1).mean() / blocks:.0f} cycles per block per wave (MFMA issue alone: {mfma * 32}, x2 with the SIMD partner)')
 for n, v in zip(names, a.sum(0)):
