@@ -31,10 +31,14 @@ def main():
     y_ref, _ = o.forward(x.double().numpy(), ei.numpy(), need_weights=False)
     ref = (y_ref,) + tuple(o.backward(dy.double().numpy()))
     names = ('y', 'dx', 'd in_proj_weight', 'd in_proj_bias', 'd out_proj.weight', 'd out_proj.bias')
-    modes = [sys.argv[sys.argv.index('--gemm') + 1]] if '--gemm' in sys.argv else ['native', 'fp32', 'bf16x3']
+    # 'native' = the scaled two-plane projections (forced on: this graph is below their size threshold),
+    # 'native-6' = the six-product form
+    from ampnet_amd.conv import functional as F_
+    modes = [sys.argv[sys.argv.index('--gemm') + 1]] if '--gemm' in sys.argv else ['native', 'native-6', 'fp32', 'bf16x3']
     res = {}
     for mode in modes:
-        layer.gemm_precision = mode
+        layer.gemm_precision = mode.split('-')[0]
+        F_.PROJ_SCALED_MIN_ELEMENTS = 0 if mode == 'native' else 1 << 62
         layer.zero_grad(set_to_none=True)
         xg = x.to(dev).requires_grad_(True)
         y = layer(xg, ei.to(dev))

@@ -1,16 +1,39 @@
 #!/bin/bash
 # rocprofv3 passes behind profiles/<tag>_*: kernel-trace stats of the headline run, the two TCC traffic passes
 # (separate: FETCH_SIZE / WRITE_SIZE do not fit one pass), kernel stats of cfg5 and the SQ counter passes.
-# Counters are collected with --kernel-trace only (no other trace domain).   usage: tools/run_profiles.sh <tag>
-tag=${1:-r03}
+# Counters are collected with --kernel-trace only (no other trace domain).
+#   usage: tools/run_profiles.sh <tag> [part]     part: all (default) | bench | counters
+tag=${1:-r04}
+part=${2:-all}
 d=gpurun_out/prof_$tag
 mkdir -p $d
 export TMPDIR=/tmp
+if [ "$part" != counters ]; then
 rocprofv3 --kernel-trace --stats --output-format csv -d $d -o stats -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt-gemm --no-extra > $d/bench_stats.log 2> $d/bench_stats.err || exit 1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $d -o fetch -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-alt-gemm --no-extra > $d/bench_fetch.log 2> $d/bench_fetch.err || exit 1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $d -o write -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-alt-gemm --no-extra > $d/bench_write.log 2> $d/bench_write.err || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d $d -o cfg5 -- python3 bench.py --workload cfg5 --steps 2 --warmup 1 --no-cpu-baseline --no-extra > $d/bench_cfg5.log 2> $d/bench_cfg5.err || exit 1
-bash tools/prof_sq.sh ${tag}_final > $d/sq_summary.txt 2>&1
-bash tools/prof_sq_proj.sh ${tag}_proj 8000000 256 --iters=2 --no-lib >> $d/sq_summary.txt 2>&1
+fi
+if [ "$part" != bench ]; then
+{
+echo "## fp32 edge kernels (cfg4 shape: uniform graph, L=20 D=256 H=8)"
+bash tools/prof_sq.sh ${tag}_f32
+bash tools/prof_fp32_pipe.sh ${tag}_pipe_f32
+echo "## bf16 edge kernels (R-MAT, cfg5 shape at 1/4 size)"
+bash tools/prof_sq.sh ${tag}_bf16 524288 10000000 20 256 8 --bf16 --rmat
+bash tools/prof_fp32_pipe.sh ${tag}_pipe_bf16 524288 10000000 20 256 8 --bf16 --rmat
+echo "## block kernels (AMPGCN default shape L=40 D=100 H=2)"
+bash tools/prof_sq.sh ${tag}_block 100000 1000000 40 100 2
+bash tools/prof_fp32_pipe.sh ${tag}_pipe_block 100000 1000000 40 100 2
+echo "## fp32 projections, scaled two-plane mode (8M rows, D=256)"
+bash tools/prof_sq_proj.sh ${tag}_proj_scaled 8000000 256 --iters=2 --no-lib --scaled
+echo "## fp32 projections, six-product form"
+bash tools/prof_sq_proj.sh ${tag}_proj_6p 8000000 256 --iters=2 --no-lib
+echo "## bf16 projections"
+bash tools/prof_sq_proj.sh ${tag}_proj_bf16 8000000 256 --iters=2 --no-lib --bf16
+} > $d/sq_summary.txt 2>&1
+# the raw counter CSVs are large (gpurun copies back at most 64 MiB): the summary is what is kept
+rm -rf gpurun_out/sq_r4/${tag}_*
+fi
 ls $d | head -40
-cat $d/sq_summary.txt
+tail -60 $d/sq_summary.txt

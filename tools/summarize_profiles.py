@@ -36,6 +36,30 @@ def short(name, n=118):
     return name if len(name) <= n else name[:n]
 
 
+def step_table(trace_csv, first_pat, last_pat):
+    """Every kernel launched inside the LAST step of a profiled bench run, from the kernel trace.  A step opens with the
+    graph preparation (two `first_pat` = extract_keys launches, one per sort) and closes with the input-gradient
+    projection behind the last weight-gradient reduction: the window runs from the first extract_keys of the last pair to
+    the last launch matching `last_pat`.  Returns markdown lines (kernel, launches, total ms)."""
+    rows = sorted(csv.DictReader(open(trace_csv)), key=lambda r: int(r['Start_Timestamp']))
+    names = [r['Kernel_Name'] for r in rows]
+    last = max(i for i, n in enumerate(names) if re.search(last_pat, n))
+    keys = [i for i, n in enumerate(names[:last]) if re.search(first_pat, n)]
+    first = keys[-2] if len(keys) >= 2 else keys[-1]
+    agg = {}
+    for r in rows[first:last + 1]:
+        a = agg.setdefault(r['Kernel_Name'], [0, 0])
+        a[0] += 1
+        a[1] += int(r['End_Timestamp']) - int(r['Start_Timestamp'])
+    span = (int(rows[last]['End_Timestamp']) - int(rows[first]['Start_Timestamp'])) / 1e6
+    out = [f'Window: {span:.1f} ms from the first `extract_keys` launch of the step (graph preparation) to its last projection launch; '
+           f'{sum(a[0] for a in agg.values())} launches, {sum(a[1] for a in agg.values()) / 1e6:.1f} ms of kernel time.\n\n',
+           '| kernel | launches | total ms |\n|---|---|---|\n']
+    for n, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        out.append(f'| `{short(n)}` | {c} | {t / 1e6:.3f} |\n')
+    return out
+
+
 def counter(path, device_kernel, launches):
     tot, calls = 0.0, 0
     for row in csv.DictReader(open(path)):
@@ -70,6 +94,10 @@ def main():
         for r in rows[:22]:
             f.write(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['AverageNs']) / 1e6:.3f} | "
                     f"{float(r['TotalDurationNs']) / 1e6:.1f} | {r['Percentage']} |\n")
+        tr = os.path.join(d, 'stats_kernel_trace.csv')
+        if os.path.exists(tr):
+            f.write('\nEverything launched inside ONE timed step (kernel trace of the same run):\n\n')
+            f.writelines(step_table(tr, r'extract_keys', r'proj_rows_kernel|wgrad_reduce_kernel'))
     N, E, L, D = cfg['N'], cfg['E'], cfg['L'], cfg['D']
     R = L * D * 4
     alg = {'ampconv_fwd_edge': (2 * E + 2 * N) * R, 'ampconv_bwd_edge_dst': (2 * E + 3 * N) * R,
@@ -122,20 +150,31 @@ def main():
             for r in rows5[:22]:
                 f.write(f"| `{short(r['Name'])}` | {r['Calls']} | {float(r['AverageNs']) / 1e6:.3f} | "
                         f"{float(r['TotalDurationNs']) / 1e6:.1f} | {r['Percentage']} |\n")
+            f.write('\nThe `at::native::*` rows above are the bench\'s set-up (R-MAT generator, randn + cast of the inputs), '
+                    'not the layer.  Everything launched inside ONE timed step, from the kernel trace of the same run '
+                    '(`cfg5_kernel_trace.csv`): no `Cijk_*` (rocBLAS / Tensile) and no `at::native::*` kernel.\n\n')
+            f.writelines(step_table(os.path.join(d, 'cfg5_kernel_trace.csv'), r'extract_keys', r'proj_rows_bf16_kernel|mask_rows_kernel|wgrad_reduce_bf16'))
     sq = os.path.join(d, 'sq_summary.txt')
     if os.path.exists(sq):
         with open(os.path.join(out, f'{tag}_sq_counters.md'), 'w') as f:
-            f.write(f'# SQ counters of the edge and projection kernels ({tag}; tools/prof_sq.sh, tools/prof_sq_proj.sh + tools/summarize_sq2.py)\n\n')
-            f.write('Two `rocprofv3 --pmc ... --kernel-trace` passes over `tools/bench_kernels.py` (100 k nodes / 1 M edges, L=20, '
-                    'D=256, H=8, fp32): `SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU '
-                    'SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE` and `SQ_WAVE_CYCLES '
-                    'SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_VALU_MFMA_COEXEC_CYCLES '
-                    'SQ_ACTIVE_INST_VMEM GRBM_GUI_ACTIVE`.  Fractions are of SQ_WAVE_CYCLES; mfma_busy = '
+            f.write(f'# SQ counters of the edge and projection kernels ({tag}; tools/prof_sq.sh, tools/prof_fp32_pipe.sh, tools/prof_sq_proj.sh)\n\n')
+            f.write('Collected by `tools/run_profiles.sh <tag> counters` on the final code of the round.  Per kernel family: two '
+                    '`rocprofv3 --pmc ... --kernel-trace` passes (`tools/prof_sq.sh` over `tools/bench_kernels.py`, '
+                    '`tools/prof_sq_proj.sh` over `tools/bench_proj.py`): `SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY '
+                    'SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT '
+                    'GRBM_GUI_ACTIVE` and `SQ_WAVE_CYCLES SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS '
+                    'SQ_VALU_MFMA_COEXEC_CYCLES SQ_ACTIVE_INST_VMEM GRBM_GUI_ACTIVE`; fractions are of SQ_WAVE_CYCLES; mfma_busy = '
                     'SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (duration x clock), clock = GRBM_GUI_ACTIVE / 8 / duration.  '
-                    f'`{tag}_final` = the edge kernels as shipped; `{tag}_proj` = the projection kernels over `tools/bench_proj.py '
-                    '8000000 256` (8 M rows, D = 256: `proj_rows` averages the qkv / out / dx launches, `proj_wgrad` the dWin / dWo '
-                    'launches; their clock column is the DVFS evidence of DESIGN.md 4: bf16 MFMA at ~0.6 pipe occupancy holds '
-                    '~1.7-1.9 GHz on random data).  Profiled runs are a few % slower than un-profiled ones.\n\n```\n')
+                    'The `pipe` tables (`tools/prof_fp32_pipe.sh`, one more pass: `SQ_BUSY_CU_CYCLES SQ_THREAD_CYCLES_VALU '
+                    'SQ_INSTS_VALU_TRANS_F32` added) are the FP32-pipe occupancy of VERDICT r3 item 2: matrix pipe busy + VALU '
+                    'active over SIMD cycles (fp32-input MFMA and VALU share one pipe on gfx950: `tools/coexec_probe`); for the '
+                    'bf16 kernels, whose MFMAs co-issue with VALU, the two columns are separate resources and the VALU column is '
+                    'the binding one.  Shapes: fp32 edge kernels 100 k nodes / 1 M edges, L=20, D=256, H=8 (uniform); bf16 edge '
+                    'kernels R-MAT scale 19 / 10 M edges (config 5 at a quarter of its size); block kernels L=40, D=100, H=2 (the '
+                    'reference\'s AMPGCN defaults); projections 8 M rows, D = 256 (`proj_rows` averages the qkv / out / dx launches, '
+                    '`proj_wgrad` the dWin / dWo launches).  The projections\' clock column is the DVFS evidence of DESIGN.md 4a: '
+                    '1.54-1.75 GHz on random data in both the six-product and the scaled three-product form.  Profiled runs are a '
+                    'few % slower than un-profiled ones.\n\n```\n')
             f.write(open(sq).read())
             f.write('```\n')
 
