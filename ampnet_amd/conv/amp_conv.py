@@ -70,9 +70,10 @@ class AMPConv(MessagePassing):
         self._attn_dropped_bytes = 0
         self._attn_param_versions = None
         # how the per-node projections run: 'native' (default: libampconv's own kernels, csrc/proj_gemm.hip -- fp32
-        # operands split exactly into three bf16 terms, six partial products on the bf16 matrix cores, fp32
-        # accumulate; fp32 storage with embed_dim % 4 == 0 -- tiles are padded inside, so the reference's default 100 is
-        # served --, anything else falls to 'fp32') | 'fp32' (library
+        # operands as two fp16 planes of the power-of-two-scaled value, three partial products on the matrix cores
+        # (operands of 2^24 elements and more; below that three bf16 planes, six products), fp32 accumulate, error
+        # below the fp32 library GEMM's; fp32 storage with embed_dim % 4 == 0 -- tiles are padded inside, so the
+        # reference's default 100 is served --, anything else falls to 'fp32') | 'fp32' (library
         # GEMMs, rocBLAS) | 'bf16x3' (hipBLASLt's 3-product split, 8x the error) -- functional.gemm_precision
         self.gemm_precision = os.environ.get('AMPCONV_GEMM', 'native')
         self.num_heads = num_heads

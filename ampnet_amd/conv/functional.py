@@ -97,8 +97,9 @@ def _tn_matmul(a, b, chunks=128):
     return out
 
 
-# ---- the per-node projections in libampconv.so.  fp32 storage (csrc/proj_gemm.hip): operands split exactly into
-# three bf16 terms, six partial products on v_mfma_f32_32x32x16_bf16, fp32 accumulate; bf16 storage
+# ---- the per-node projections in libampconv.so.  fp32 storage (csrc/proj_gemm.hip): operands scaled by a power of two
+# and split into two fp16 planes, three partial products on v_mfma_f32_32x32x16_f16 (large operands; PROJ_SCALED below), or
+# split exactly into three bf16 terms, six partial products on v_mfma_f32_32x32x16_bf16; fp32 accumulate.  bf16 storage
 # (csrc/proj_gemm_bf16.hip): one product, fp32 accumulate, one rounding on the way out
 NODE_LISTS = os.environ.get('AMPCONV_NODE_LISTS', '1') != '0'      # developer switch (A/B measurements)
 # fp32 storage: two scaled fp16 planes, three products (include/ampconv.h "SCALED MODE"); '0': three bf16 planes, six

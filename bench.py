@@ -216,8 +216,9 @@ def parse_args():
                     help='storage dtype (default: f32; bf16 for cfg5)')
     ap.add_argument('--gemm', default='native', choices=['native', 'fp32', 'bf16x3'],
                     help="per-node projections: 'native' (default, the headline: libampconv's own kernels, fp32 operands "
-                         "split exactly into three bf16 terms, six partial products on the bf16 matrix cores, fp32-grade "
-                         "error -- csrc/proj_gemm.hip), 'fp32' (library GEMMs, rocBLAS) or 'bf16x3' (hipBLASLt's "
+                         "scaled by a power of two and split into two fp16 planes, three partial products on the matrix "
+                         "cores -- six bf16 ones for small operands --, error below the fp32 library GEMM's "
+                         "-- csrc/proj_gemm.hip), 'fp32' (library GEMMs, rocBLAS) or 'bf16x3' (hipBLASLt's "
                          "3-product split, 8x the error; ampnet_amd.conv.functional.gemm_precision)")
     return ap.parse_args()
 
@@ -567,8 +568,9 @@ def measure_full(workload, steps, warmup, args, rank, world, dev, dist_on, dt_na
                         'achieved_TFLOPs_per_gpu': (flops_attn + flops_proj) / t_step / 1e12,
                         'peak_TFLOPs': mfma_peak, 'frac_of_peak': (flops_attn + flops_proj) / t_step / 1e12 / mfma_peak,
                         'peak_note': ('fp32-input MFMA = fp32 vector rate (157.3 TF): the peak of the edge kernels; the '
-                                      "'native' projections run as 6 bf16 MFMA products per fp32 product (2.5 PF / 6 = 417 TF "
-                                      'fp32-equivalent at the dense bf16 peak)') if dt_name == 'f32' else 'dense bf16 MFMA',
+                                      "'native' projections run as 3 fp16 MFMA products per fp32 product on scaled operands "
+                                      '(2.5 PF / 3 = 833 TF fp32-equivalent at the dense 16-bit peak; 6 bf16 products with '
+                                      'AMPCONV_PROJ_SCALED=0): node_phase_mfma') if dt_name == 'f32' else 'dense bf16 MFMA',
                         'floor_ms': {'hbm_at_8TBps': 1e3 * t_hbm, 'mfma_at_peak': 1e3 * t_mfma},
                         'binding': 'mfma' if t_mfma > t_hbm else 'hbm'},
         'node_phase_ms': 1e3 * t_step - edge_ms,             # projections + glue + CSR build (+ all-reduce)
