@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('AMPCONV_LIB_PATH', os.path.join(_HERE, 'libampconv.so'))   # override: dev A/B builds
 
-EXPECTED_ABI = 104          # AMPCONV_VERSION of include/ampconv.h this binding was written against
+EXPECTED_ABI = 105          # AMPCONV_VERSION of include/ampconv.h this binding was written against
 
 AMPCONV_F32 = 0
 AMPCONV_BF16 = 1
@@ -53,9 +53,9 @@ SIGNATURES = {
     'ampconv_csc_positions': (_i32, [_vp, _vp, _i64, _vp, _vp, _vp]),
     'ampconv_softmax_stats_bytes': (_sz, [_i64, _i32, _i32, _i32, _i32]),
     'ampconv_bwd_edge_dst': (_i32, [View, View, View, View, _vp, _vp, _i64, _i32, _i32, _i32, View, _vp, _i64, _vp,
-                                    _vp, _vp, _i32, _vp]),
+                                    _vp, _vp, _vp, _i32, _vp]),
     'ampconv_bwd_edge_src': (_i32, [View, View, View, View, _vp, _vp, _vp, _i64, _i32, _i32, _i32,
-                                    View, View, _vp, _i64, _vp, _vp, _i32, _vp]),
+                                    View, View, _vp, _i64, _vp, _vp, _vp, _i32, _vp]),
     'ampconv_attn_weights': (_i32, [View, View, _vp, _i64, _i32, _i32, _i32, _vp, _i32, _vp]),
     'ampconv_attn_scores': (_i32, [View, View, _vp, _i64, _i32, _i32, _i32, _vp, _i32, _vp]),
     'ampconv_gather_segment_sum': (_i32, [_vp, _vp, _vp, _vp, _i32, _i64, _i64, _vp, _vp]),

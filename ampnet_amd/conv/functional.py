@@ -346,7 +346,7 @@ class AMPConvFunction(torch.autograd.Function):
             # out-projection: rows with no in-edge contribute nothing (their obar is 0, and
             # the bias gradient masks them explicitly)
             lists, am = ctx.lists, ctx.amax
-            ag = None           # maxima of the gradients that are operands: [dY, dQ(KV), dKV]
+            ag = None           # maxima of the gradients that are operands: [dY, dQ (shared: dQKV), dK | dV]
             if am is not None:
                 ag = torch.empty(3, dtype=torch.float32, device=dev)
                 absmax(dy2, ag[0:1], reset=True)
@@ -389,15 +389,25 @@ class AMPConvFunction(torch.autograd.Function):
                 stats = torch.empty(nstat // 4, dtype=torch.float32, device=dev)
                 spos = csr.csc_positions()
             plan, nch, ws = csr.hub_args('dst', L, D, 1)
+            # (scaled projections: the operand maximum of the two products that consume dQKV.  The destination pass
+            # records the maximum of dQ as it stores; dK | dV: one pass below -- the source-pass kernels have no register
+            # to spare for it (csrc/edge_mfma.hip); shared: one maximum, else dQ and dK | dV apart)
+            if am is not None:
+                _zero(ag[1:2])
             rc = lib.ampconv_bwd_edge_dst(Qv, Kv, Vv, dOv, csr.rowptr.data_ptr(), csr.col.data_ptr(),
                                           Nq, L, D, H, dQv, plan, nch, _ptr(ws), _ptr(spos), _ptr(stats),
-                                          ctx.dtype, _stream())
+                                          _ptr(sl(ag, 1)), ctx.dtype, _stream())
             _lib.check(rc, 'ampconv_bwd_edge_dst')
             plan, nch, ws = csr.hub_args('src', L, D, 2)
             rc = lib.ampconv_bwd_edge_src(Qv, Kv, Vv, dOv, csr.cscptr.data_ptr(), csr.crow.data_ptr(),
                                           csr.cinv.data_ptr(), Nk, L, D, H, dKv, dVv, plan, nch, _ptr(ws),
-                                          _ptr(stats), ctx.dtype, _stream())
+                                          _ptr(stats), None, ctx.dtype, _stream())
             _lib.check(rc, 'ampconv_bwd_edge_src')
+            if am is not None:
+                if shared:
+                    absmax(dqkv[:, D:], ag[1:2])              # merged into the maximum of dQ
+                else:
+                    absmax(dkv, ag[2:3], reset=True)
             # in_proj_bias gradient without a pass over all of dQKV: softmax rows sum to 1, so the
             # column sum of dV over every source token equals the column sum of dObar over the rows
             # that receive messages, and dObar = dY Wo is linear in dY, so that sum is (masked column sum of
@@ -420,15 +430,10 @@ class AMPConvFunction(torch.autograd.Function):
                         _zero_unlisted(dxq2, lists['any'], Nq, L)
                         dxq = dxq2.view(Nq, L * D)
                 elif shared:
-                    if am is not None:
-                        absmax(dqkv, ag[1:2], reset=True)
                     proj_wgrad(dqkv, xq2, dw_in, db_in, amax=pair(sl(ag, 1), sl(am, 0)))
                     dxq = proj_rows(dqkv, ctx.images_t[0], amax=sl(ag, 1)).view(Nq, L * D) if need_xq else None
                     dxkv = None
                 else:
-                    if am is not None:
-                        absmax(dqkv, ag[1:2], reset=True)
-                        absmax(dkv, ag[2:3], reset=True)
                     proj_wgrad(dqkv, xq2, dw_in[:D], db_in[:D], amax=pair(sl(ag, 1), sl(am, 0)))
                     proj_wgrad(dkv, xkv2, dw_in[D:], db_in[D:], amax=pair(sl(ag, 2), sl(am, 2)))
                     dxq = proj_rows(dqkv, ctx.images_t[0], amax=sl(ag, 1)).view(Nq, L * D) if need_xq else None

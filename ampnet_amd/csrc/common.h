@@ -24,6 +24,22 @@ __device__ __forceinline__ float wave_max(float x) {
   for (int o = 32; o > 0; o >>= 1) x = fmaxf(x, __shfl_xor(x, o, 64));
   return x;
 }
+// |x|, or 0 for NaN / infinity (operand maxima skip non-finite values: include/ampconv.h "SCALED MODE")
+__device__ __forceinline__ float finite_abs(float x) {
+  const float a = __builtin_fabsf(x);
+  return a < __builtin_inff() ? a : 0.f;
+}
+__device__ __forceinline__ float finite_abs_max(float m, const float4 &v) {
+  return fmaxf(fmaxf(m, fmaxf(finite_abs(v.x), finite_abs(v.y))), fmaxf(finite_abs(v.z), finite_abs(v.w)));
+}
+// one wave's share of a running maximum kept in *p (non-negative floats order as their bits): a plain read first -- a
+// stale value only costs an atomic that changes nothing -- so that almost every wave of a launch leaves it at the read
+__device__ __forceinline__ void wave_record_absmax(float *p, float m) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m > __builtin_nontemporal_load(p))
+    atomicMax(reinterpret_cast<unsigned *>(p), __builtin_bit_cast(unsigned, m));
+}
 __device__ __forceinline__ float wave_sum(float x) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
@@ -43,6 +59,8 @@ constexpr int kStatsPerUnit = 40;
 struct StatsArgs {
   const int32_t *spos;     // CSR position -> CSC position (dst pass only)
   float *stats;            // nullptr: the source pass reduces its own softmax
+  float *absmax;           // nullptr, or: atomic max of the finite magnitudes the pass writes (include/ampconv.h;
+                           // recorded by edge_mfma's destination pass and the combine pass, the C entry covers the rest)
 };
 
 struct HubArgs {
@@ -161,7 +179,7 @@ int ampconv_bwd_edge_src_small(ampconv_view_t Q, ampconv_view_t K, ampconv_view_
 // hub.hip
 int ampconv_hub_combine(const void *plan, int64_t n_chunks, const float *P, ampconv_view_t out,
                         const int32_t *ptr_for_mean, int L, int D, int H, float scale, int out_bf16,
-                        hipStream_t stream);
+                        hipStream_t stream, float *absmax = nullptr);
 
 // ---- bf16-storage path (edge_mfma_bf16.hip): L <= 20, dh == 32, 16-byte aligned bf16 views
 bool ampconv_bf16_supported(int L, int D, int H, const ampconv_view_t *views, int n);

@@ -130,15 +130,24 @@ extern "C" size_t ampconv_softmax_stats_bytes(int64_t E, int L, int D, int H, in
   return 0;
 }
 
-extern "C" int ampconv_bwd_edge_dst(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
-                                    ampconv_view_t dObar, const int32_t *rowptr,
-                                    const int32_t *col, int64_t n_rows, int L, int D, int H,
-                                    ampconv_view_t dQ, const void *hub_plan, int64_t hub_chunks,
-                                    void *hub_ws, const int32_t *spos, float *stats, int dtype,
-                                    void *stream) {
+// ampconv_absmax (proj_gemm.hip)
+extern "C" int ampconv_absmax(const void *X, int64_t ld, int64_t M, int K, int dtype, float *out, int reset, void *stream);
+
+namespace {
+// out_absmax of the backward passes for the kernel families that do not record it themselves: one pass over what was
+// just written, which must then be a row-major matrix (token rows of D contiguous channels, nodes L rows apart)
+int view_absmax(const ampconv_view_t &v, int64_t n, int L, int D, int H, float *out, void *stream) {
+  if (v.head_stride != D / H || v.node_stride != (int64_t)L * v.row_stride) return AMPCONV_E_BADARG;
+  return ampconv_absmax(v.ptr, v.row_stride, n * L, D, AMPCONV_F32, out, 0, stream);
+}
+
+int bwd_dst_dispatch(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V, ampconv_view_t dObar, const int32_t *rowptr,
+                     const int32_t *col, int64_t n_rows, int L, int D, int H, ampconv_view_t dQ, const void *hub_plan,
+                     int64_t hub_chunks, void *hub_ws, const int32_t *spos, float *stats, float *out_absmax,
+                     bool *recorded, int dtype, void *stream) {
   if (int rc = check_common(L, D, H, dtype)) return rc;
   if (stats && (!spos || (uintptr_t)stats % 16 != 0)) return AMPCONV_E_BADARG;
-  const StatsArgs sa{spos, stats};
+  const StatsArgs sa{spos, stats, out_absmax};
   if (n_rows < 0) return AMPCONV_E_BADARG;
   if (n_rows == 0) return AMPCONV_OK;
   if (!view_ok(Q) || !view_ok(K) || !view_ok(V) || !view_ok(dObar) || !view_ok(dQ) || !rowptr)
@@ -176,17 +185,19 @@ extern "C" int ampconv_bwd_edge_dst(ampconv_view_t Q, ampconv_view_t K, ampconv_
     return ampconv_bwd_edge_dst_small(Q, K, V, dObar, rowptr, col, n_rows, L, D, H, dQ, HubArgs{nullptr, 0}, st);
   }
   if (!bf && !force_generic() && ampconv_mfma_supported(L, D, H) && ampconv_mfma_views_ok(views, 5)) {
+    *recorded = true;          // these kernels (and the combine pass behind them) keep out_absmax themselves
     if (hub_plan && hub_chunks > 0 && hub_ws) {
       HubArgs hm = hub_args(hub_plan, 1), hh = hub_args(hub_plan, 2);
       if (int rc = ampconv_bwd_edge_dst_mfma(Q, K, V, dObar, rowptr, col, n_rows, L, D, H, dQ, hm, sa,
                                              (hipStream_t)stream))
         return rc;
       ampconv_view_t P = partial_view(hub_ws, 0, hub_chunks, L, D, H);
-      if (int rc = ampconv_bwd_edge_dst_mfma(Q, K, V, dObar, rowptr, col, hub_chunks, L, D, H, P, hh, sa,
+      if (int rc = ampconv_bwd_edge_dst_mfma(Q, K, V, dObar, rowptr, col, hub_chunks, L, D, H, P, hh,
+                                             StatsArgs{sa.spos, sa.stats, nullptr},      // partial tiles: not recorded
                                              (hipStream_t)stream))
         return rc;
       return ampconv_hub_combine(hub_plan, hub_chunks, (const float *)P.ptr, dQ, nullptr, L, D, H,
-                                 1.f / sqrtf((float)(D / H)), 0, (hipStream_t)stream);
+                                 1.f / sqrtf((float)(D / H)), 0, (hipStream_t)stream, out_absmax);
     }
     return ampconv_bwd_edge_dst_mfma(Q, K, V, dObar, rowptr, col, n_rows, L, D, H, dQ,
                                      HubArgs{nullptr, 0}, sa, (hipStream_t)stream);
@@ -213,16 +224,30 @@ extern "C" int ampconv_bwd_edge_dst(ampconv_view_t Q, ampconv_view_t K, ampconv_
   return ampconv_bwd_edge_dst_generic(Q, K, V, dObar, rowptr, col, n_rows, L, D, H, dQ,
                                       (hipStream_t)stream);
 }
+}  // namespace
 
-extern "C" int ampconv_bwd_edge_src(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
-                                    ampconv_view_t dObar, const int32_t *cscptr,
-                                    const int32_t *crow, const float *cinv, int64_t n_src,
-                                    int L, int D, int H, ampconv_view_t dK, ampconv_view_t dV,
-                                    const void *hub_plan, int64_t hub_chunks, void *hub_ws,
-                                    const float *stats, int dtype, void *stream) {
+extern "C" int ampconv_bwd_edge_dst(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
+                                    ampconv_view_t dObar, const int32_t *rowptr,
+                                    const int32_t *col, int64_t n_rows, int L, int D, int H,
+                                    ampconv_view_t dQ, const void *hub_plan, int64_t hub_chunks,
+                                    void *hub_ws, const int32_t *spos, float *stats, float *out_absmax,
+                                    int dtype, void *stream) {
+  if (out_absmax && dtype != AMPCONV_F32) return AMPCONV_E_DTYPE;       // operand maxima: fp32 storage (scaled projections)
+  bool recorded = false;
+  const int rc = bwd_dst_dispatch(Q, K, V, dObar, rowptr, col, n_rows, L, D, H, dQ, hub_plan, hub_chunks, hub_ws, spos,
+                                  stats, out_absmax, &recorded, dtype, stream);
+  if (rc != AMPCONV_OK || !out_absmax || recorded || n_rows == 0) return rc;
+  return view_absmax(dQ, n_rows, L, D, H, out_absmax, stream);
+}
+
+namespace {
+int bwd_src_dispatch(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V, ampconv_view_t dObar, const int32_t *cscptr,
+                     const int32_t *crow, const float *cinv, int64_t n_src, int L, int D, int H, ampconv_view_t dK,
+                     ampconv_view_t dV, const void *hub_plan, int64_t hub_chunks, void *hub_ws, const float *stats,
+                     float *out_absmax, bool *recorded, int dtype, void *stream) {
   if (int rc = check_common(L, D, H, dtype)) return rc;
   if (stats && (uintptr_t)stats % 16 != 0) return AMPCONV_E_BADARG;
-  const StatsArgs sa{nullptr, const_cast<float *>(stats)};
+  const StatsArgs sa{nullptr, const_cast<float *>(stats), nullptr};
   if (n_src < 0) return AMPCONV_E_BADARG;
   if (n_src == 0) return AMPCONV_OK;
   if (!view_ok(Q) || !view_ok(K) || !view_ok(V) || !view_ok(dObar) || !view_ok(dK) ||
@@ -270,6 +295,7 @@ extern "C" int ampconv_bwd_edge_src(ampconv_view_t Q, ampconv_view_t K, ampconv_
     return ampconv_bwd_edge_src_small(Q, K, V, dObar, cscptr, crow, cinv, n_src, L, D, H, dK, dV, HubArgs{nullptr, 0}, st);
   }
   if (!bf && !force_generic() && ampconv_mfma_supported(L, D, H) && ampconv_mfma_views_ok(views, 6)) {
+    // (the source-pass kernels do not record out_absmax -- register budget, edge_mfma.hip: the pass below does)
     if (hub_plan && hub_chunks > 0 && hub_ws) {
       HubArgs hm = hub_args(hub_plan, 1), hh = hub_args(hub_plan, 2);
       if (int rc = ampconv_bwd_edge_src_mfma(Q, K, V, dObar, cscptr, crow, cinv, n_src, L, D, H, dK, dV,
@@ -315,4 +341,20 @@ extern "C" int ampconv_bwd_edge_src(ampconv_view_t Q, ampconv_view_t K, ampconv_
   if (stats) return AMPCONV_E_BADARG;
   return ampconv_bwd_edge_src_generic(Q, K, V, dObar, cscptr, crow, cinv, n_src, L, D, H, dK,
                                       dV, (hipStream_t)stream);
+}
+}  // namespace
+
+extern "C" int ampconv_bwd_edge_src(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
+                                    ampconv_view_t dObar, const int32_t *cscptr,
+                                    const int32_t *crow, const float *cinv, int64_t n_src,
+                                    int L, int D, int H, ampconv_view_t dK, ampconv_view_t dV,
+                                    const void *hub_plan, int64_t hub_chunks, void *hub_ws,
+                                    const float *stats, float *out_absmax, int dtype, void *stream) {
+  if (out_absmax && dtype != AMPCONV_F32) return AMPCONV_E_DTYPE;
+  bool recorded = false;
+  const int rc = bwd_src_dispatch(Q, K, V, dObar, cscptr, crow, cinv, n_src, L, D, H, dK, dV, hub_plan, hub_chunks, hub_ws,
+                                  stats, out_absmax, &recorded, dtype, stream);
+  if (rc != AMPCONV_OK || !out_absmax || recorded || n_src == 0) return rc;
+  if (int rc2 = view_absmax(dK, n_src, L, D, H, out_absmax, stream)) return rc2;
+  return view_absmax(dV, n_src, L, D, H, out_absmax, stream);
 }

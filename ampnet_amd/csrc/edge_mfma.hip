@@ -248,6 +248,18 @@ __device__ unsigned long long g_stamp_sums[8 * 4096];
 #define STAMP_FLUSH(unit)
 #endif
 
+#ifdef AMPCONV_NO_ABSMAX      // A/B build without the out_absmax code (register pressure of the backward kernels)
+constexpr bool kRecordAbsmax = false;
+#else
+constexpr bool kRecordAbsmax = true;
+#endif
+struct BwdArgs;
+// BwdArgs::absmax, read from the kernel-argument segment where it is used (the kernel's epilogue) instead of being held
+// in scalar registers through the edge loop.  Only the DESTINATION pass records: the source pass sits exactly at its 168
+// registers (three waves per SIMD), the same code there spills two loop-invariant LDS addresses whose reloads carry a
+// `vmcnt(0)` -- draining the prefetched tiles twice per edge, +4.5 % on the dominant kernel -- so the C entry point runs a
+// pass over dK | dV instead (edge_api.hip)
+__device__ __forceinline__ float *late_absmax_arg();
 struct BwdArgs {
   ampconv_view_t Q, K, V, dO, dQ, dK, dV;
   HubArgs hub;
@@ -260,7 +272,16 @@ struct BwdArgs {
   int L, H;
   float qscale;            // log2(e) / sqrt(dh)
   float oscale;            // 1 / sqrt(dh) (dst pass) or ln 2 (src pass): final factor of dQ / dK
+  float *absmax;           // dst pass: nullptr, or the running maximum of the finite magnitudes written to dQ
 };
+
+__device__ __forceinline__ float *late_absmax_arg() {
+  const char __attribute__((address_space(4))) *ka =
+      (const char __attribute__((address_space(4))) *)__builtin_amdgcn_kernarg_segment_ptr();
+  float *p;
+  asm volatile("s_load_dwordx2 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=s"(p) : "s"(ka), "n"(offsetof(BwdArgs, absmax)));
+  return p;
+}
 
 // ---- backward, destination pass: dQ[r], one wave per (destination, head).
 //   S^T = K Q^T, P^T = softmax;  dP^T = V dO^T;  delta = colsum(P^T o dP^T);
@@ -386,6 +407,7 @@ __global__ LB_DST void bwd_dst_mfma(BwdArgs a) {
   }
 
   float *ob = tile_ptr<float>(a.dQ, onode, h);
+  float wmax = 0.f;          // largest finite magnitude this lane stores (recorded at the end if the caller asked)
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
     const int i = (lane & 15) + 16 * nt;
@@ -395,9 +417,14 @@ __global__ LB_DST void bwd_dst_mfma(BwdArgs a) {
         float4 o = make_float4(dQT[mc][nt][0] * oscale, dQT[mc][nt][1] * oscale,
                                dQT[mc][nt][2] * oscale, dQT[mc][nt][3] * oscale);
         *reinterpret_cast<float4 *>(ob + (int64_t)i * a.dQ.row_stride + 4 * g + 16 * mc) = o;
+        if (kRecordAbsmax) wmax = finite_abs_max(wmax, o);
       }
     }
   }
+  if (kRecordAbsmax) {
+    float *const amax_p = late_absmax_arg();
+    if (amax_p) wave_record_absmax(amax_p, wmax);
+  }      // (partial-tile passes get no pointer: the combine pass records)
 }
 
 // ---- backward, source pass: dK[s], dV[s], one wave per (source, head) over the CSC.
@@ -1624,6 +1651,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? AMPCONV_DST_WAVES :
 #undef AMPCONV_IDS
 
   float *ob = tile_ptr<float>(a.dQ, onode, h);
+  float wmax = 0.f;          // largest finite magnitude this lane stores (recorded at the end if the caller asked)
 #pragma unroll
   for (int nt = 0; nt < NTM; ++nt) {
     const int i = n + 16 * nt;
@@ -1633,6 +1661,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? AMPCONV_DST_WAVES :
         float4 o = make_float4(dQT[mc][nt][0] * oscale, dQT[mc][nt][1] * oscale,
                                dQT[mc][nt][2] * oscale, dQT[mc][nt][3] * oscale);
         *reinterpret_cast<float4 *>(ob + (int64_t)i * a.dQ.row_stride + 4 * g + 16 * mc) = o;
+        if (kRecordAbsmax) wmax = finite_abs_max(wmax, o);
       }
     }
   }
@@ -1643,9 +1672,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, DH == 32 ? AMPCONV_DST_WAVES :
       float4 o;
       o.x = quads_sum(dQ4[hf][0]) * oscale; o.y = quads_sum(dQ4[hf][1]) * oscale;
       o.z = quads_sum(dQ4[hf][2]) * oscale; o.w = quads_sum(dQ4[hf][3]) * oscale;
-      if (sg == 0 && 16 + jt < L)
+      if (sg == 0 && 16 + jt < L) {
         *reinterpret_cast<float4 *>(ob + (int64_t)(16 + jt) * a.dQ.row_stride + 16 * hf + 4 * g) = o;
+        if (kRecordAbsmax) wmax = finite_abs_max(wmax, o);
+      }
     }
+  }
+  if (kRecordAbsmax) {
+    float *const amax_p = late_absmax_arg();
+    if (amax_p) wave_record_absmax(amax_p, wmax);
   }
 }
 
@@ -1722,7 +1757,7 @@ int ampconv_bwd_edge_dst_mfma(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t
   const int dh = D / H;
   BwdArgs a{};
   a.hub = hub;
-  a.spos = st.spos; a.stats = st.stats;
+  a.spos = st.spos; a.stats = st.stats; a.absmax = st.absmax;
   a.Q = Q; a.K = K; a.V = V; a.dO = dO; a.dQ = dQ;
   a.ptr = rowptr; a.idx = col; a.cinv = nullptr;
   a.n_units = n_rows * H; a.L = L; a.H = H;
@@ -1770,7 +1805,7 @@ int ampconv_bwd_edge_src_mfma(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t
   const int dh = D / H;
   BwdArgs a{};
   a.hub = hub;
-  a.stats = st.stats;
+  a.stats = st.stats; a.absmax = st.absmax;
   a.Q = Q; a.K = K; a.V = V; a.dO = dO; a.dK = dK; a.dV = dV;
   a.ptr = cscptr; a.idx = crow; a.cinv = cinv;
   a.n_units = n_src * H; a.L = L; a.H = H;

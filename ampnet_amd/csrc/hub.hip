@@ -43,7 +43,7 @@ template <int VEC>
 __global__ __launch_bounds__(256) void hub_combine_kernel(const HubDesc *__restrict__ descs, const float *__restrict__ P,
                                                           ampconv_view_t out, const int32_t *__restrict__ ptr, int L,
                                                           int D, int dh, float scale, int out_bf16,
-                                                          const int32_t *__restrict__ header) {
+                                                          const int32_t *__restrict__ header, float *absmax) {
   if ((int)blockIdx.x >= header[2]) return;          // the grid is sized for the most rows n_chunks can hold
   const int64_t c = header[header[3] + blockIdx.x];
   const HubDesc d = descs[c];
@@ -100,6 +100,12 @@ __global__ __launch_bounds__(256) void hub_combine_kernel(const HubDesc *__restr
   } else {
     reinterpret_cast<float *>(out.ptr)[off] = r[0];
   }
+  if (absmax) {            // (lanes of phase 0 that hold elements; the others left above)
+    float m = 0.f;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) m = fmaxf(m, finite_abs(r[v]));
+    if (m > __builtin_nontemporal_load(absmax)) atomicMax(reinterpret_cast<unsigned *>(absmax), __builtin_bit_cast(unsigned, m));
+  }
 }
 
 }  // namespace
@@ -132,7 +138,7 @@ extern "C" size_t ampconv_hub_workspace_bytes(int64_t n_chunks, int L, int D, in
 
 int ampconv_hub_combine(const void *plan, int64_t n_chunks, const float *P, ampconv_view_t out,
                         const int32_t *ptr_for_mean, int L, int D, int H, float scale, int out_bf16,
-                        hipStream_t stream) {
+                        hipStream_t stream, float *absmax) {
   if (n_chunks <= 0) return AMPCONV_OK;
   const HubDesc *descs = (const HubDesc *)((const int32_t *)plan + 4);
   const int dh = D / H;
@@ -145,10 +151,10 @@ int ampconv_hub_combine(const void *plan, int64_t n_chunks, const float *P, ampc
   const unsigned max_rows = (unsigned)(n_chunks / 2 + 1);      // a long row has at least two chunks
   if (vec4) {
     const dim3 grid(max_rows, (unsigned)((LD + 255) / 256));
-    hub_combine_kernel<4><<<grid, 256, 0, stream>>>(descs, P, out, ptr_for_mean, L, D, dh, scale, out_bf16, header);
+    hub_combine_kernel<4><<<grid, 256, 0, stream>>>(descs, P, out, ptr_for_mean, L, D, dh, scale, out_bf16, header, absmax);
   } else {
     const dim3 grid(max_rows, (unsigned)((LD + 63) / 64));
-    hub_combine_kernel<1><<<grid, 256, 0, stream>>>(descs, P, out, ptr_for_mean, L, D, dh, scale, out_bf16, header);
+    hub_combine_kernel<1><<<grid, 256, 0, stream>>>(descs, P, out, ptr_for_mean, L, D, dh, scale, out_bf16, header, absmax);
   }
   return ampconv_launch_status();
 }

@@ -142,10 +142,6 @@ __host__ __device__ inline size_t image_half_offset(int N, int K) {
 __host__ __device__ inline size_t image_amax_offset(int N, int K) {
   return (size_t)((N + 127) / 128 * 128) * (size_t)((K + 31) / 32 * 32) * 10;
 }
-__device__ __forceinline__ float finite_abs(float x) {          // |x|, or 0 for NaN / infinity
-  const float a = __builtin_fabsf(x);
-  return a < __builtin_inff() ? a : 0.f;
-}
 // 64 workgroups per weight, each the largest finite magnitude of its share, read in memory order; no atomics (nothing to
 // zero first): the partial maxima go to the image's trailer [64 floats], weight_image_kernel folds them ([64] = the result)
 constexpr int kAmaxParts = 64;
@@ -432,7 +428,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void proj_rows_kernel(RowsArgs a) 
       float f = 1.f;
       if (a.rowptr) {
         const int64_t m = cur.row0 + t < a.M ? cur.row0 + t : a.M - 1;
-        const int64_t node = m / a.L;
+        const unsigned node = (unsigned)m / (unsigned)a.L;        // (M < 2^31 with a mask: host check)
         f = a.rowptr[node + 1] != a.rowptr[node] ? 1.f : 0.f;
       }
       flags[par * BM + t] = f;
@@ -647,7 +643,10 @@ __global__ __launch_bounds__(64 * WI * WJ, 2) void proj_wgrad_kernel(WgradArgs a
       else xa[set][i] = make_float4(0.f, 0.f, 0.f, 0.f);
       float f = m < m1 ? 1.f : 0.f;
       if (MASK) {
-        const int64_t node = mc / a.L;
+        // 32-bit division (M < 2^31 with a mask: host check).  The 64-bit one expands to ~140 instructions in divergent
+        // control flow per row and stage, and with two stages of rows in flight that build gave WRONG sums now and
+        // then (7 % of the launches of the 128 x 128 shape: tests/test_gpu_proj.py::test_proj_wgrad_masked_is_reproducible)
+        const unsigned node = (unsigned)mc / (unsigned)a.L;
         f = a.rowptr[node + 1] != a.rowptr[node] ? f : 0.f;
       }
       fa[set][i] = f;
@@ -886,7 +885,7 @@ extern "C" int ampconv_proj_rows(const void *A_, int64_t lda, int64_t M, int K, 
   if (M < 0 || !supported_f32(N, K) || lda < K || ldc < N || lda % 4) return AMPCONV_E_BADARG;
   if (M == 0) return AMPCONV_OK;
   if (!A || !wimage || !out || (uintptr_t)A % 16 || (uintptr_t)wimage % 16) return AMPCONV_E_BADARG;
-  if (rowptr && L <= 0) return AMPCONV_E_BADARG;
+  if (rowptr && (L <= 0 || M > 0x7fffffff)) return AMPCONV_E_BADARG;
   if (ldc % 4 || (uintptr_t)out % 16) return AMPCONV_E_BADARG;
   // tile shape (developer switch AMPCONV_PROJ_ROWS: 0 = 128 x 256 tile of 4 waves where N allows, 1 = 256 x 256 of 8)
   static const int variant = [] {
@@ -1010,7 +1009,7 @@ extern "C" int ampconv_proj_wgrad(const void *A_, int64_t lda, const void *B_, i
   if (M < 0 || Na <= 0 || Nb <= 0 || Na % 4 || Nb % 4 || lda < Na || ldb < Nb || lda % 4 || ldb % 4)
     return AMPCONV_E_BADARG;
   if (!dW || (uintptr_t)dW % 16 || (colsum && (uintptr_t)colsum % 16)) return AMPCONV_E_BADARG;
-  if (rowptr && L <= 0) return AMPCONV_E_BADARG;
+  if (rowptr && (L <= 0 || M > 0x7fffffff)) return AMPCONV_E_BADARG;       // (rows of a masked product are addressed as int32)
   hipStream_t st = (hipStream_t)stream;
   if (M == 0) {
     hipError_t e = hipMemsetAsync(dW, 0, sizeof(float) * (size_t)Na * Nb, st);

@@ -186,13 +186,13 @@ class _PartitionedFunction(torch.autograd.Function):
                 spos = csr.csc_positions()
             plan, nch, ws = csr.hub_args('dst', L, D, 1)
             rc = lib.ampconv_bwd_edge_dst(Qv, Kv, Vv, dOv, csr.rowptr.data_ptr(), csr.col.data_ptr(), nl, L, D, H,
-                                          dQv, plan, nch, F_._ptr(ws), F_._ptr(spos), F_._ptr(stats), ctx.dtype,
-                                          _stream())
+                                          dQv, plan, nch, F_._ptr(ws), F_._ptr(spos), F_._ptr(stats), None,
+                                          ctx.dtype, _stream())
             _lib.check(rc, 'ampconv_bwd_edge_dst')
             plan, nch, ws = csr.hub_args('src', L, D, 2)
             rc = lib.ampconv_bwd_edge_src(Qv, Kv, Vv, dOv, csr.cscptr.data_ptr(), csr.crow.data_ptr(),
                                           csr.cinv.data_ptr(), NP, L, D, H, dKv, dVv, plan, nch, F_._ptr(ws),
-                                          F_._ptr(stats), ctx.dtype, _stream())
+                                          F_._ptr(stats), None, ctx.dtype, _stream())
             _lib.check(rc, 'ampconv_bwd_edge_src')
             del dobar, stats
             # this rank's rows of dK|dV, summed over ranks: in flight while the Q-side products run

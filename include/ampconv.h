@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define AMPCONV_VERSION 104
+#define AMPCONV_VERSION 105
 
 enum {
   AMPCONV_OK = 0,
@@ -157,20 +157,27 @@ int ampconv_fwd_edge(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
  * `stats` (ampconv_softmax_stats_bytes(E, ...) bytes, 16-byte aligned; 0 = this dtype/shape keeps
  * none and `stats` must be NULL) the destination pass stores them at the edge's CSC position
  * (`spos`, ampconv_csc_positions) as 20 log2-sum-exp + 20 delta floats per (edge, head), and the
- * source pass -- which must then run AFTER the destination pass -- reads them back sequentially.  */
+ * source pass -- which must then run AFTER the destination pass -- reads them back sequentially.
+ * `out_absmax` (may be NULL; AMPCONV_F32 only): a device float that receives, by atomic max, the largest finite
+ * magnitude of what the pass writes to dQ (dK and dV) -- the scale source of the projections that consume the
+ * gradient (SCALED MODE below); the caller zeroes it, both passes may share one.  The destination pass's tile kernels
+ * record it as they store (one compare per wave); the source pass and the other kernel families get it from one
+ * ampconv_absmax pass over the output, run by the entry point -- the output must then be a plain row-major matrix (rows
+ * of D channels, a node's L rows consecutive).  */
 size_t ampconv_softmax_stats_bytes(int64_t E, int L, int D, int H, int dtype);
 int ampconv_bwd_edge_dst(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
                          ampconv_view_t dObar, const int32_t *rowptr,
                          const int32_t *col, int64_t n_rows, int L, int D, int H,
                          ampconv_view_t dQ, const void *hub_plan, int64_t hub_chunks,
-                         void *hub_ws, const int32_t *spos, float *stats, int dtype,
-                         void *stream);
+                         void *hub_ws, const int32_t *spos, float *stats, float *out_absmax,
+                         int dtype, void *stream);
 int ampconv_bwd_edge_src(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
                          ampconv_view_t dObar, const int32_t *cscptr,
                          const int32_t *crow, const float *cinv,
                          int64_t n_src, int L, int D, int H, ampconv_view_t dK,
                          ampconv_view_t dV, const void *hub_plan, int64_t hub_chunks,
-                         void *hub_ws, const float *stats, int dtype, void *stream);
+                         void *hub_ws, const float *stats, float *out_absmax, int dtype,
+                         void *stream);
 
 /* ---- per-edge side outputs, ORIGINAL edge order ------------------------------
  * attn_weights: W[e] = mean_h softmax_rows(Q[dst e,:,h] K[src e,:,h]^T/sqrt(dh)),

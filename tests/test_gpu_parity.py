@@ -800,6 +800,55 @@ def test_message_aggregate_gradients_scaled_projections(dev, monkeypatch):
     test_message_matches_per_edge_reference(dev)
 
 
+@pytest.mark.parametrize('shape', [(600, 9000, 20, 256, 8), (500, 6000, 20, 64, 4), (400, 5000, 13, 64, 2), (300, 3000, 40, 100, 2),
+                                   (300, 2500, 2, 128, 8), (200, 2000, 5, 12, 4)],
+                         ids=['t4_dh32', 't4_dh16', 'mfma_L13', 'block_L40_dh50', 'small_L2', 'generic_dh3'])
+def test_backward_passes_record_the_maximum_of_what_they_write(shape, dev, monkeypatch):
+    """`out_absmax` of ampconv_bwd_edge_dst / _src (include/ampconv.h): every kernel family, with long segments (the
+    combine pass writes those rows), equals max |dQKV| exactly; the scale source of the fp32 projections' scaled mode."""
+    from ampnet_amd import EdgeCSR, _lib
+    from ampnet_amd.conv import functional as F_
+    monkeypatch.setattr(_lib, 'HUB_CHUNK', 64)
+    N, E, L, D, H = shape
+    dh = D // H
+    lib = _lib.load()
+    g = torch.Generator(device=dev).manual_seed(E)
+    ei = torch.randint(0, N, (2, E), device=dev, generator=g)
+    ei[1, : E // 8] = 3                  # long segments on both sides
+    ei[0, E // 8: E // 4] = 5
+    csr = EdgeCSR(ei, N)
+    qkv = torch.randn(N * L, 3 * D, device=dev, generator=g)
+    dobar = torch.randn(N * L, D, device=dev, generator=g) * 1e-3
+    dqkv = torch.full((N * L, 3 * D), float('nan'), device=dev)
+    Qv, Kv, Vv = (F_._view(qkv, i * D, L, dh) for i in range(3))
+    dQv, dKv, dVv = (F_._view(dqkv, i * D, L, dh) for i in range(3))
+    dOv = F_._view(dobar, 0, L, dh)
+    nstat = lib.ampconv_softmax_stats_bytes(E, L, D, H, _lib.AMPCONV_F32)
+    stats = torch.empty(max(nstat, 4) // 4, device=dev) if nstat else None
+    spos = csr.csc_positions() if nstat else None
+    am = torch.zeros(2, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    plan, nch, ws = csr.hub_args('dst', L, D, 1)
+    assert nch > 0
+    _lib.check(lib.ampconv_bwd_edge_dst(Qv, Kv, Vv, dOv, csr.rowptr.data_ptr(), csr.col.data_ptr(), N, L, D, H, dQv, plan,
+                                        nch, F_._ptr(ws), F_._ptr(spos), F_._ptr(stats), am[0:1].data_ptr(),
+                                        _lib.AMPCONV_F32, st), 'dst')
+    plan, nch, ws = csr.hub_args('src', L, D, 2)
+    _lib.check(lib.ampconv_bwd_edge_src(Qv, Kv, Vv, dOv, csr.cscptr.data_ptr(), csr.crow.data_ptr(), csr.cinv.data_ptr(),
+                                        N, L, D, H, dKv, dVv, plan, nch, F_._ptr(ws), F_._ptr(stats), am[1:2].data_ptr(),
+                                        _lib.AMPCONV_F32, st), 'src')
+    assert torch.isfinite(dqkv).all()
+    assert float(am[0]) == float(dqkv[:, :D].abs().max()) > 0
+    assert float(am[1]) == float(dqkv[:, D:].abs().max()) > 0
+    # bf16 storage takes no maximum
+    hq = qkv.bfloat16()
+    hv = [F_._view(hq, i * D, L, dh) for i in range(3)]
+    rc = lib.ampconv_bwd_edge_dst(*hv, F_._view(dobar.bfloat16(), 0, L, dh), csr.rowptr.data_ptr(), csr.col.data_ptr(), N, L,
+                                  D, H, F_._view(dqkv.bfloat16(), 0, L, dh), None, 0, None, None, None, am[0:1].data_ptr(),
+                                  _lib.AMPCONV_BF16, st)
+    assert rc == -2
+
+
 def test_retain_attention_auto(dev, monkeypatch):
     """Default 'auto': small graphs keep what the lazy per-edge attributes need, large projection buffers are
     dropped and reading the attributes says so instead of pinning them (61 GB at config 4)."""

@@ -83,7 +83,9 @@ def test_proj_rows_mask_gives_exact_zero_rows(L, empty):
 
 
 @pytest.mark.parametrize('M,Na,Nb', [(37, 128, 128), (20 * 271, 384, 128), (5000, 768, 256), (70001, 256, 256),
-                                     (40 * 77, 300, 100), (4000, 100, 100), (999, 192, 64), (61, 24, 8), (20 * 40, 200, 100)])
+                                     (40 * 77, 300, 100), (4000, 100, 100), (999, 192, 64), (61, 24, 8), (20 * 40, 200, 100),
+                                     # several stages per row slice (the rows of two stages are in flight), with the mask
+                                     (20 * 3000, 128, 128), (20 * 9000, 256, 256), (20 * 5000, 384, 256)])
 @pytest.mark.parametrize('masked', [False, True])
 def test_proj_wgrad_matches_fp64(M, Na, Nb, masked):
     from ampnet_amd.conv import functional as F_
@@ -108,6 +110,36 @@ def test_proj_wgrad_matches_fp64(M, Na, Nb, masked):
     cs2 = torch.empty_like(cs)
     F_.proj_wgrad(a, b, dw2, cs2, rp, L)
     assert torch.equal(dw, dw2) and torch.equal(cs, cs2)            # fixed slices, ordered sum
+
+
+@pytest.mark.parametrize('Na,Nb', [(128, 128), (384, 128), (256, 256)])
+@pytest.mark.parametrize('scaled', [False, True])
+def test_proj_wgrad_masked_is_reproducible(Na, Nb, scaled):
+    """300 launches of the masked weight-gradient product on the same inputs give the same bits (a build of round 4
+    -- 64-bit row / L division beside two stages of rows in flight -- was wrong in 7 % of the launches at 128 x 128)."""
+    from ampnet_amd.conv import functional as F_
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(Na + Nb)
+    M, L = 60000, 20
+    a = torch.randn(M, Na, device=dev, generator=g)
+    b = torch.randn(M, Nb, device=dev, generator=g)
+    deg = (torch.rand(M // L, device=dev, generator=g) < 0.8).int()
+    rp = torch.zeros(M // L + 1, dtype=torch.int32, device=dev)
+    rp[1:] = torch.cumsum(deg, 0)
+    amax = (F_.absmax(a), F_.absmax(b)) if scaled else None
+    flag = deg.bool().repeat_interleave(L)[:, None]
+    ref = (a.double() * flag).t() @ b.double()
+    dw0, cs0 = torch.empty(Na, Nb, device=dev), torch.empty(Na, device=dev)
+    F_.proj_wgrad(a, b, dw0, cs0, rp, L, amax=amax)
+    assert _err(dw0, ref) < 2e-6
+    bad = 0
+    for it in range(300):
+        dw, cs = torch.empty(Na, Nb, device=dev), torch.empty(Na, device=dev)
+        if it % 2:
+            torch.randn(1 << 18, device=dev, generator=g)          # something else on the stream in between
+        F_.proj_wgrad(a, b, dw, cs, rp, L, amax=amax)
+        bad += int(not (torch.equal(dw, dw0) and torch.equal(cs, cs0)))
+    assert bad == 0, f'{bad} of 300 launches differ'
 
 
 def test_proj_wgrad_into_row_block_views():
@@ -195,7 +227,8 @@ def test_proj_rows_scaled_wide_range_rows_and_nonfinite():
 
 
 @pytest.mark.parametrize('M,Na,Nb', [(37, 128, 128), (20 * 271, 384, 128), (5000, 768, 256), (70001, 256, 256),
-                                     (999, 100, 100), (20 * 40, 300, 100)])
+                                     (999, 100, 100), (20 * 40, 300, 100), (20 * 3000, 128, 128), (20 * 9000, 256, 256),
+                                     (20 * 5000, 384, 256)])
 @pytest.mark.parametrize('masked', [False, True])
 def test_proj_wgrad_scaled_matches_fp64(M, Na, Nb, masked):
     from ampnet_amd.conv import functional as F_

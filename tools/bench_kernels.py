@@ -1,6 +1,6 @@
 """Developer micro-benchmark: time each C-ABI edge kernel on a synthetic uniform graph.
 
-    python tools/bench_kernels.py [N E L D H] [--generic] [--bf16] [--hub] [--rmat] [--compact]
+    python tools/bench_kernels.py [N E L D H] [--generic] [--bf16] [--hub] [--rmat] [--compact] [--absmax]
 """
 import os
 import sys
@@ -111,15 +111,18 @@ def main():
     spos = csr.csc_positions() if nstat else None
     sp = (spos.data_ptr(), stats.data_ptr()) if nstat else (None, None)
     print('softmax stats:', f'{nstat / 1e9:.2f} GB' if nstat else 'off')
+    # --absmax: the backward passes record the maximum of what they write (fp32; include/ampconv.h out_absmax)
+    amax_t = torch.zeros(1, device=dev) if '--absmax' in sys.argv else None
+    amax = amax_t.data_ptr() if amax_t is not None else None
 
     def bwd_dst():
         _lib.check(lib.ampconv_bwd_edge_dst(Qv, Kv, Vv, dOv, csr.rowptr.data_ptr(), csr.col.data_ptr(),
-                                            N, L, D, H, dQv, *hub('dst', 1), *sp, dt, st), 'bwd_dst')
+                                            N, L, D, H, dQv, *hub('dst', 1), *sp, amax, dt, st), 'bwd_dst')
 
     def bwd_src():
         _lib.check(lib.ampconv_bwd_edge_src(Qv, Kv, Vv, dOv, csr.cscptr.data_ptr(), csr.crow.data_ptr(),
                                             csr.cinv.data_ptr(), N, L, D, H, dKv, dVv, *hub('src', 2), sp[1],
-                                            dt, st), 'bwd_src')
+                                            amax, dt, st), 'bwd_src')
 
     for name, fn, nbytes, flops in (
             ('fwd_edge', fwd, (2 * E + 2 * N) * R, 4 * L * L * D * E),

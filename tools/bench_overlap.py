@@ -46,10 +46,10 @@ def main():
     def edges():
         st = torch.cuda.current_stream().cuda_stream
         _lib.check(lib.ampconv_bwd_edge_dst(Qv, Kv, Vv, dOv, csr.rowptr.data_ptr(), csr.col.data_ptr(), N, L, D, H, dQv,
-                                            None, 0, None, spos.data_ptr(), stats.data_ptr(), 0, st), 'dst')
+                                            None, 0, None, spos.data_ptr(), stats.data_ptr(), None, 0, st), 'dst')
         _lib.check(lib.ampconv_bwd_edge_src(Qv, Kv, Vv, dOv, csr.cscptr.data_ptr(), csr.crow.data_ptr(),
-                                            csr.cinv.data_ptr(), N, L, D, H, dKv, dVv, None, 0, None, stats.data_ptr(), 0,
-                                            st), 'src')
+                                            csr.cinv.data_ptr(), N, L, D, H, dKv, dVv, None, 0, None, stats.data_ptr(), None,
+                                            0, st), 'src')
 
     native = '--native' in sys.argv                  # libampconv's own projection kernels (bf16 matrix cores)
     img = F_.proj_image(w) if native else None

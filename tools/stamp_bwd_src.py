@@ -20,10 +20,10 @@ if T4:
     stats = torch.empty(lib.ampconv_softmax_stats_bytes(E, L, D, H, 0) // 4, device=dev)
     spos = csr.csc_positions()
     _lib.check(lib.ampconv_bwd_edge_dst(Qv, Kv, Vv, dOv, csr.rowptr.data_ptr(), csr.col.data_ptr(), N, L, D, H, dQv,
-                                        None, 0, None, spos.data_ptr(), stats.data_ptr(), 0, st), 'dst')
+                                        None, 0, None, spos.data_ptr(), stats.data_ptr(), None, 0, st), 'dst')
 for _ in range(2):
     _lib.check(lib.ampconv_bwd_edge_src(Qv, Kv, Vv, dOv, csr.cscptr.data_ptr(), csr.crow.data_ptr(), csr.cinv.data_ptr(),
-                                        N, L, D, H, dKv, dVv, None, 0, None, stats.data_ptr() if T4 else None, 0 if T4 else 2, st), 'src')
+                                        N, L, D, H, dKv, dVv, None, 0, None, stats.data_ptr() if T4 else None, None, 0 if T4 else 2, st), 'src')
 torch.cuda.synchronize()
 raw = ctypes.CDLL(os.environ['AMPCONV_LIB_PATH'])
 buf = (ctypes.c_ulonglong * (8 * 4096))()
