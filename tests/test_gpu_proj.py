@@ -142,6 +142,38 @@ def test_proj_wgrad_masked_is_reproducible(Na, Nb, scaled):
     assert bad == 0, f'{bad} of 300 launches differ'
 
 
+@pytest.mark.parametrize('K,N', [(256, 768), (768, 256), (100, 300), (128, 128)])
+@pytest.mark.parametrize('scaled', [False, True])
+def test_proj_rows_is_reproducible(K, N, scaled):
+    """The row kernel streams its rows with inline-assembly loads and hand-counted waits (csrc/proj_gemm.hip): 200
+    launches on the same inputs, other work on the stream in between, give the same bits -- full tiles, ragged K / N
+    (embed_dim 100), with and without the mask, both plane modes."""
+    from ampnet_amd.conv import functional as F_
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(K + N)
+    L, n_nodes = 20, 2500
+    M = n_nodes * L
+    a = torch.randn(M, K, device=dev, generator=g)
+    W = torch.randn(N, K, device=dev, generator=g) * 0.1
+    bias = torch.randn(N, device=dev, generator=g)
+    deg = (torch.rand(n_nodes, device=dev, generator=g) < 0.8).int()
+    rp = torch.zeros(n_nodes + 1, dtype=torch.int32, device=dev)
+    rp[1:] = torch.cumsum(deg, 0)
+    img = F_.proj_image(W)
+    amax = F_.absmax(a) if scaled else None
+    ref = a.double() @ W.double().t() + bias.double()
+    for mask in (None, rp):
+        out0 = F_.proj_rows(a, img, bias, mask, L, amax=amax)
+        want = ref if mask is None else ref * deg.bool().repeat_interleave(L)[:, None]
+        assert _err(out0, want) < 2e-6
+        bad = 0
+        for it in range(200):
+            if it % 2:
+                torch.randn(1 << 18, device=dev, generator=g)
+            bad += int(not torch.equal(F_.proj_rows(a, img, bias, mask, L, amax=amax), out0))
+        assert bad == 0, f'{bad} of 200 launches differ (mask: {mask is not None})'
+
+
 def test_proj_wgrad_into_row_block_views():
     # the non-shared path writes d in_proj_weight in two row blocks of one tensor
     from ampnet_amd.conv import functional as F_
