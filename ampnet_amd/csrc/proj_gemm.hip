@@ -646,8 +646,17 @@ __global__ __launch_bounds__(64 * WI * WJ, 2) void proj_wgrad_kernel(WgradArgs a
         // 32-bit division (M < 2^31 with a mask: host check).  The 64-bit one expands to ~140 instructions in divergent
         // control flow per row and stage, and with two stages of rows in flight that build gave WRONG sums now and
         // then (7 % of the launches of the 128 x 128 shape: tests/test_gpu_proj.py::test_proj_wgrad_masked_is_reproducible)
+#ifdef AMPCONV_WG_DIV64        // developer builds that reproduce / bisect the race described above
+        const int64_t node = mc / a.L;
+#else
         const unsigned node = (unsigned)mc / (unsigned)a.L;
+#endif
+#ifdef AMPCONV_WG_SPLITRP
+        const int32_t rp0 = __builtin_nontemporal_load(a.rowptr + node), rp1 = __builtin_nontemporal_load(a.rowptr + node + 1);
+        f = rp1 != rp0 ? f : 0.f;
+#else
         f = a.rowptr[node + 1] != a.rowptr[node] ? f : 0.f;
+#endif
       }
       fa[set][i] = f;
     }
