@@ -551,8 +551,7 @@ struct WgradArgs {
   int64_t ldb;
   int64_t M;
   int Na, Nb;
-  const int32_t *rowptr;
-  int L;
+  const float *rowflag;       // MASK: 1.0 / 0.0 per row (node of the row has an in-edge), in the workspace behind the slabs
   float *part;                // [S][Nap * Nbp + Nap]
   int S;
   int64_t rows_per_slice;     // multiple of 16
@@ -643,20 +642,9 @@ __global__ __launch_bounds__(64 * WI * WJ, 2) void proj_wgrad_kernel(WgradArgs a
       else xa[set][i] = make_float4(0.f, 0.f, 0.f, 0.f);
       float f = m < m1 ? 1.f : 0.f;
       if (MASK) {
-        // 32-bit division (M < 2^31 with a mask: host check).  The 64-bit one expands to ~140 instructions in divergent
-        // control flow per row and stage, and with two stages of rows in flight that build gave WRONG sums now and
-        // then (7 % of the launches of the 128 x 128 shape: tests/test_gpu_proj.py::test_proj_wgrad_masked_is_reproducible)
-#ifdef AMPCONV_WG_DIV64        // developer builds that reproduce / bisect the race described above
-        const int64_t node = mc / a.L;
-#else
-        const unsigned node = (unsigned)mc / (unsigned)a.L;
-#endif
-#ifdef AMPCONV_WG_SPLITRP
-        const int32_t rp0 = __builtin_nontemporal_load(a.rowptr + node), rp1 = __builtin_nontemporal_load(a.rowptr + node + 1);
-        f = rp1 != rp0 ? f : 0.f;
-#else
-        f = a.rowptr[node + 1] != a.rowptr[node] ? f : 0.f;
-#endif
+        // one flag per row, written by row_mask_kernel before this launch (the lanes of a row read one address; until the
+        // end of round 4 every thread derived it here: row / L in 64 bits, two CSR bounds -- 280 instructions per stage)
+        f *= a.rowflag[mc];
       }
       fa[set][i] = f;
     }
@@ -709,6 +697,9 @@ __global__ __launch_bounds__(64 * WI * WJ, 2) void proj_wgrad_kernel(WgradArgs a
 #pragma unroll
     for (int i = 0; i < NIW; i += 2) {
       i32x4 af[2][3];
+#ifndef AMPCONV_WG_NOFENCE      // (the next round's reads are not hoisted into this round's MFMAs either)
+      __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
       for (int ii = 0; ii < 2; ++ii) {
         const int it = NIW * wi + i + ii;
@@ -716,6 +707,17 @@ __global__ __launch_bounds__(64 * WI * WJ, 2) void proj_wgrad_kernel(WgradArgs a
 #pragma unroll
         for (int p = 0; p < kNP; ++p) af[ii][p] = tr_frag(r0 + p * kPlaneA, r0 + p * kPlaneA + 4 * kRowA);
       }
+      // Every fragment of the round is in its registers before the round's first MFMA issues, and no fragment read is
+      // scheduled in among the MFMAs.  Left to itself hipcc interleaves them and re-uses an operand register for the next
+      // fragment right behind the MFMA that reads it (`v_mfma .. v[128:131] ..; ds_read_b64_tr_b16 v[128:129] ..;
+      // s_waitcnt lgkmcnt(0); v_mfma .. v[128:131]`); builds with that schedule gave WRONG sums in 7-100 % of the launches
+      // of the masked product (one 16-bit element of a fragment stale; flags, rows and the LDS image verified correct
+      // at the barrier by an in-kernel dump: DESIGN.md 4a), with this fence 0 of 1 600.  -DAMPCONV_WG_NOFENCE rebuilds it.
+#ifndef AMPCONV_WG_NOFENCE
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 7\n\ts_nop 7" ::: "memory");      // (+ 16 idle cycles behind the wait)
+      __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
       for (int q = 0; q < Pl<HP>::NQ; ++q)
 #pragma unroll
@@ -756,6 +758,16 @@ __global__ __launch_bounds__(64 * WI * WJ, 2) void proj_wgrad_kernel(WgradArgs a
       *reinterpret_cast<float4 *>(part + (size_t)a.Nap * a.Nbp + ti * TI + 4 * t) = sum;
     }
   }
+}
+
+// flag[m] = 1.0 if the node of row m has an in-edge, else 0.0 (one thread per NODE: no division)
+__global__ __launch_bounds__(256) void row_mask_kernel(const int32_t *__restrict__ rowptr, int L, int64_t n_nodes,
+                                                       int64_t M, float *__restrict__ flag) {
+  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (n >= n_nodes) return;
+  const float f = rowptr[n + 1] != rowptr[n] ? 1.f : 0.f;
+  const int64_t m0 = n * L;
+  for (int l = 0; l < L && m0 + l < M; ++l) flag[m0 + l] = f;
 }
 
 // out[e] = sum over the slices of part[s][e]; e < n_dw goes to dW, the rest to colsum.  256 threads = 32 float4
@@ -999,7 +1011,8 @@ extern "C" size_t ampconv_proj_wgrad_workspace_bytes(int64_t M, int Na, int Nb, 
   if (dtype != AMPCONV_F32 || M < 0 || Na <= 0 || Nb <= 0 || Na % 4 || Nb % 4) return 0;
   const int Nap = (Na + 127) / 128 * 128, Nbp = (Nb + 127) / 128 * 128;
   const WgradPlan p = wgrad_plan(M, Nap, Nbp);
-  return (size_t)p.S * ((size_t)Nap * Nbp + Nap) * sizeof(float);
+  // [S partial slabs][one flag per row: used with a mask]
+  return (size_t)p.S * ((size_t)Nap * Nbp + Nap) * sizeof(float) + ((size_t)M + 3) / 4 * 16;
 }
 
 extern "C" int ampconv_proj_wgrad(const void *A_, int64_t lda, const void *B_, int64_t ldb, int64_t M, int Na,
@@ -1031,8 +1044,14 @@ extern "C" int ampconv_proj_wgrad(const void *A_, int64_t lda, const void *B_, i
   const bool ragged = Nap != Na || Nbp != Nb;
   const WgradPlan p = wgrad_plan(M, Nap, Nbp);
   const size_t n_all = (size_t)Nap * Nbp + Nap;
-  if (workspace_bytes < (size_t)p.S * n_all * sizeof(float)) return AMPCONV_E_WORKSPACE;
-  WgradArgs a{A, lda, B, ldb, M, Na, Nb, rowptr, L, (float *)workspace, p.S, p.rows_per_slice, Nap, Nbp, a_absmax,
+  const size_t slab_bytes = (size_t)p.S * n_all * sizeof(float);
+  if (workspace_bytes < slab_bytes + (rowptr ? ((size_t)M + 3) / 4 * 16 : 0)) return AMPCONV_E_WORKSPACE;
+  float *rowflag = rowptr ? (float *)((char *)workspace + slab_bytes) : nullptr;
+  if (rowptr) {
+    const int64_t n_nodes = (M + L - 1) / L;
+    row_mask_kernel<<<(unsigned)((n_nodes + 255) / 256), 256, 0, st>>>(rowptr, L, n_nodes, M, rowflag);
+  }
+  WgradArgs a{A, lda, B, ldb, M, Na, Nb, rowflag, (float *)workspace, p.S, p.rows_per_slice, Nap, Nbp, a_absmax,
               b_absmax};
   const bool hp = a_absmax != nullptr;
   const int ntiles = (Nap / p.ti) * (Nbp / p.tj);

@@ -549,10 +549,16 @@ __global__ __launch_bounds__(T == 256 ? 512 : 256, 2) void proj_wgrad_bf16_kerne
         const char *r0 = buf + so + ((rd + ((it >> 2) << 8)) ^ ((it & 3) << 6));
         af[i] = tr_frag(r0, r0 + 4 * kRow);
       }
+      // every transposed fragment of the half stage is in its registers before the first MFMA issues, and none is read in
+      // among the MFMAs (csrc/proj_gemm.hip, proj_wgrad_kernel: the schedule hipcc picks by itself gave wrong sums there)
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_nop 7\n\ts_nop 7" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < NIW; ++i)
 #pragma unroll
         for (int j = 0; j < NJW; ++j) acc[i][j] = MFMA32(af[i], bf[j], acc[i][j]);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (do_cs) {
       const char *fl = smem + oFl + (s & (NBUF - 1)) * kMeta;

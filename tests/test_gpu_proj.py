@@ -115,8 +115,9 @@ def test_proj_wgrad_matches_fp64(M, Na, Nb, masked):
 @pytest.mark.parametrize('Na,Nb', [(128, 128), (384, 128), (256, 256)])
 @pytest.mark.parametrize('scaled', [False, True])
 def test_proj_wgrad_masked_is_reproducible(Na, Nb, scaled):
-    """300 launches of the masked weight-gradient product on the same inputs give the same bits (a build of round 4
-    -- 64-bit row / L division beside two stages of rows in flight -- was wrong in 7 % of the launches at 128 x 128)."""
+    """300 launches of the masked weight-gradient product on the same inputs give the same bits (builds of round 4 with
+    two stages of rows in flight and the compiler's own interleaving of transposed fragment reads and MFMAs were wrong in
+    7-100 % of the launches at 128 x 128: DESIGN.md 4a; the kernel now fences the reads)."""
     from ampnet_amd.conv import functional as F_
     dev = _dev()
     g = torch.Generator(device=dev).manual_seed(Na + Nb)
@@ -419,6 +420,33 @@ def test_proj_wgrad_bf16_masked_rows_do_not_leak_into_the_column_sums():
     flag = has.to(dev).repeat_interleave(L)[:, None]
     ref = torch.where(flag, a.double(), torch.zeros((), dtype=torch.float64, device=dev)).sum(0)
     assert float((cs.double() - ref).abs().max()) <= 2.0 ** -8 * float(ref.abs().max()) + 1e-4
+
+
+@pytest.mark.parametrize('Na,Nb', [(128, 128), (768, 256)])
+def test_proj_wgrad_bf16_is_reproducible(Na, Nb):
+    """The bf16 weight-gradient product reads its operands with the same transposing LDS instruction as the fp32 one
+    (whose compiler-chosen schedule was racy: DESIGN.md 4a) and carries the same fence: 200 launches, same bits."""
+    from ampnet_amd.conv import functional as F_
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(Na)
+    M, L = 60000, 20
+    a = torch.randn(M, Na, device=dev, generator=g).bfloat16()
+    b = torch.randn(M, Nb, device=dev, generator=g).bfloat16()
+    deg = (torch.rand(M // L, device=dev, generator=g) < 0.8).int()
+    rp = torch.zeros(M // L + 1, dtype=torch.int32, device=dev)
+    rp[1:] = torch.cumsum(deg, 0)
+    for mask in (rp, None):
+        dw0 = torch.empty(Na, Nb, device=dev, dtype=torch.bfloat16)
+        cs0 = torch.empty(Na, device=dev, dtype=torch.bfloat16)
+        F_.proj_wgrad(a, b, dw0, cs0, mask, L)
+        bad = 0
+        for it in range(200):
+            dw, cs = torch.empty_like(dw0), torch.empty_like(cs0)
+            if it % 2:
+                torch.randn(1 << 18, device=dev, generator=g)
+            F_.proj_wgrad(a, b, dw, cs, mask, L)
+            bad += int(not (torch.equal(dw, dw0) and torch.equal(cs, cs0)))
+        assert bad == 0, f'{bad} of 200 launches differ'
 
 
 def test_proj_wgrad_bf16_into_row_block_views():
