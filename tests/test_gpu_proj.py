@@ -422,6 +422,35 @@ def test_proj_wgrad_bf16_masked_rows_do_not_leak_into_the_column_sums():
     assert float((cs.double() - ref).abs().max()) <= 2.0 ** -8 * float(ref.abs().max()) + 1e-4
 
 
+@pytest.mark.parametrize('K,N', [(256, 768), (768, 256), (72, 40)])
+def test_proj_rows_bf16_is_reproducible(K, N):
+    """The all-DMA bf16 row kernel (hand-counted waits throughout): 200 launches, same bits -- plain, masked, node list."""
+    from ampnet_amd.conv import functional as F_
+    dev = _dev()
+    g = torch.Generator(device=dev).manual_seed(K + N)
+    L, n_nodes = 20, 2500
+    a = torch.randn(n_nodes * L, K, device=dev, generator=g).bfloat16()
+    W = (torch.randn(N, K, device=dev, generator=g) * 0.1).bfloat16()
+    bias = torch.randn(N, device=dev, generator=g).bfloat16()
+    deg = (torch.rand(n_nodes, device=dev, generator=g) < 0.6).int()
+    rp = torch.zeros(n_nodes + 1, dtype=torch.int32, device=dev)
+    rp[1:] = torch.cumsum(deg, 0)
+    ids = torch.cat([deg.nonzero().flatten().int(), torch.zeros(8, dtype=torch.int32, device=dev)])
+    cnt = int(deg.sum())
+    img = F_.proj_image(W)
+    for kw in (dict(), dict(rowptr=rp), dict(nodes=(ids, cnt))):
+        out0 = torch.zeros(n_nodes * L, N, device=dev, dtype=torch.bfloat16)
+        F_.proj_rows(a, img, bias, L=L, out=out0, **kw)
+        bad = 0
+        for it in range(200):
+            out = torch.zeros_like(out0)
+            if it % 2:
+                torch.randn(1 << 18, device=dev, generator=g)
+            F_.proj_rows(a, img, bias, L=L, out=out, **kw)
+            bad += int(not torch.equal(out, out0))
+        assert bad == 0, f'{bad} of 200 launches differ ({list(kw)})'
+
+
 @pytest.mark.parametrize('Na,Nb', [(128, 128), (768, 256)])
 def test_proj_wgrad_bf16_is_reproducible(Na, Nb):
     """The bf16 weight-gradient product reads its operands with the same transposing LDS instruction as the fp32 one
