@@ -118,6 +118,21 @@ __device__ __forceinline__ i32x4 colfrag(const char *tile, int mc, int lane) {
   const i32x2 ai = __builtin_bit_cast(i32x2, a), bi = __builtin_bit_cast(i32x2, b);
   return i32x4{ai[0], ai[1], bi[0], bi[1]};
 }
+// Every transposed fragment of a product group is in its registers before the group's first MFMA issues, and no
+// transposed read is scheduled in among the MFMAs: the interleaved schedule hipcc picks by itself -- an MFMA's operand
+// register redefined by the next ds_read_b64_tr_b16 right behind it, consumed right behind the wait -- gave wrong sums in
+// the weight-gradient kernel (csrc/proj_gemm.hip).  These kernels never showed it (thousands of bitwise
+// identical repeated steps), at 4-6 waves per SIMD the wait costs nothing measurable, so they carry the fence too.
+#ifdef AMPCONV_BF16_NOFENCE
+#define TR_FRAG_FENCE() do {} while (0)
+#else
+#define TR_FRAG_FENCE()                                    \
+  do {                                                     \
+    __builtin_amdgcn_sched_barrier(0);                     \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     \
+    __builtin_amdgcn_sched_barrier(0);                     \
+  } while (0)
+#endif
 // C/D registers -> token-product fragment (t1[1..3] must already be zero: only reg 0 of tile 1 is a token)
 __device__ __forceinline__ i32x4 cd_frag(const f32x4 &t0, const f32x4 &t1) {
   return i32x4{cvt_pk_bf16(t0[0], t0[1]), cvt_pk_bf16(t0[2], t0[3]), cvt_pk_bf16(t1[0], t1[1]),
@@ -253,11 +268,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void fwd_bf16(Args a) {
       column_softmax<FULL>(S[0][nt], S[1][nt], a.qscale, L, g);
       pB[nt] = cd_frag(S[0][nt], S[1][nt]);
     }
+    i32x4 vA[2];
+#pragma unroll
+    for (int mc = 0; mc < 2; ++mc) vA[mc] = colfrag(Vt, mc, lane);
+    TR_FRAG_FENCE();
 #pragma unroll
     for (int mc = 0; mc < 2; ++mc) {
-      const i32x4 vA = colfrag(Vt, mc, lane);
-      OT[mc][0] = MFMA_BF16(vA, pB[0], OT[mc][0]);
-      OT[mc][1] = MFMA_BF16(vA, pB[1], OT[mc][1]);
+      OT[mc][0] = MFMA_BF16(vA[mc], pB[0], OT[mc][0]);
+      OT[mc][1] = MFMA_BF16(vA[mc], pB[1], OT[mc][1]);
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -337,11 +355,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void bwd_dst_bf16(Args a) {
       }
       sB[nt] = cd_frag(S[0][nt], S[1][nt]);
     }
+    i32x4 kC[2];
+#pragma unroll
+    for (int mc = 0; mc < 2; ++mc) kC[mc] = colfrag(Kt, mc, lane);
+    TR_FRAG_FENCE();
 #pragma unroll
     for (int mc = 0; mc < 2; ++mc) {
-      const i32x4 kC = colfrag(Kt, mc, lane);
-      dQT[mc][0] = MFMA_BF16(kC, sB[0], dQT[mc][0]);
-      dQT[mc][1] = MFMA_BF16(kC, sB[1], dQT[mc][1]);
+      dQT[mc][0] = MFMA_BF16(kC[mc], sB[0], dQT[mc][0]);
+      dQT[mc][1] = MFMA_BF16(kC[mc], sB[1], dQT[mc][1]);
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -441,13 +462,19 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void bwd_src_bf16(Args a) {
       pB[nt] = cd_frag(S[0][nt], S[1][nt]);
       sB[nt] = cd_frag(dP[0][nt], dP[1][nt]);
     }
+    i32x4 gC[2], qC[2];
 #pragma unroll
     for (int mc = 0; mc < 2; ++mc) {
-      const i32x4 gC = colfrag(Gt, mc, lane), qC = colfrag(Qt, mc, lane);
-      dVT[mc][0] = MFMA_BF16(gC, pB[0], dVT[mc][0]);
-      dVT[mc][1] = MFMA_BF16(gC, pB[1], dVT[mc][1]);
-      dKT[mc][0] = MFMA_BF16(qC, sB[0], dKT[mc][0]);
-      dKT[mc][1] = MFMA_BF16(qC, sB[1], dKT[mc][1]);
+      gC[mc] = colfrag(Gt, mc, lane);
+      qC[mc] = colfrag(Qt, mc, lane);
+    }
+    TR_FRAG_FENCE();
+#pragma unroll
+    for (int mc = 0; mc < 2; ++mc) {
+      dVT[mc][0] = MFMA_BF16(gC[mc], pB[0], dVT[mc][0]);
+      dVT[mc][1] = MFMA_BF16(gC[mc], pB[1], dVT[mc][1]);
+      dKT[mc][0] = MFMA_BF16(qC[mc], sB[0], dKT[mc][0]);
+      dKT[mc][1] = MFMA_BF16(qC[mc], sB[1], dKT[mc][1]);
     }
     __builtin_amdgcn_wave_barrier();
   }
