@@ -422,7 +422,8 @@ def measure_saint(workload, steps, warmup, args, rank, world, dev, dist_on, dt_n
         'config': {'workload': f'{workload}: {desc}; sampler + feature-row gather + one AMPConv layer fwd+bwd incl. CSR '
                                f'build of the subgraph' + (' + RCCL grad all-reduce' if world > 1 else ''),
                    'N': N, 'E': E, 'L': L, 'D': D, 'H': H, 'roots': roots, 'walk_length': walk,
-                   'parallelism': f'dp{world}', 'gemm': args.gemm if dt_name == 'f32' else 'bf16'},
+                   'parallelism': f'dp{world}', 'gemm': args.gemm if dt_name == 'f32' else 'bf16',
+                   'projections': _projection_note(dt_name, args.gemm)},
         'nodes_avg': n_avg, 'edges_avg': e_avg, 'sampler_ms': sampler_ms, 'allreduce_ms': ar_ms,
         'batch': {'nodes_avg': n_avg, 'edges_avg': e_avg, 'sampler_ms': sampler_ms,
                   'sampler_share_of_step': sampler_ms / (1e3 * t_step),
@@ -526,7 +527,8 @@ def measure_full(workload, steps, warmup, args, rank, world, dev, dist_on, dt_na
            'config': {'workload': f'{workload}: {desc}, one AMPConv layer fwd+bwd incl. CSR build, '
                                   f'one graph per GPU' + (' + RCCL grad all-reduce' if world > 1 else ''),
                       'N': N, 'E': E, 'L': L, 'D': D, 'H': H, 'parallelism': f'dp{world}',
-                      'gemm': args.gemm if dt_name == 'f32' else 'bf16'}}
+                      'gemm': args.gemm if dt_name == 'f32' else 'bf16',
+                      'projections': _projection_note(dt_name, args.gemm)}}
     if args.softmax_free:
         # the edge phase of this variant is one segment reduction (conv/linear.py): no edge-kernel roofline
         out['metric'] += ', softmax-free variant'
@@ -598,6 +600,19 @@ def measure_full(workload, steps, warmup, args, rank, world, dev, dist_on, dt_na
                                  'out-edge / either); layer_flops and node_phase_mfma count those rows; the HBM figures keep '
                                  "SURVEY 8d's all-node bytes")
     return out
+
+
+def _projection_note(dt_name, gemm):
+    """config.projections: which arithmetic the per-node projections of this line ran."""
+    from ampnet_amd.conv import functional as F_
+    if dt_name == 'bf16':
+        return 'bf16 storage: one bf16 matrix product, fp32 accumulate' + (', node lists on graphs with edge-less nodes'
+                                                                            if F_.NODE_LISTS else '')
+    if gemm != 'native':
+        return {'fp32': 'library fp32 GEMMs (rocBLAS)', 'bf16x3': "hipBLASLt's 3-product bf16 split"}[gemm]
+    return ('fp32 in / out / accumulate; operands of >= 2^24 elements: two fp16 planes of the power-of-two-scaled operand, '
+            '3 matrix products; smaller: three bf16 planes, 6 products' if F_.PROJ_SCALED
+            else 'fp32 in / out / accumulate; three bf16 planes, 6 matrix products')
 
 
 def _node_phase_mfma(flops_proj, t_node, dt_name, gemm):
