@@ -13,6 +13,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $d -o stats -- python3 b
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $d -o fetch -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-alt-gemm --no-extra > $d/bench_fetch.log 2> $d/bench_fetch.err || exit 1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $d -o write -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-alt-gemm --no-extra > $d/bench_write.log 2> $d/bench_write.err || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d $d -o cfg5 -- python3 bench.py --workload cfg5 --steps 2 --warmup 1 --no-cpu-baseline --no-extra > $d/bench_cfg5.log 2> $d/bench_cfg5.err || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d $d -o saint -- python3 bench.py --workload cfg4-saint --steps 10 --warmup 2 --no-cpu-baseline > $d/bench_saint.log 2> $d/bench_saint.err || exit 1
+rm -f $d/saint_kernel_trace.csv
 fi
 if [ "$part" != bench ]; then
 {

@@ -154,6 +154,25 @@ def main():
                     'not the layer.  Everything launched inside ONE timed step, from the kernel trace of the same run '
                     '(`cfg5_kernel_trace.csv`): no `Cijk_*` (rocBLAS / Tensile) and no `at::native::*` kernel.\n\n')
             f.writelines(step_table(os.path.join(d, 'cfg5_kernel_trace.csv'), r'extract_keys', r'proj_rows_bf16_kernel|mask_rows_kernel|wgrad_reduce_bf16'))
+    # GraphSAINT batches of config 4, if profiled
+    cs = os.path.join(d, 'saint_kernel_stats.csv')
+    if os.path.exists(cs) and os.path.exists(os.path.join(d, 'bench_saint.log')):
+        b = bench_line(os.path.join(d, 'bench_saint.log'))
+        shutil.copy(cs, os.path.join(out, f'{tag}_cfg4_saint_kernel_stats.csv'))
+        rows_s = list(csv.DictReader(open(cs)))
+        nb = b['steps'] + b['warmup']
+        with open(os.path.join(out, f'{tag}_cfg4_saint_kernel_stats.md'), 'w') as f:
+            f.write(f'# rocprofv3 --kernel-trace --stats, GraphSAINT batches of config 4 ({tag}, final code of the round)\n\n')
+            f.write(f'Command: `rocprofv3 --kernel-trace --stats --output-format csv -d {d} -o saint -- python3 bench.py '
+                    '--workload cfg4-saint --steps 10 --warmup 2 --no-cpu-baseline`\n\n')
+            f.write(f"Bench line of this profiled run: {b['value'] / 1e6:.2f} M sampled edges/s, {b['ms_per_step']:.2f} ms per batch "
+                    f"({b['nodes_avg']:.0f} nodes / {b['edges_avg']:.0f} edges per batch, sampler {b['sampler_ms']:.2f} ms); {nb} "
+                    f"batches recorded ({b['warmup']} warm-up + {b['steps']} timed).  The `distribution_elementwise` / `copyBuffer` rows "
+                    "are the bench's data fill of the resident 1 M-node graph, outside the timed batches.\n\n")
+            f.write('| kernel | calls | calls per batch | avg ms | total ms | % |\n|---|---|---|---|---|---|\n')
+            for r in rows_s[:24]:
+                f.write(f"| `{short(r['Name'], 110)}` | {r['Calls']} | {int(r['Calls']) / nb:.1f} | {float(r['AverageNs']) / 1e6:.3f} | "
+                        f"{float(r['TotalDurationNs']) / 1e6:.1f} | {r['Percentage']} |\n")
     sq = os.path.join(d, 'sq_summary.txt')
     if os.path.exists(sq):
         with open(os.path.join(out, f'{tag}_sq_counters.md'), 'w') as f:
