@@ -59,6 +59,7 @@ class AMPConv(MessagePassing):
         super().__init__(aggr='mean')
         self.softmax = bool(softmax)
         self._attn_ctx = None
+        self._attn_plane_bounds = None
         self._attn_output = None
         self._attn_output_weights = None
         # what the lazy per-edge outputs (attn_output, attn_output_weights) need is the projection
@@ -122,15 +123,18 @@ class AMPConv(MessagePassing):
         csr = graph_cache.get(edge_index, x.size(0))
         # the previous call's projection buffer goes before this call allocates its own (peak memory)
         self._attn_ctx = self._attn_output = self._attn_output_weights = None
+        bounds = None
         if self.softmax:
-            y, qkv, _ = F_.AMPConvFunction.apply(x, x, *self._params(), csr, self.num_heads, True,
-                                                 _lib.AMPCONV_F32, self.gemm_precision)
+            # (third output of a self-attention call: None, or -- the projections left their kernel in the plane format
+            # of the 16-bit edge passes -- the device bounds that read `qkv` back, functional.planes_to_f32)
+            y, qkv, bounds = F_.AMPConvFunction.apply(x, x, *self._params(), csr, self.num_heads, True,
+                                                      _lib.AMPCONV_F32, self.gemm_precision)
         else:
             self._check_linear(x)
             y, qkv, _ = FL_.LinearAMPConvFunction.apply(x, x, *self._params(), csr, self.num_heads, True,
                                                         self.gemm_precision)
         L = x.size(1) // self.embed_dim
-        self._set_attn_ctx(qkv, None, edge_index, L, shared=True)
+        self._set_attn_ctx(qkv, None, edge_index, L, shared=True, plane_bounds=bounds)
         return y
 
     def message(self, x_i, x_j):
@@ -167,7 +171,7 @@ class AMPConv(MessagePassing):
         return F_.segment_mean(inputs.to(torch.float32), csr, index.to(torch.int64))
 
     # ------------------------------------------------------------------ lazy per-edge outputs
-    def _set_attn_ctx(self, q_buf, kv_buf, edge_index, L, shared):
+    def _set_attn_ctx(self, q_buf, kv_buf, edge_index, L, shared, plane_bounds=None):
         self._attn_output = None
         self._attn_output_weights = None
         self._attn_ctx = None
@@ -181,6 +185,7 @@ class AMPConv(MessagePassing):
             return
         self._attn_ctx = (q_buf.detach(), None if kv_buf is None else kv_buf.detach(),
                           edge_index, L, shared)
+        self._attn_plane_bounds = None if plane_bounds is None else plane_bounds.detach()
         # attn_output is produced lazily with the out-projection parameters: remember which version
         # of them the forward pass saw (an optimizer step in between changes the result)
         m = self.multi_head_attention
@@ -196,6 +201,11 @@ class AMPConv(MessagePassing):
 
     def _attn_views(self):
         q_buf, kv_buf, edge_index, L, shared = self._attn_ctx
+        if getattr(self, '_attn_plane_bounds', None) is not None:      # plane format -> fp32, once
+            with torch.cuda.device(q_buf.device):
+                q_buf = F_.planes_to_f32(q_buf, self._attn_plane_bounds[0:1])
+            self._attn_ctx = (q_buf, kv_buf, edge_index, L, shared)
+            self._attn_plane_bounds = None
         if q_buf.dtype != torch.float32:              # side outputs are served in fp32
             q_buf = q_buf.float()
             kv_buf = None if kv_buf is None else kv_buf.float()

@@ -110,6 +110,82 @@ PROJ_SCALED = os.environ.get('AMPCONV_PROJ_SCALED', '1') != '0'
 PROJ_SCALED_MIN_ELEMENTS = 1 << 24
 
 
+# fp32 storage, scaled mode, L <= 20, head width 32, self-attention layers (xq is xkv): the edge passes run on the
+# 16-bit matrix pipe -- the in-projection and dObar = dY Wo leave their kernels as two fp16 planes of the scaled value
+# (csrc/edge_mfma_f16x2.hip, include/ampconv.h "edge phase on fp16 PLANES"); '0': the fp32-MFMA edge kernels
+EDGE_PLANES = os.environ.get('AMPCONV_EDGE_PLANES', '1') != '0'
+# ONE power-of-two scale per tensor serves rows within this many binades of the tensor's maximum at fp32 grade; operands
+# that have a head slot further down (ampconv_absmax_stats) take the exact kernels instead: six-product projections,
+# fp32 edge passes.  The price of knowing is one 8-byte read-back per operand (x: cached per tensor version; dY: per step)
+RANGE_LOG2 = 12
+_STATS_CACHE = {}         # id(tensor) -> (weakref, _version, stats tensor, narrow)
+
+
+def operand_stats(t2, key=None):
+    """(stats, narrow): stats = device tensor [largest finite magnitude, smallest non-zero head-slot maximum] of the
+    2-D fp32 tensor t2 (one pass, ampconv_absmax_stats), narrow = the whole tensor lies within 2^RANGE_LOG2 of its
+    maximum (host bool: ONE 8-byte read-back).  key: the tensor OBJECT the caller was handed (t2 may be a view of it);
+    the result is remembered for as long as that object lives and its version counter stands still -- the features of
+    a full-graph run are measured once, not once per step."""
+    import weakref
+    if key is not None:
+        hit = _STATS_CACHE.get(id(key))
+        if hit is not None and hit[0]() is key and hit[1] == key._version and hit[2].device == t2.device:
+            return hit[2], hit[3]
+    lib = _lib.load()
+    t2 = _aligned(t2)
+    st = torch.empty(2, dtype=torch.float32, device=t2.device)
+    _lib.check(lib.ampconv_absmax_stats(t2.data_ptr(), t2.stride(0), t2.size(0), t2.size(1), st.data_ptr(), _stream()),
+               'ampconv_absmax_stats')
+    amax, smin = st.tolist()
+    narrow = not (smin * float(1 << RANGE_LOG2) < amax)          # (an all-zero tensor: inf < 0 is false -> narrow)
+    if key is not None:
+        if len(_STATS_CACHE) >= 16:
+            for k in [k for k, v in _STATS_CACHE.items() if v[0]() is None] or list(_STATS_CACHE)[:8]:
+                _STATS_CACHE.pop(k, None)
+        _STATS_CACHE[id(key)] = (weakref.ref(key), key._version, st, narrow)
+    return st, narrow
+
+
+def planes_to_f32(buf2d, bound):
+    """fp32 copy of a projection buffer held in the plane format (side outputs, fall-backs)."""
+    out = torch.empty_like(buf2d)
+    _lib.check(_lib.load().ampconv_planes_to_f32(buf2d.data_ptr(), buf2d.stride(0), buf2d.size(0), buf2d.size(1),
+                                                 bound.data_ptr(), out.data_ptr(), out.stride(0), _stream()),
+               'ampconv_planes_to_f32')
+    return out
+
+
+def proj_out_bound(W, transpose, bias, amax, out):
+    """out[0] = amax * (largest absolute row sum of B) + max |bias|, B = W (transpose: W^T): the scale source of a
+    plane-format projection output, on the device."""
+    R, C = W.shape
+    N, K = (C, R) if transpose else (R, C)
+    sn, sk = (1, W.stride(0)) if transpose else (W.stride(0), 1)
+    _lib.check(_lib.load().ampconv_proj_out_bound(W.data_ptr(), sn, sk, N, K, _ptr(bias), amax.data_ptr(), out.data_ptr(),
+                                                  _stream()), 'ampconv_proj_out_bound')
+
+
+def proj_rows_planes(a2, image, bound, bias=None, rowptr=None, L=0, row_scale=0, amax=None, out_amax=None, amax_col0=0):
+    """proj_rows whose output leaves as two fp16 planes of value * 2^e(bound) in the 128-byte slots of the fp32 buffer
+    (include/ampconv.h).  row_scale = 1 (with rowptr): rows are divided by their node's in-degree (0 for none)."""
+    lib = _lib.load()
+    img, N, K, wdt = image
+    assert a2.dim() == 2 and a2.size(1) == K and a2.stride(1) == 1 and a2.dtype == wdt == torch.float32
+    a2 = _aligned(a2)
+    out = torch.empty(a2.size(0), N, dtype=wdt, device=a2.device)
+    _lib.check(lib.ampconv_proj_rows_planes(a2.data_ptr(), a2.stride(0), a2.size(0), K, img.data_ptr(), N, _ptr(bias),
+                                            _ptr(rowptr), L, row_scale, out.data_ptr(), out.stride(0), amax.data_ptr(),
+                                            bound.data_ptr(), _ptr(out_amax), amax_col0, _stream()),
+               'ampconv_proj_rows_planes')
+    return out
+
+
+def planes_ok(L, D, H, shared):
+    """Does the plane-format edge phase serve this layer call?  (Only with the scaled projections; the caller checks.)"""
+    return bool(EDGE_PLANES and shared and D % 128 == 0 and _lib.load().ampconv_planes_supported(L, D, H))
+
+
 def absmax(t2, out=None, reset=False):
     """Largest finite magnitude of a 2-D tensor with contiguous rows, as a one-element device tensor (no host sync):
     the scale source of the fp32 projections' two-plane mode.  `out`: merge into an existing maximum (reset: zero it
@@ -281,25 +357,38 @@ class AMPConvFunction(torch.autograd.Function):
             # fp32 storage: operand maxima for the scaled two-plane products, device-side.  am = [x (query side), the
             # in-projection's output (K | V side: an upper bound of |Obar|, a mean of convex combinations of V rows),
             # x (key/value side)]; inputs are measured by one pass, outputs recorded by the product that writes them
-            am = None
+            # The scaled mode serves operands that lie within 2^RANGE_LOG2 of their maximum (operand_stats: one pass, one
+            # 8-byte read-back, remembered per tensor version); anything wider takes the exact six-product kernels.
+            am = bounds = None
+            planes = False
+            xkv2 = xq2 if shared else xkv.contiguous().view(Nk * L, D)
             if native and PROJ_SCALED and xq.dtype == torch.float32 and xq2.numel() >= PROJ_SCALED_MIN_ELEMENTS:
-                am = torch.empty(3, dtype=torch.float32, device=xq.device)
-                absmax(xq2, am[0:1], reset=True)
-                _zero(am[1:2])
-            sl = (lambda i: am[i:i + 1]) if am is not None else (lambda i: None)
-            if shared:
+                st, narrow = operand_stats(xq2, key=xq)
+                stk = None
+                if narrow and not shared:
+                    stk, narrow = operand_stats(xkv2, key=xkv)
+                if narrow:
+                    am = [st[0:1], torch.zeros(1, dtype=torch.float32, device=xq.device), None if shared else stk[0:1]]
+                    planes = planes_ok(L, D, H, shared)
+            sl = (lambda i: am[i]) if am is not None else (lambda i: None)
+            if planes:
+                # Q | K | V leave the in-projection as two fp16 planes scaled by a bound known before the product runs
+                # (max |x| times the largest absolute row sum of W, plus max |b|); the recorded maximum covers the V third
+                # only: it bounds Obar, a mean of convex combinations of V rows
+                bounds = torch.empty(2, dtype=torch.float32, device=xq.device)
+                proj_out_bound(w_in, False, b_in, am[0], bounds[0:1])
+                qkv = proj_rows_planes(xq2, imgs[0], bounds[0:1], b_in, amax=am[0], out_amax=am[1], amax_col0=2 * D)
+                Qv, Kv, Vv = (_view(qkv, i * D, L, dh) for i in range(3))
+                kv = None
+            elif shared:
                 # (node lists: Q rows matter for nodes with in-edges, K / V rows for nodes with out-edges; the rows of
                 # nodes with neither are never read by an edge pass and stay unwritten)
                 qkv = (proj_rows(xq2, imgs[0], b_in, L=L, nodes=lists and lists['any'], amax=sl(0), out_amax=sl(1))
                        if native else torch.addmm(b_in, xq2, w_in.t()))              # [N*L, 3D]
                 Qv, Kv, Vv = (_view(qkv, i * D, L, dh) for i in range(3))
-                xkv2 = xq2
                 kv = None
             else:
-                xkv2 = xkv.contiguous().view(Nk * L, D)
                 if native:
-                    if am is not None:
-                        absmax(xkv2, am[2:3], reset=True)
                     qkv = proj_rows(xq2, imgs[0], b_in[:D], amax=sl(0))
                     kv = proj_rows(xkv2, imgs[1], b_in[D:], amax=sl(2), out_amax=sl(1))
                 else:
@@ -308,7 +397,13 @@ class AMPConvFunction(torch.autograd.Function):
                 Qv = _view(qkv, 0, L, dh)
                 Kv, Vv = _view(kv, 0, L, dh), _view(kv, D, L, dh)
             obar = torch.empty(Nq * L, D, dtype=xq.dtype, device=xq.device)
-            edge_forward(Qv, Kv, Vv, csr, Nq, L, D, H, obar, dtype=dtype)
+            if planes:
+                plan, nch, ws = csr.hub_args('dst', L, D, 1)
+                _lib.check(lib.ampconv_fwd_edge_planes(Qv, Kv, Vv, csr.rowptr.data_ptr(), csr.col.data_ptr(), Nq, L, D, H,
+                                                       _view(obar, 0, L, dh), plan, nch, _ptr(ws), bounds.data_ptr(),
+                                                       _stream()), 'ampconv_fwd_edge_planes')
+            else:
+                edge_forward(Qv, Kv, Vv, csr, Nq, L, D, H, obar, dtype=dtype)
             if lists:       # the rows of the nodes with in-edges; the others are zeroed without being read
                 y = proj_rows(obar, imgs[1], b_out, L=L, nodes=lists['in'])
                 _zero_unlisted(y, lists['in'], Nq, L)
@@ -322,11 +417,14 @@ class AMPConvFunction(torch.autograd.Function):
         ctx.set_materialize_grads(False)     # no zero-filled [N*L, 3D] gradient for the qkv side output
         ctx.save_for_backward(xq2, xkv2, w_in, w_out, qkv, kv, obar)
         ctx.csr, ctx.dims, ctx.shared, ctx.dtype, ctx.gemm = csr, (Nq, Nk, L, D, H), shared, dtype, gemm
-        ctx.lists, ctx.amax = lists, am
+        ctx.lists, ctx.amax, ctx.bounds = lists, am, bounds
         ctx.images_t = imgs[len(imgs) // 2:] if imgs else None     # the transposed images, for the input gradients
         ctx.mark_non_differentiable(qkv)
         if kv is not None:
             ctx.mark_non_differentiable(kv)
+        if bounds is not None:              # plane format: the third output is what reads `qkv` back (planes_to_f32)
+            ctx.mark_non_differentiable(bounds)
+            return y.view(Nq, L * D), qkv, bounds
         return y.view(Nq, L * D), qkv, kv
 
     @staticmethod
@@ -345,12 +443,21 @@ class AMPConvFunction(torch.autograd.Function):
             native = proj_native(ctx.gemm, dy2.dtype, D)
             # out-projection: rows with no in-edge contribute nothing (their obar is 0, and
             # the bias gradient masks them explicitly)
-            lists, am = ctx.lists, ctx.amax
-            ag = None           # maxima of the gradients that are operands: [dY, dQ (shared: dQKV), dK | dV]
+            lists, am, bounds = ctx.lists, ctx.amax, ctx.bounds
+            # maxima of the gradients that are operands: [dY, dQ (shared: dQKV), dK | dV].  The scaled products serve dY
+            # only if it lies within 2^RANGE_LOG2 of its maximum too (one pass + one read-back per step: gradients are
+            # new every step); otherwise the whole backward pass takes the exact kernels
+            ag = None
             if am is not None:
-                ag = torch.empty(3, dtype=torch.float32, device=dev)
-                absmax(dy2, ag[0:1], reset=True)
-            sl = (lambda t, i: t[i:i + 1]) if am is not None else (lambda t, i: None)
+                stg, narrow = operand_stats(dy2)
+                if narrow:
+                    ag = [stg[0:1], torch.zeros(1, dtype=torch.float32, device=dev), None]
+                else:
+                    am = None
+            planes = bounds is not None and ag is not None
+            if bounds is not None and not planes:         # the saved projections as fp32 for the exact edge passes
+                qkv = planes_to_f32(qkv, bounds[0:1])
+            sl = (lambda t, i: t[i]) if am is not None else (lambda t, i: None)
             pair = (lambda a, b: (a, b)) if am is not None else (lambda a, b: None)
             if native:
                 dw_out = torch.empty_like(w_out)
@@ -358,6 +465,11 @@ class AMPConvFunction(torch.autograd.Function):
                 if lists:   # the listed nodes ARE the ones that pass the mask; dObar is read for destinations only
                     proj_wgrad(dy2, obar, dw_out, db_out, L=L, nodes=lists['in'])
                     dobar = proj_rows(dy2, ctx.images_t[-1], L=L, nodes=lists['in'])
+                elif planes:    # dObar / in-degree as two fp16 planes (the edge passes then carry no per-edge weight)
+                    proj_wgrad(dy2, obar, dw_out, db_out, csr.rowptr, L, amax=pair(sl(ag, 0), sl(am, 1)))
+                    proj_out_bound(w_out, True, None, ag[0], bounds[1:2])
+                    dobar = proj_rows_planes(dy2, ctx.images_t[-1], bounds[1:2], rowptr=csr.rowptr, L=L, row_scale=1,
+                                             amax=ag[0])
                 else:
                     proj_wgrad(dy2, obar, dw_out, db_out, csr.rowptr, L, amax=pair(sl(ag, 0), sl(am, 1)))
                     dobar = proj_rows(dy2, ctx.images_t[-1], amax=sl(ag, 0))
@@ -384,30 +496,39 @@ class AMPConvFunction(torch.autograd.Function):
             # softmax statistics (normaliser, delta) per edge: a by-product of the destination
             # pass that saves the source pass its cross-lane reductions (include/ampconv.h)
             stats = spos = None
-            nstat = lib.ampconv_softmax_stats_bytes(csr.num_edges, L, D, H, ctx.dtype) if SOFTMAX_STATS else 0
+            nstat = (lib.ampconv_softmax_stats_bytes(csr.num_edges, L, D, H, ctx.dtype)
+                     if SOFTMAX_STATS and not planes else 0)
             if nstat:
                 stats = torch.empty(nstat // 4, dtype=torch.float32, device=dev)
                 spos = csr.csc_positions()
             plan, nch, ws = csr.hub_args('dst', L, D, 1)
-            # (scaled projections: the operand maximum of the two products that consume dQKV.  The destination pass
-            # records the maximum of dQ as it stores; dK | dV: one pass below -- the source-pass kernels have no register
-            # to spare for it (csrc/edge_mfma.hip); shared: one maximum, else dQ and dK | dV apart)
-            if am is not None:
-                _zero(ag[1:2])
-            rc = lib.ampconv_bwd_edge_dst(Qv, Kv, Vv, dOv, csr.rowptr.data_ptr(), csr.col.data_ptr(),
-                                          Nq, L, D, H, dQv, plan, nch, _ptr(ws), _ptr(spos), _ptr(stats),
-                                          _ptr(sl(ag, 1)), ctx.dtype, _stream())
-            _lib.check(rc, 'ampconv_bwd_edge_dst')
-            plan, nch, ws = csr.hub_args('src', L, D, 2)
-            rc = lib.ampconv_bwd_edge_src(Qv, Kv, Vv, dOv, csr.cscptr.data_ptr(), csr.crow.data_ptr(),
-                                          csr.cinv.data_ptr(), Nk, L, D, H, dKv, dVv, plan, nch, _ptr(ws),
-                                          _ptr(stats), None, ctx.dtype, _stream())
-            _lib.check(rc, 'ampconv_bwd_edge_src')
-            if am is not None:
-                if shared:
-                    absmax(dqkv[:, D:], ag[1:2])              # merged into the maximum of dQ
-                else:
-                    absmax(dkv, ag[2:3], reset=True)
+            if planes:
+                # both passes on the 16-bit matrix pipe; each records the maximum of what it writes (ag[1]: all of dQKV)
+                _lib.check(lib.ampconv_bwd_edge_dst_planes(Qv, Kv, Vv, dOv, csr.rowptr.data_ptr(), csr.col.data_ptr(),
+                                                           Nq, L, D, H, dQv, plan, nch, _ptr(ws), bounds.data_ptr(),
+                                                           ag[1].data_ptr(), _stream()), 'ampconv_bwd_edge_dst_planes')
+                plan, nch, ws = csr.hub_args('src', L, D, 2)
+                _lib.check(lib.ampconv_bwd_edge_src_planes(Qv, Kv, Vv, dOv, csr.cscptr.data_ptr(), csr.crow.data_ptr(),
+                                                           Nk, L, D, H, dKv, dVv, plan, nch, _ptr(ws), bounds.data_ptr(),
+                                                           ag[1].data_ptr(), _stream()), 'ampconv_bwd_edge_src_planes')
+            else:
+                # (scaled projections: the operand maximum of the two products that consume dQKV.  The destination pass
+                # records the maximum of dQ as it stores; dK | dV: one pass below -- the fp32 source-pass kernels have no
+                # register to spare for it (csrc/edge_mfma.hip); shared: one maximum, else dQ and dK | dV apart)
+                rc = lib.ampconv_bwd_edge_dst(Qv, Kv, Vv, dOv, csr.rowptr.data_ptr(), csr.col.data_ptr(),
+                                              Nq, L, D, H, dQv, plan, nch, _ptr(ws), _ptr(spos), _ptr(stats),
+                                              _ptr(sl(ag, 1)), ctx.dtype, _stream())
+                _lib.check(rc, 'ampconv_bwd_edge_dst')
+                plan, nch, ws = csr.hub_args('src', L, D, 2)
+                rc = lib.ampconv_bwd_edge_src(Qv, Kv, Vv, dOv, csr.cscptr.data_ptr(), csr.crow.data_ptr(),
+                                              csr.cinv.data_ptr(), Nk, L, D, H, dKv, dVv, plan, nch, _ptr(ws),
+                                              _ptr(stats), None, ctx.dtype, _stream())
+                _lib.check(rc, 'ampconv_bwd_edge_src')
+                if am is not None:
+                    if shared:
+                        absmax(dqkv[:, D:], ag[1])                # merged into the maximum of dQ
+                    else:
+                        ag[2] = absmax(dkv)
             # in_proj_bias gradient without a pass over all of dQKV: softmax rows sum to 1, so the
             # column sum of dV over every source token equals the column sum of dObar over the rows
             # that receive messages, and dObar = dY Wo is linear in dY, so that sum is (masked column sum of

@@ -237,12 +237,19 @@ struct RowsArgs {
   // scaled mode (HP): largest finite magnitudes of A and of the weight (device floats); the output's may be recorded
   const float *amax_a, *amax_w;
   float *out_amax;            // or null: atomic max over this launch's outputs (the caller zeroes it), scaled mode only
+  int amax_col0;              // ... over the output columns >= amax_col0 only (the V third of a packed in-projection)
+  // PLANES (scaled mode only): `out` receives, per 32-column block, the two fp16 planes of value * plane_scale(*out_bound)
+  // (the format of csrc/edge_mfma_f16x2.hip); out_bound: device float, an upper bound of the output's magnitudes
+  const float *out_bound;
+  int row_scale;              // with rowptr: 0 = rows of nodes with an empty segment come out 0 (the mask),
+                              // 1 = every row is DIVIDED by its node's segment length as well (1 / in-degree)
 };
 
 // RAGGED: K % 32 != 0 or N % BN != 0 (e.g. the reference's default embed_dim = 100): row loads beyond K read as zero,
 // columns beyond N are computed on the image's zero padding and not stored
-template <int BM, int BN, int WM, int WN, bool RAGGED, bool HP>
+template <int BM, int BN, int WM, int WN, bool RAGGED, bool HP, bool PLANES = false>
 __global__ __launch_bounds__(64 * WM * WN, 2) void proj_rows_kernel(RowsArgs a) {
+  static_assert(!PLANES || HP, "plane output exists in the scaled mode only");
   constexpr int kNP = Pl<HP>::NP, kTile3 = Pl<HP>::kTile;
   constexpr int NW = WM * WN, NTHR = 64 * NW;
   constexpr int MTB = BM / 32, NTB = BN / 32;          // 32-row / 32-column tiles per workgroup
@@ -280,6 +287,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void proj_rows_kernel(RowsArgs a) 
   // could leave the fp32 range)
   const float sa = HP ? plane_scale(*a.amax_a) : 1.f;
   const float ua = HP ? 1.f / sa : 1.f, uw = HP ? plane_unscale(*a.amax_w) : 1.f;
+  const float so = PLANES ? plane_scale(*a.out_bound) : 1.f;      // PLANES: the output leaves in these units
   float omax = 0.f;                     // largest finite |output| this thread has stored
 
   // tile slot u -> (row tile, column tile).  Workgroups b, b + 8, ... share an XCD (round-robin dispatch, speed
@@ -323,10 +331,16 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void proj_rows_kernel(RowsArgs a) 
   // pieces (also assembly), so the wait it would put in front of the first use of an ordinary load -- "all my loads but
   // the n youngest" -- also drains every DMA piece issued since: a full L2 round trip in the even step, in plain sight
   // once the products per step were halved (in-kernel stamps: even step 3306 cycles, odd step 1885).
+  // (the two ragged six-product shapes -- the reference's embed_dim = 100, no benchmark shape -- sit at the register
+  // limit and spill an address pair; a spill between an assembly load and its wait would save a register whose data has
+  // not landed, so THEY keep compiler-managed loads: hipcc then waits by itself wherever it touches the values, at the
+  // price of the drained DMA pieces described above)
+  constexpr bool kAsmRows = !(RAGGED && !HP);
   f32x4 x[2][NLH];                      // one 32-deep line block of the thread's rows: [half][row]
   auto gload = [](const float *p) {
     f32x4 v;
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    if constexpr (kAsmRows) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    else v = *reinterpret_cast<const f32x4 *>(p);
     return v;
   };
 // behind a wait: the values of half H are used after this point only
@@ -429,7 +443,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void proj_rows_kernel(RowsArgs a) 
       if (a.rowptr) {
         const int64_t m = cur.row0 + t < a.M ? cur.row0 + t : a.M - 1;
         const unsigned node = (unsigned)m / (unsigned)a.L;        // (M < 2^31 with a mask: host check)
-        f = a.rowptr[node + 1] != a.rowptr[node] ? 1.f : 0.f;
+        const int seg = a.rowptr[node + 1] - a.rowptr[node];
+        f = seg != 0 ? (a.row_scale ? 1.f / (float)seg : 1.f) : 0.f;
       }
       flags[par * BM + t] = f;
     }
@@ -485,6 +500,49 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void proj_rows_kernel(RowsArgs a) 
         const int col = cur.col0 + (NTW * wn + j) * 32 + fr;
         bj[j] = (a.bias && (!RAGGED || col < a.N)) ? a.bias[col] : 0.f;
       }
+      // PLANES: the 32 x 32 sub-tile is one (row, head) slot per row -- 32 fp16 hi then 32 fp16 lo of value * so.  The
+      // staged values are already in plane units (both operand scales and so folded into one factor, exact powers of
+      // two).  Staging swaps the two 4-float chunks of every chunk pair in the rows with bit 1 set, so that lane
+      // (row = lane >> 2, c = lane & 3) reads its 8 consecutive channels 8 c .. 8 c + 7 as two conflict-free
+      // ds_read_b128 (rows r, r + 1 take the even physical chunks, r + 2, r + 3 the odd ones); it splits them and
+      // stores 16 bytes of each plane: four dwordx4 stores per sub-tile, as the fp32 tail.
+      auto store_planes = [&](auto ragged) {
+        const float kso = ua * uw * so;
+        const int pr = lane >> 2, pc = lane & 3, ps = (pr >> 1) & 1;
+#pragma unroll
+        for (int i = 0; i < MTW; ++i) {
+          const int rl0 = (MTW * wm + i) * 32;
+          float fl[16];
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const float4 f4 = *reinterpret_cast<const float4 *>(fl_t + rl0 + 4 * fh + 8 * g);
+            fl[4 * g] = f4.x; fl[4 * g + 1] = f4.y; fl[4 * g + 2] = f4.z; fl[4 * g + 3] = f4.w;
+          }
+#pragma unroll
+          for (int j = 0; j < NTW; ++j) {
+            const int colt = cur.col0 + (NTW * wn + j) * 32;
+            const float bjs = bj[j] * so;
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+              stage[((e & 3) + 8 * (e >> 2) + 4 * fh) * 32 + (fr ^ (((e >> 1) & 1) << 2))] = (acc[i][j][e] * kso + bjs) * fl[e];
+            const bool rec = a.out_amax && colt >= a.amax_col0;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+              const int row = pr + 16 * g;
+              const float4 v0 = *reinterpret_cast<const float4 *>(stage + row * 32 + 4 * ((2 * pc) ^ ps));
+              const float4 v1 = *reinterpret_cast<const float4 *>(stage + row * 32 + 4 * ((2 * pc + 1) ^ ps));
+              const Pair3 p0 = split_pair_h(v0.x, v0.y, 1.f), p1 = split_pair_h(v0.z, v0.w, 1.f);
+              const Pair3 p2 = split_pair_h(v1.x, v1.y, 1.f), p3 = split_pair_h(v1.z, v1.w, 1.f);
+              if ((!decltype(ragged)::value || cur.row0 + rl0 + row < a.M) && (!RAGGED || colt < a.N)) {
+                char *o = reinterpret_cast<char *>(a.out + (cur.row0 + rl0 + row) * a.ldc + colt) + 16 * pc;
+                *reinterpret_cast<i32x4 *>(o) = i32x4{p0.h1, p1.h1, p2.h1, p3.h1};
+                *reinterpret_cast<i32x4 *>(o + 64) = i32x4{p0.h2, p1.h2, p2.h2, p3.h2};
+                if (rec) omax = finite_abs_max(finite_abs_max(omax, v0), v1);       // (in plane units: undone at the end)
+              }
+            }
+          }
+        }
+      };
       auto store_tile = [&](auto ragged) {
 #pragma unroll
         for (int i = 0; i < MTW; ++i) {
@@ -503,22 +561,27 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void proj_rows_kernel(RowsArgs a) 
               stage[((e & 3) + 8 * (e >> 2) + 4 * fh) * 32 + fr] =
                   ((HP ? acc[i][j][e] * ua * uw : acc[i][j][e]) + bj[j]) * fl[e];
             float *o = a.out + (cur.row0 + rl0 + sr) * a.ldc + colt + 4 * sc4;
+            const bool rec = HP && a.out_amax && colt >= a.amax_col0;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
               const float4 v = *reinterpret_cast<const float4 *>(stage + (sr + 8 * g) * 32 + 4 * sc4);
               if ((!decltype(ragged)::value || cur.row0 + rl0 + sr + 8 * g < a.M) && (!RAGGED || colt + 4 * sc4 < a.N)) {
                 *reinterpret_cast<float4 *>(o + (int64_t)(8 * g) * a.ldc) = v;
-                if (HP && a.out_amax)
-                  omax = fmaxf(fmaxf(omax, fmaxf(finite_abs(v.x), finite_abs(v.y))), fmaxf(finite_abs(v.z), finite_abs(v.w)));
+                if (rec) omax = finite_abs_max(omax, v);
               }
             }
           }
         }
       };
-      if (cur.row0 + BM <= a.M)            // workgroup-uniform: only the last row tile is ragged
-        store_tile(std::false_type{});
-      else
-        store_tile(std::true_type{});
+      if constexpr (PLANES) {
+        if (cur.row0 + BM <= a.M) store_planes(std::false_type{});
+        else store_planes(std::true_type{});
+      } else {
+        if (cur.row0 + BM <= a.M)            // workgroup-uniform: only the last row tile is ragged
+          store_tile(std::false_type{});
+        else
+          store_tile(std::true_type{});
+      }
     }
     PSTAMP(6);
     if (!nxt.valid) break;
@@ -528,6 +591,7 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void proj_rows_kernel(RowsArgs a) 
     par ^= 1;
   }
   if (HP && a.out_amax) {                 // one atomic per wave and launch; non-negative floats order as their bits
+    if (PLANES) omax *= 1.f / so;         // recorded in plane units
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) omax = fmaxf(omax, __shfl_xor(omax, o));
     if (lane == 0) atomicMax(reinterpret_cast<unsigned *>(a.out_amax), __builtin_bit_cast(unsigned, omax));
@@ -890,17 +954,14 @@ extern "C" int ampconv_proj_weight_image(const void *W, int64_t stride_n, int64_
   return ampconv_proj_weight_images(1, &job, dtype, stream);
 }
 
-extern "C" int ampconv_proj_rows(const void *A_, int64_t lda, int64_t M, int K, const void *wimage, int N,
-                                 const void *bias_, const int32_t *rowptr, int L, void *out_, int64_t ldc,
-                                 const int32_t *nodes, int64_t n_nodes, const float *a_absmax, float *out_absmax,
-                                 int dtype, void *stream) {
-  if (dtype == AMPCONV_BF16) {
-    if (a_absmax || out_absmax) return AMPCONV_E_DTYPE;           // scaled mode: fp32 storage only
-    return ampconv_proj_rows_bf16(A_, lda, M, K, wimage, N, bias_, rowptr, L, out_, ldc, nodes, n_nodes,
-                                  (hipStream_t)stream);
-  }
-  if (dtype != AMPCONV_F32 || nodes) return AMPCONV_E_DTYPE;      // node lists: bf16 storage only
+// fp32 storage; out_bound != null: plane output (ampconv_proj_rows_planes)
+static int proj_rows_f32(const void *A_, int64_t lda, int64_t M, int K, const void *wimage, int N, const void *bias_,
+                         const int32_t *rowptr, int L, void *out_, int64_t ldc, const float *a_absmax, float *out_absmax,
+                         int amax_col0, const float *out_bound, int row_scale, void *stream) {
   if (out_absmax && !a_absmax) return AMPCONV_E_BADARG;           // recorded by the scaled kernels only
+  // planes: scaled mode, whole 128-byte slots, and the unpadded tile shapes only (N % 128 == 0, K % 32 == 0)
+  if (out_bound && (!a_absmax || N % 128 || K % 32 || ldc % 32)) return AMPCONV_E_BADARG;
+  if (row_scale && !rowptr) return AMPCONV_E_BADARG;
   const float *A = (const float *)A_, *bias = (const float *)bias_;
   float *out = (float *)out_;
   if (M < 0 || !supported_f32(N, K) || lda < K || ldc < N || lda % 4) return AMPCONV_E_BADARG;
@@ -923,7 +984,8 @@ extern "C" int ampconv_proj_rows(const void *A_, int64_t lda, int64_t M, int K, 
   const bool hp = a_absmax != nullptr;                 // scaled two-plane mode: the image's fp16 half and its maximum
   const char *img = (const char *)wimage;
   RowsArgs a{A, lda, M, K, N, hp ? img + image_half_offset(N, K) : img, bias, rowptr, L, out, ldc, (int)rts,
-             rtp * (Np / bn), Kp, Np, a_absmax, (const float *)(img + image_amax_offset(N, K)) + kAmaxParts, out_absmax};
+             rtp * (Np / bn), Kp, Np, a_absmax, (const float *)(img + image_amax_offset(N, K)) + kAmaxParts, out_absmax,
+             amax_col0, out_bound, row_scale};
   const int n_cu = cu_count();
   // a multiple of 8: slot u of a workgroup keeps u % 8 (its XCD label), so "my next slot is invalid" means "nothing
   // further for me" only then (a.tiles is a multiple of 8 by construction)
@@ -934,7 +996,8 @@ extern "C" int ampconv_proj_rows(const void *A_, int64_t lda, int64_t M, int K, 
   const unsigned g = (unsigned)grid;
 #define ROWS_LAUNCH(BM_, BN_, WM_, WN_, NT_)                                                          \
   do {                                                                                                \
-    if (hp && ragged) proj_rows_kernel<BM_, BN_, WM_, WN_, true, true><<<g, NT_, 0, st>>>(a);          \
+    if (out_bound) proj_rows_kernel<BM_, BN_, WM_, WN_, false, true, true><<<g, NT_, 0, st>>>(a); \
+    else if (hp && ragged) proj_rows_kernel<BM_, BN_, WM_, WN_, true, true><<<g, NT_, 0, st>>>(a);     \
     else if (hp) proj_rows_kernel<BM_, BN_, WM_, WN_, false, true><<<g, NT_, 0, st>>>(a);              \
     else if (ragged) proj_rows_kernel<BM_, BN_, WM_, WN_, true, false><<<g, NT_, 0, st>>>(a);          \
     else proj_rows_kernel<BM_, BN_, WM_, WN_, false, false><<<g, NT_, 0, st>>>(a);                     \
@@ -943,6 +1006,104 @@ extern "C" int ampconv_proj_rows(const void *A_, int64_t lda, int64_t M, int K, 
   else if (shape == 1) ROWS_LAUNCH(256, 256, 2, 4, 512);
   else ROWS_LAUNCH(128, 128, 2, 2, 256);
 #undef ROWS_LAUNCH
+  return ampconv_launch_status();
+}
+
+extern "C" int ampconv_proj_rows(const void *A_, int64_t lda, int64_t M, int K, const void *wimage, int N,
+                                 const void *bias_, const int32_t *rowptr, int L, void *out_, int64_t ldc,
+                                 const int32_t *nodes, int64_t n_nodes, const float *a_absmax, float *out_absmax,
+                                 int dtype, void *stream) {
+  if (dtype == AMPCONV_BF16) {
+    if (a_absmax || out_absmax) return AMPCONV_E_DTYPE;           // scaled mode: fp32 storage only
+    return ampconv_proj_rows_bf16(A_, lda, M, K, wimage, N, bias_, rowptr, L, out_, ldc, nodes, n_nodes,
+                                  (hipStream_t)stream);
+  }
+  if (dtype != AMPCONV_F32 || nodes) return AMPCONV_E_DTYPE;      // node lists: bf16 storage only
+  return proj_rows_f32(A_, lda, M, K, wimage, N, bias_, rowptr, L, out_, ldc, a_absmax, out_absmax, 0, nullptr, 0, stream);
+}
+
+extern "C" int ampconv_proj_rows_planes(const void *A, int64_t lda, int64_t M, int K, const void *wimage, int N,
+                                        const void *bias, const int32_t *rowptr, int L, int row_scale, void *out,
+                                        int64_t ldc, const float *a_absmax, const float *out_bound, float *out_absmax,
+                                        int absmax_col0, void *stream) {
+  if (!out_bound || !a_absmax || row_scale < 0 || row_scale > 1 || absmax_col0 < 0) return AMPCONV_E_BADARG;
+  return proj_rows_f32(A, lda, M, K, wimage, N, bias, rowptr, L, out, ldc, a_absmax, out_absmax, absmax_col0, out_bound,
+                       row_scale, stream);
+}
+
+// bound of the magnitudes of out = A W^T + bias from the largest magnitude of A: a_absmax * max_n sum_k |W[n][k]| +
+// max_n |bias[n]| (W[n][k] at W[n * stride_n + k * stride_k]) -- what the plane output of proj_rows scales by, known
+// BEFORE the product runs.  One workgroup: the weights are a few hundred KB.
+namespace {
+__global__ __launch_bounds__(1024) void out_bound_kernel(const float *__restrict__ W, int64_t sn, int64_t sk, int N, int K,
+                                                         const float *__restrict__ bias, const float *__restrict__ amax,
+                                                         float *__restrict__ out) {
+  __shared__ float red[2][16];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float l1 = 0.f, bm = 0.f;
+  for (int n = w; n < N; n += 16) {
+    float sum = 0.f;
+    for (int k = lane; k < K; k += 64) sum += finite_abs(W[(int64_t)n * sn + (int64_t)k * sk]);
+    l1 = fmaxf(l1, wave_sum(sum));
+  }
+  if (bias)
+    for (int n = threadIdx.x; n < N; n += 1024) bm = fmaxf(bm, finite_abs(bias[n]));
+  bm = wave_max(bm);
+  if (lane == 0) { red[0][w] = l1; red[1][w] = bm; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int i = 1; i < 16; ++i) { l1 = fmaxf(l1, red[0][i]); bm = fmaxf(bm, red[1][i]); }
+    out[0] = *amax * l1 + bm;
+  }
+}
+}  // namespace
+
+extern "C" int ampconv_proj_out_bound(const void *W, int64_t stride_n, int64_t stride_k, int N, int K, const void *bias,
+                                      const float *a_absmax, float *out, void *stream) {
+  if (!W || !a_absmax || !out || N <= 0 || K <= 0) return AMPCONV_E_BADARG;
+  out_bound_kernel<<<1, 1024, 0, (hipStream_t)stream>>>((const float *)W, stride_n, stride_k, N, K, (const float *)bias,
+                                                        a_absmax, out);
+  return ampconv_launch_status();
+}
+
+// plane slots -> fp32, in place layout (the reverse of the PLANES epilogue; the lazily served side outputs and the
+// fall-back paths read the projection buffer as fp32): X[M, K] with K a multiple of 32, rows ld floats apart
+namespace {
+__global__ __launch_bounds__(256) void planes_to_f32_kernel(const char *__restrict__ X, int64_t ld, int64_t M, int K32,
+                                                            const float *__restrict__ bound, float *__restrict__ out,
+                                                            int64_t ldo) {
+  const float u = 1.f / plane_scale(*bound);
+  const int64_t total = M * K32 * 4;                       // 8-channel pieces
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t row = i / (K32 * 4);
+    const int r = (int)(i - row * (K32 * 4)), slot = r >> 2, c = r & 3;
+    const char *src = X + (row * ld + slot * 32) * 4 + 16 * c;
+    const uint4 h = *reinterpret_cast<const uint4 *>(src), l = *reinterpret_cast<const uint4 *>(src + 64);
+    const unsigned hu[4] = {h.x, h.y, h.z, h.w}, lu[4] = {l.x, l.y, l.z, l.w};
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const f16x2 hv = __builtin_bit_cast(f16x2, hu[k]), lv = __builtin_bit_cast(f16x2, lu[k]);
+      v[2 * k] = ((float)hv[0] + (float)lv[0]) * u;
+      v[2 * k + 1] = ((float)hv[1] + (float)lv[1]) * u;
+    }
+    float *o = out + row * ldo + slot * 32 + 8 * c;
+    *reinterpret_cast<float4 *>(o) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4 *>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  }
+}
+}  // namespace
+
+extern "C" int ampconv_planes_to_f32(const void *X, int64_t ld, int64_t M, int K, const float *bound, void *out,
+                                     int64_t ldo, void *stream) {
+  if (M < 0 || K <= 0 || K % 32 || ld < K || ldo < K || ld % 4 || ldo % 4 || !bound) return AMPCONV_E_BADARG;
+  if (M == 0) return AMPCONV_OK;
+  if (!X || !out || (uintptr_t)X % 16 || (uintptr_t)out % 16) return AMPCONV_E_BADARG;
+  const int64_t pieces = M * (K / 8);
+  int64_t grid = (pieces + 255) / 256;
+  const int64_t cap = (int64_t)cu_count() * 16;
+  if (grid > cap) grid = cap;
+  planes_to_f32_kernel<<<(unsigned)grid, 256, 0, (hipStream_t)stream>>>((const char *)X, ld, M, K / 32, bound, (float *)out, ldo);
   return ampconv_launch_status();
 }
 
@@ -1003,6 +1164,69 @@ extern "C" int ampconv_absmax(const void *X, int64_t ld, int64_t M, int K, int d
     absmax_kernel<float><<<(unsigned)grid, 256, 0, st>>>((const float *)X, ld, M, K / epp, out);
   else
     absmax_kernel<unsigned short><<<(unsigned)grid, 256, 0, st>>>((const unsigned short *)X, ld, M, K / epp, out);
+  return ampconv_launch_status();
+}
+
+// the same pass with a RANGE statistic beside the maximum (fp32): out[0] = largest finite magnitude, out[1] = the smallest
+// non-zero maximum of any group of 8 consecutive 16-byte pieces (32 channels: one head slot of a row where K % 32 == 0).
+// out[1] far below out[0] means whole rows / heads live binades under the tensor's maximum -- the data on which ONE scale
+// per tensor costs the small rows their low plane (include/ampconv.h "SCALED MODE"); the caller then takes the exact
+// kernels.  Single elements near zero do not count (absolute error is what a sum feels), all-zero groups neither.
+namespace {
+__global__ void absmax_stats_init_kernel(float *out) {
+  out[0] = 0.f;
+  out[1] = __builtin_inff();
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_get(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+__global__ __launch_bounds__(256) void absmax_stats_kernel(const float *__restrict__ X, int64_t ld, int64_t M, int K4,
+                                                           float *__restrict__ out) {
+  const int64_t total = M * K4;
+  float m = 0.f, smin = __builtin_inff();
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t row = i / K4;
+    const int c = (int)(i - row * K4);
+    const float4 v = *reinterpret_cast<const float4 *>(X + row * ld + (int64_t)c * 4);
+    const float m4 = finite_abs_max(0.f, v);
+    m = fmaxf(m, m4);
+    float g = fmaxf(m4, dpp_get<0xB1>(m4));     // quad_perm [1,0,3,2]
+    g = fmaxf(g, dpp_get<0x4E>(g));             // quad_perm [2,3,0,1]
+    g = fmaxf(g, dpp_get<0x141>(g));            // row_half_mirror: the 8 lanes of a half row (masked lanes read as 0)
+    if (g > 0.f) smin = fminf(smin, g);
+  }
+  __shared__ float red[2][4];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    m = fmaxf(m, __shfl_xor(m, o));
+    smin = fminf(smin, __shfl_xor(smin, o));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = m;
+    red[1][threadIdx.x >> 6] = smin;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+    smin = fminf(fminf(red[1][0], red[1][1]), fminf(red[1][2], red[1][3]));
+    atomicMax(reinterpret_cast<unsigned *>(out), __builtin_bit_cast(unsigned, m));          // non-negative floats order
+    atomicMin(reinterpret_cast<unsigned *>(out + 1), __builtin_bit_cast(unsigned, smin));   // as their bits
+  }
+}
+}  // namespace
+
+extern "C" int ampconv_absmax_stats(const void *X, int64_t ld, int64_t M, int K, float *out, void *stream) {
+  if (!out || M < 0 || K < 0 || K % 4 || ld < K || ld % 4) return AMPCONV_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  absmax_stats_init_kernel<<<1, 1, 0, st>>>(out);
+  if (M == 0 || K == 0) return ampconv_launch_status();
+  if (!X || (uintptr_t)X % 16) return AMPCONV_E_BADARG;
+  const int64_t pieces = M * (K / 4);
+  int64_t grid = (pieces + 255) / 256;
+  const int64_t cap = (int64_t)cu_count() * 16;
+  if (grid > cap) grid = cap;
+  absmax_stats_kernel<<<(unsigned)grid, 256, 0, st>>>((const float *)X, ld, M, K / 4, out);
   return ampconv_launch_status();
 }
 

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define AMPCONV_VERSION 105
+#define AMPCONV_VERSION 106
 
 enum {
   AMPCONV_OK = 0,
@@ -179,6 +179,36 @@ int ampconv_bwd_edge_src(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
                          void *hub_ws, const float *stats, float *out_absmax, int dtype,
                          void *stream);
 
+/* ---- edge phase on fp16 PLANES: fp32-grade results off the FP32 pipe (csrc/edge_mfma_f16x2.hip, ABI 106) --------
+ * The same three passes (same reference arithmetic: torch functional.py:6578-6594 per edge, amp_conv.py:11, SURVEY.md
+ * A.2) for L <= 20, dh = 32, with Q, K, V and dObar in the PLANE FORMAT: the 128-byte slot of the 32 fp32 channels of
+ * one (token row, head) holds 32 fp16 `hi` then 32 fp16 `lo` with hi + lo = x * 2^e (to 2^-22 |x|, absolute 2^-25 in
+ * scaled units below that), ONE exponent per tensor: e = 14 - floor(log2 bound) for a device-side upper bound of the
+ * tensor's magnitudes -- bounds[0] for Q | K | V (written by ONE ampconv_proj_rows_planes call), bounds[1] for dObar.
+ * Views keep the strides, in 4-byte elements, of the fp32 tensor the planes replace; head_stride must be 32.  Every
+ * product is the fp32 sum of three v_mfma_f32_16x16x32_f16 partial products (dropped: lo x lo <= 2^-22 of the product),
+ * softmax and all sums are fp32, the outputs (Obar, dQ, dK, dV) plain fp32 views.
+ * dObar must arrive DIVIDED by the in-degree of its node (ampconv_proj_rows_planes, row_scale = 1): the passes carry no
+ * per-edge weight.  No softmax statistics.  out_absmax as above (both backward passes record it themselves).
+ * planes_supported: 1 if (L, D, H) is served.  Same accuracy class as the fp32 kernels on tensors whose rows lie
+ * within ~2^12 of the tensor's maximum (ampconv_absmax_stats measures exactly that; callers fall back to the fp32
+ * entry points otherwise).  */
+int ampconv_planes_supported(int L, int D, int H);
+int ampconv_fwd_edge_planes(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
+                            const int32_t *rowptr, const int32_t *col, int64_t n_rows, int L, int D,
+                            int H, ampconv_view_t O, const void *hub_plan, int64_t hub_chunks,
+                            void *hub_ws, const float *bounds, void *stream);
+int ampconv_bwd_edge_dst_planes(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
+                                ampconv_view_t dObar, const int32_t *rowptr, const int32_t *col,
+                                int64_t n_rows, int L, int D, int H, ampconv_view_t dQ,
+                                const void *hub_plan, int64_t hub_chunks, void *hub_ws,
+                                const float *bounds, float *out_absmax, void *stream);
+int ampconv_bwd_edge_src_planes(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
+                                ampconv_view_t dObar, const int32_t *cscptr, const int32_t *crow,
+                                int64_t n_src, int L, int D, int H, ampconv_view_t dK,
+                                ampconv_view_t dV, const void *hub_plan, int64_t hub_chunks,
+                                void *hub_ws, const float *bounds, float *out_absmax, void *stream);
+
 /* ---- per-edge side outputs, ORIGINAL edge order ------------------------------
  * attn_weights: W[e] = mean_h softmax_rows(Q[dst e,:,h] K[src e,:,h]^T/sqrt(dh)),
  * [E, L, L] fp32 -- `self.attn_output_weights` (amp_conv.py:39,43-47; torch
@@ -302,6 +332,28 @@ int ampconv_proj_wgrad(const void *A, int64_t lda, const void *B, int64_t ldb, i
                        const float *a_absmax, const float *b_absmax, int dtype, void *stream);
 int ampconv_absmax(const void *X, int64_t ld, int64_t M, int K, int dtype, float *out, int reset,
                    void *stream);
+/* PLANE OUTPUT (fp32 storage, scaled mode; N % 128 == 0, K % 32 == 0, ldc % 32 == 0): proj_rows whose result leaves in
+ * the plane format of the edge kernels above instead of fp32 -- same bytes, same layout of 128-byte slots.
+ *   proj_out_bound  : out[0] = *a_absmax * max_n sum_k |B[n][k]| + max_n |bias[n]| (B as in proj_weight_image): an upper
+ *                     bound of |A B^T + bias| that is known BEFORE the product runs; the scale of its planes
+ *   proj_rows_planes: as proj_rows; `out_bound` = that device float; row_scale = 1 (with rowptr): rows are also DIVIDED
+ *                     by their node's segment length (dObar / in-degree); out_absmax (may be NULL) records the largest
+ *                     finite magnitude of the fp32 values behind the planes over the columns >= absmax_col0 only (the V
+ *                     third of a packed in-projection bounds Obar, a mean of convex combinations of V rows)
+ *   planes_to_f32   : the reverse: out[m, k] = (hi + lo) * 2^-e of X[M, K] in plane format (side outputs, fall-backs)
+ *   absmax_stats    : out[0] = largest finite magnitude of X[M, K] (fp32), out[1] = the smallest NON-ZERO maximum of any
+ *                     group of 8 consecutive 16-byte pieces (32 channels: a head slot); out[1] * 2^12 < out[0] says that
+ *                     whole rows / heads lie far below the tensor's maximum: one scale per tensor then costs them their
+ *                     low plane and the caller should use the exact kernels (six-product projections, fp32 edge passes)  */
+int ampconv_proj_out_bound(const void *W, int64_t stride_n, int64_t stride_k, int N, int K,
+                           const void *bias, const float *a_absmax, float *out, void *stream);
+int ampconv_proj_rows_planes(const void *A, int64_t lda, int64_t M, int K, const void *wimage, int N,
+                             const void *bias, const int32_t *rowptr, int L, int row_scale, void *out,
+                             int64_t ldc, const float *a_absmax, const float *out_bound,
+                             float *out_absmax, int absmax_col0, void *stream);
+int ampconv_planes_to_f32(const void *X, int64_t ld, int64_t M, int K, const float *bound, void *out,
+                          int64_t ldo, void *stream);
+int ampconv_absmax_stats(const void *X, int64_t ld, int64_t M, int K, float *out, void *stream);
 
 /* ---- GraphSAINT random-walk sampler ("next" row: the step before the hot path) -------------
  * In-tree spec: the reference's vendored PyG sampler, visualization/visualize_graphsaint_subgraphs.py

@@ -142,8 +142,8 @@ def test_bench_node_phase_roofline_object(monkeypatch):
 def test_register_budgets_of_the_kernels_that_must_not_spill():
     """hipcc's kernel-resource-usage remarks, kept by __graft_entry__.build() in build/obj/*.usage.json.
     * proj_rows_kernel streams its rows with inline-assembly loads whose waits are counted by hand: a register spilled
-      between such a load and its wait would be saved before the data has landed.  The shipped variants spill nothing
-      but one address pair in the prologue of the two ragged six-product shapes (checked in the ISA: not a row register).
+      between such a load and its wait would be saved before the data has landed.  Every variant with assembly loads
+      spills nothing; the two ragged six-product shapes, which do spill, keep compiler-managed loads (kAsmRows).
     * bwd_src_mfma_t4 / bwd_dst_mfma_t4 (config 4's dominant kernels) run at three waves per SIMD, i.e. at most 168
       registers, and a spill reload inside their edge loop carries a vmcnt(0) that drains the prefetched tiles
       (measured: +4.5 % with two spilled registers)."""
@@ -154,15 +154,26 @@ def test_register_budgets_of_the_kernels_that_must_not_spill():
     files = glob.glob(os.path.join(root, 'build', 'obj', '*.usage.json'))
     if not files:
         import pytest
+        # a library built in-tree without its usage records is a broken build, not a reason to skip
+        # (on the GPU box neither travels -- build/obj is scratch there -- and the skip stands)
+        assert not glob.glob(os.path.join(root, 'build', 'obj', '*.o')), \
+            'build/obj holds objects but no *.usage.json: rebuild with __graft_entry__.build(force=True)'
         pytest.skip('no build/obj/*.usage.json: run __graft_entry__.build() first')
     usage = {}
     for f in files:
         usage.update(json.load(open(f)))
     rows = {k: v for k, v in usage.items() if 'proj_rows_kernel' in k and 'bf16' not in k}
-    assert len(rows) == 12
+    assert len(rows) == 15              # 3 tile shapes x (ragged x {six products, scaled} + plane output)
     for k, v in rows.items():
-        ragged_six = 'ELb1ELb0EEEv' in k                      # <..., RAGGED = true, HP = false>
-        assert v['spill'] <= (2 if ragged_six else 0), (k, v)
+        ragged_six = 'ELb1ELb0ELb0EEEv' in k                  # <..., RAGGED = true, HP = false, PLANES = false>
+        assert ragged_six or v['spill'] == 0, (k, v)          # (ragged six-product: compiler-managed loads, spills are safe)
+    # the plane-format edge kernels (config 4's edge phase since round 5): forward at four waves per SIMD, both backward
+    # passes at three, nothing spilled
+    for name, budget in (('fwd_f16x2', 128), ('bwd_dst_f16x2', 168), ('bwd_src_f16x2', 168)):
+        ks = [k for k in usage if name in k]
+        assert len(ks) == 2, (name, ks)
+        for k in ks:
+            assert usage[k]['spill'] == 0 and usage[k]['vgprs'] <= budget, (k, usage[k])
     hot = [k for k in usage if ('bwd_src_mfma_t4ILi32ELb1ELb1E' in k or 'bwd_dst_mfma_t4ILi32ELb1ELb1ELb1E' in k
                                 or 'fwd_mfma_t4ILi32ELb1ELb1E' in k)]
     assert len(hot) == 3, hot
