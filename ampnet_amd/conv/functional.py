@@ -368,14 +368,17 @@ class AMPConvFunction(torch.autograd.Function):
                 if narrow and not shared:
                     stk, narrow = operand_stats(xkv2, key=xkv)
                 if narrow:
-                    am = [st[0:1], torch.zeros(1, dtype=torch.float32, device=xq.device), None if shared else stk[0:1]]
                     planes = planes_ok(L, D, H, shared)
+                    # device scalars of the plane format (include/ampconv.h): [bound of Q|K|V, bound of dObar, recorded
+                    # max |V|, recorded max |dObar|]; max |V| doubles as the operand maximum of Obar (am[1])
+                    bounds = torch.zeros(4, dtype=torch.float32, device=xq.device) if planes else None
+                    am = [st[0:1], bounds[2:3] if planes else torch.zeros(1, dtype=torch.float32, device=xq.device),
+                          None if shared else stk[0:1]]
             sl = (lambda i: am[i]) if am is not None else (lambda i: None)
             if planes:
                 # Q | K | V leave the in-projection as two fp16 planes scaled by a bound known before the product runs
                 # (max |x| times the largest absolute row sum of W, plus max |b|); the recorded maximum covers the V third
                 # only: it bounds Obar, a mean of convex combinations of V rows
-                bounds = torch.empty(2, dtype=torch.float32, device=xq.device)
                 proj_out_bound(w_in, False, b_in, am[0], bounds[0:1])
                 qkv = proj_rows_planes(xq2, imgs[0], bounds[0:1], b_in, amax=am[0], out_amax=am[1], amax_col0=2 * D)
                 Qv, Kv, Vv = (_view(qkv, i * D, L, dh) for i in range(3))
@@ -468,8 +471,9 @@ class AMPConvFunction(torch.autograd.Function):
                 elif planes:    # dObar / in-degree as two fp16 planes (the edge passes then carry no per-edge weight)
                     proj_wgrad(dy2, obar, dw_out, db_out, csr.rowptr, L, amax=pair(sl(ag, 0), sl(am, 1)))
                     proj_out_bound(w_out, True, None, ag[0], bounds[1:2])
+                    bounds[3:4].zero_()
                     dobar = proj_rows_planes(dy2, ctx.images_t[-1], bounds[1:2], rowptr=csr.rowptr, L=L, row_scale=1,
-                                             amax=ag[0])
+                                             amax=ag[0], out_amax=bounds[3:4])
                 else:
                     proj_wgrad(dy2, obar, dw_out, db_out, csr.rowptr, L, amax=pair(sl(ag, 0), sl(am, 1)))
                     dobar = proj_rows(dy2, ctx.images_t[-1], amax=sl(ag, 0))

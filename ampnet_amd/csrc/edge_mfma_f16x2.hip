@@ -46,10 +46,13 @@ constexpr int kLoOff = kPlaneBytes + 64;               // 1344
 constexpr int kTileBytes = kLoOff + kPlaneBytes;       // 2624 (a multiple of 16)
 constexpr float kPScale = 16384.f;                     // softmax weights (<= 1) are split as P * 2^14
 constexpr float kPUnscale = 1.f / 16384.f;
-// dS = P (dP - delta) in the units of dP' = dO' V'^T: |dO'|, |V'| < 2^15, 32 channels, |dP - delta| <= 2 max |dP|:
-// below 2^36, so dS * 2^-21 < 2^15
-constexpr float kSScale = 1.f / 2097152.f;             // 2^-21
-constexpr float kSUnscale = 2097152.f;
+// dS = P (dP - delta), in the units of dP' = dO' V'^T, is split with ONE power-of-two scale per unit from a bound of
+// what the unit can see: |dP'_ij| <= |dO'_i| |V'_j| (Cauchy-Schwarz over the 32 channels), |dP - delta| <= 2 max |dP|,
+// P <= 1.  The unit's OWN side enters with the largest token-row norm it really has (computed once per unit from its
+// hi plane), the streamed side with sqrt(32) x the recorded maximum of its tensor.  (The a-priori worst case --
+// 32 channels at 2^15 each -- is 2^17 above typical data: scaled by it, dS sits at 2^-9 and its low plane is a
+// subnormal with four bits left.  Measured: dx error 4e-6 of the maximum instead of 8e-7.)
+constexpr float kSqrtDh = 5.656854249492381f;
 // mask value of the softmaxes: the scores here are in the units of Q' K'^T and meet their scale only inside the
 // exponential, so a large finite mask (kNegBig) could be scaled back into range; -inf stays -inf (every column / row
 // has at least one finite score: token 0)
@@ -82,6 +85,28 @@ __device__ __forceinline__ void split2(float x0, float x1, int &h, int &l) {
   h = cvt_pk_f16(x0, x1);
   const f16x2 hv = __builtin_bit_cast(f16x2, h);
   l = cvt_pk_f16(x0 - (float)hv[0], x1 - (float)hv[1]);
+}
+
+// sum of squares of the 8 fp16 values of a fragment register quadruple (v_dot2_f32_f16)
+__device__ __forceinline__ float frag_sumsq(const i32x4 &f) {
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const f16x2 v = __builtin_bit_cast(f16x2, f[k]);
+    s = __builtin_amdgcn_fdot2(v, v, s, false);
+  }
+  return s;
+}
+// largest token-row norm^2 of a tile given as its two channel-product fragments (lane (n, kg) = 8 channels of the token
+// of column n): wave-uniform
+__device__ __forceinline__ float tile_max_norm2(const i32x4 &f0, const i32x4 &f1) {
+  const float t = fmaxf(groups_sum(frag_sumsq(f0)), groups_sum(frag_sumsq(f1)));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, row16_max(t))));
+}
+// scale of dS for a unit whose own side has largest row norm^2 `own2` and whose streamed side is bounded by `other`
+// per element (both in plane units): dS * scale < 2^15
+__device__ __forceinline__ float ds_scale(float own2, float other) {
+  return plane_scale(2.f * __builtin_sqrtf(own2) * (kSqrtDh * other));
 }
 
 // byte offset of 16-byte chunk `ch` (0..3) of token row `j` in a plane image (the swizzle of edge_mfma_bf16.hip)
@@ -207,7 +232,8 @@ __device__ __forceinline__ void column_softmax(f32x4 &t0, f32x4 &t1, float sc, f
 struct Args {
   ampconv_view_t Q, K, V, dO, O, dK, dV;   // O = forward output / dQ (fp32); Q, K, V, dO: planes
   const int32_t *ptr, *idx;
-  const float *bounds;                      // device: {bound of |Q|K|V|, bound of |dObar|}: the planes' scales
+  const float *bounds;                      // device: {bound of |Q|K|V|, bound of |dObar|: the planes' scales;
+                                            //          recorded max |V|, recorded max |dObar|: the scale of dS}
   float *absmax;                            // or null: atomic max of the finite magnitudes written (backward passes)
   HubArgs hub;
   int64_t n_units;
@@ -357,6 +383,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 3) void bwd_dst_f16x2(Args a) 
       gl[nt] = rowfrag_global(gb, grb, nt, 64, L, lane);
     }
   }
+  // dS scale of this unit: its own dObar rows against the bound of any V row
+  const float ss = ds_scale(tile_max_norm2(gh[0], gh[1]), a.bounds[2] * plane_scale(a.bounds[0]));
   if (!FULL) lds_zero(Kt, 2 * kTileBytes, lane);
   f32x4 dQT[2][2];
 #pragma unroll
@@ -398,8 +426,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 3) void bwd_dst_f16x2(Args a) 
       for (int q = 0; q < 4; ++q) part = fmaf(S[0][nt][q], dP[0][nt][q], part);
       const float delta = groups_sum(part);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) S[0][nt][q] *= (dP[0][nt][q] - delta) * kSScale;      // dS^T * 2^-21 (units of dP')
-      S[1][nt][0] *= (dP[1][nt][0] - delta) * kSScale;
+      for (int q = 0; q < 4; ++q) S[0][nt][q] *= (dP[0][nt][q] - delta) * ss;      // dS^T in the unit's split scale
+      S[1][nt][0] *= (dP[1][nt][0] - delta) * ss;
       cd_frag2(S[0][nt], S[1][nt][0], sh[nt], sl[nt]);
     }
     i32x4 ch[2], cl[2];
@@ -415,10 +443,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 3) void bwd_dst_f16x2(Args a) 
       for (int nt = 0; nt < 2; ++nt) dQT[mc][nt] = mfma3(ch[mc], cl[mc], sh[nt], sl[nt], dQT[mc][nt]);
     __builtin_amdgcn_wave_barrier();
   }
-  // dQ = sum dS K / sqrt(dh): undo 2^-21, the scales of dP' (Q|K|V and dObar) and of K'; the hub pass leaves 1/sqrt(dh)
-  // to the combine pass
+  // dQ = sum dS K / sqrt(dh): undo the split scale, the scales of dP' (Q|K|V and dObar) and of K'; the hub pass leaves
+  // 1/sqrt(dh) to the combine pass
   const bool hubp = a.hub.mode == 2;
-  const float m = store_tile<false>(a.O, onode, h, dQT, ((kSUnscale * uq) * ug) * uq * (hubp ? 1.f : 0.17677669529663687f),
+  const float m = store_tile<false>(a.O, onode, h, dQT, (((1.f / ss) * uq) * ug) * uq * (hubp ? 1.f : 0.17677669529663687f),
                                     L, lane);
   if (a.absmax) wave_record_absmax(a.absmax, m);
 }
@@ -452,6 +480,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 3) void bwd_src_f16x2(Args a) 
   pair_load_p<FULL>(qg, slot_ptr(a.K, s, h), (unsigned)a.K.row_stride * 4u, slot_ptr(a.V, s, h),
                     (unsigned)a.V.row_stride * 4u, L, lane);
   pair_to_lds_p<FULL>(Ko, qg, L, lane);
+  __builtin_amdgcn_wave_barrier();
+  // dS scale of this unit: its own V rows against the bound of any dObar row
+  const float ss = ds_scale(tile_max_norm2(rowfrag(Vo, 0, lane), rowfrag(Vo, 1, lane)), a.bounds[3] * plane_scale(a.bounds[1]));
   f32x4 dKT[2][2], dVT[2][2];
 #pragma unroll
   for (int mc = 0; mc < 2; ++mc)
@@ -497,7 +528,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 3) void bwd_src_f16x2(Args a) 
     }
     // row softmax over the source tokens (columns across the 16 lanes of a DPP row); rows: tile 0 reg q = destination
     // token 4 g + q, tile 1 reg 0 = token 16 + g (quarter map).  After this block S holds P * 2^14 (for dV) and dP holds
-    // dS * 2^-21.
+    // dS in the unit's split scale.
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
@@ -511,8 +542,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 3) void bwd_src_f16x2(Args a) 
         const float delta = row16_sum(fmaf(p0, dP[mt][0][q], p1 * dP[mt][1][q]));
         S[mt][0][q] = p0 * kPScale;
         S[mt][1][q] = p1 * kPScale;
-        dP[mt][0][q] = p0 * (dP[mt][0][q] - delta) * kSScale;
-        dP[mt][1][q] = p1 * (dP[mt][1][q] - delta) * kSScale;
+        dP[mt][0][q] = p0 * (dP[mt][0][q] - delta) * ss;
+        dP[mt][1][q] = p1 * (dP[mt][1][q] - delta) * ss;
       }
     }
     {
@@ -549,7 +580,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 3) void bwd_src_f16x2(Args a) 
   }
   // dK = sum dS^T Q / sqrt(dh), dV = sum P^T dObar (1/deg is inside dObar); the hub pass leaves 1/sqrt(dh) to the combine
   const bool hubp = a.hub.mode == 2;
-  float m = store_tile<true>(a.dK, onode, h, dKT, ((kSUnscale * uq) * ug) * uq * (hubp ? 1.f : 0.17677669529663687f), L, lane);
+  float m = store_tile<true>(a.dK, onode, h, dKT, (((1.f / ss) * uq) * ug) * uq * (hubp ? 1.f : 0.17677669529663687f), L, lane);
   m = fmaxf(m, store_tile<true>(a.dV, onode, h, dVT, kPUnscale * ug, L, lane));
   if (a.absmax) wave_record_absmax(a.absmax, m);
 }

@@ -73,10 +73,14 @@ class KernelTimer:
 
     def __init__(self):
         self.events = {}
+        self.entry_points = set()
         self.enabled = False
 
-    def wrap(self, lib, name):
+    def wrap(self, lib, name, key=None):
+        """Events around C entry point `name`, filed under `key` (the plane-format edge passes of ABI 106 are filed under
+        the name of the fp32 entry point whose work they do; `entry_points` keeps what really ran)."""
         fn = getattr(lib, name)
+        key = key or name
 
         def timed(*args):
             if not self.enabled:
@@ -86,7 +90,8 @@ class KernelTimer:
             e0.record()
             rc = fn(*args)
             e1.record()
-            self.events.setdefault(name, []).append((e0, e1))
+            self.events.setdefault(key, []).append((e0, e1))
+            self.entry_points.add(name)
             return rc
         return timed
 
@@ -99,6 +104,7 @@ class TimedLib:
         self._lib = lib
         for n in ('ampconv_fwd_edge', 'ampconv_bwd_edge_dst', 'ampconv_bwd_edge_src'):
             setattr(self, n, timer.wrap(lib, n))
+            setattr(self, n + '_planes', timer.wrap(lib, n + '_planes', key=n))
 
     def __getattr__(self, name):
         return getattr(self._lib, name)
@@ -423,7 +429,8 @@ def measure_saint(workload, steps, warmup, args, rank, world, dev, dist_on, dt_n
                                f'build of the subgraph' + (' + RCCL grad all-reduce' if world > 1 else ''),
                    'N': N, 'E': E, 'L': L, 'D': D, 'H': H, 'roots': roots, 'walk_length': walk,
                    'parallelism': f'dp{world}', 'gemm': args.gemm if dt_name == 'f32' else 'bf16',
-                   'projections': _projection_note(dt_name, args.gemm)},
+                   'projections': _projection_note(dt_name, args.gemm),
+                   'edge_entry_points': sorted(timer.entry_points)},
         'nodes_avg': n_avg, 'edges_avg': e_avg, 'sampler_ms': sampler_ms, 'allreduce_ms': ar_ms,
         'batch': {'nodes_avg': n_avg, 'edges_avg': e_avg, 'sampler_ms': sampler_ms,
                   'sampler_share_of_step': sampler_ms / (1e3 * t_step),
@@ -528,7 +535,10 @@ def measure_full(workload, steps, warmup, args, rank, world, dev, dist_on, dt_na
                                   f'one graph per GPU' + (' + RCCL grad all-reduce' if world > 1 else ''),
                       'N': N, 'E': E, 'L': L, 'D': D, 'H': H, 'parallelism': f'dp{world}',
                       'gemm': args.gemm if dt_name == 'f32' else 'bf16',
-                      'projections': _projection_note(dt_name, args.gemm)}}
+                      'projections': _projection_note(dt_name, args.gemm),
+                      # which C entry points the timed edge calls were (kernels_ms files the plane-format passes of ABI
+                      # 106 -- fp16 planes, 16-bit matrix pipe -- under the fp32 entry point whose work they do)
+                      'edge_entry_points': sorted(timer.entry_points)}}
     if args.softmax_free:
         # the edge phase of this variant is one segment reduction (conv/linear.py): no edge-kernel roofline
         out['metric'] += ', softmax-free variant'
@@ -545,6 +555,10 @@ def measure_full(workload, steps, warmup, args, rank, world, dev, dist_on, dt_na
     if lists:      # in-projection + its two gradients over the nodes with any edge, out-projection + its two over the receivers
         flops_proj = L * D * D * (18 * lists['any'] + 6 * lists['in'])
     mfma_peak = MFMA_PEAK_TFLOPS[dt_name]
+    planes_ran = any(n.endswith('_planes') for n in timer.entry_points)
+    # the arithmetic peak of the dominant EDGE kernel: fp32-input MFMA = the vector rate; the plane-format passes issue
+    # three 16-bit matrix products per fp32 product
+    edge_peak = MFMA_PEAK_TFLOPS['bf16'] / 3 if planes_ran else mfma_peak
     t_step = dt / steps
     t_hbm, t_mfma = b_alg / (HBM_PEAK_GBS * 1e9), (flops_attn + flops_proj) / (mfma_peak * 1e12)
     traffic = traffic_source = None                        # PMC-measured HBM bytes per launch
@@ -590,8 +604,8 @@ def measure_full(workload, steps, warmup, args, rank, world, dev, dist_on, dt_na
                      'algorithmic_bytes_per_launch': alg[dom], 'avg_launch_ms': ms[dom],
                      # the same launch against the arithmetic peak (fp32: MFMA and VALU share the FP32 pipe)
                      'arithmetic': {'flops_per_launch': kflops[dom], 'achieved_TFLOPs': kflops[dom] / (ms[dom] * 1e-3) / 1e12,
-                                    'peak_TFLOPs': mfma_peak,
-                                    'frac': kflops[dom] / (ms[dom] * 1e-3) / 1e12 / mfma_peak}},
+                                    'peak_TFLOPs': edge_peak,
+                                    'frac': kflops[dom] / (ms[dom] * 1e-3) / 1e12 / edge_peak}},
     })
     if alt_out is not None:
         out['alt_gemm'] = alt_out

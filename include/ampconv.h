@@ -185,6 +185,9 @@ int ampconv_bwd_edge_src(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
  * one (token row, head) holds 32 fp16 `hi` then 32 fp16 `lo` with hi + lo = x * 2^e (to 2^-22 |x|, absolute 2^-25 in
  * scaled units below that), ONE exponent per tensor: e = 14 - floor(log2 bound) for a device-side upper bound of the
  * tensor's magnitudes -- bounds[0] for Q | K | V (written by ONE ampconv_proj_rows_planes call), bounds[1] for dObar.
+ * `bounds` (device, 4 floats) also carries what the backward passes scale dS = P (dP - delta) by before they split it:
+ * bounds[2] = the largest |V| and bounds[3] = the largest |dObar| (true fp32 magnitudes, as recorded by the out_absmax
+ * of the two ampconv_proj_rows_planes calls; any upper bound serves).  The forward pass reads bounds[0] only.
  * Views keep the strides, in 4-byte elements, of the fp32 tensor the planes replace; head_stride must be 32.  Every
  * product is the fp32 sum of three v_mfma_f32_16x16x32_f16 partial products (dropped: lo x lo <= 2^-22 of the product),
  * softmax and all sums are fp32, the outputs (Obar, dQ, dK, dV) plain fp32 views.
