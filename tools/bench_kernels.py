@@ -1,6 +1,9 @@
 """Developer micro-benchmark: time each C-ABI edge kernel on a synthetic uniform graph.
 
-    python tools/bench_kernels.py [N E L D H] [--generic] [--bf16] [--hub] [--rmat] [--compact] [--absmax]
+    python tools/bench_kernels.py [N E L D H] [--generic] [--bf16] [--hub] [--rmat] [--compact] [--absmax] [--planes]
+
+--planes: the plane-format passes of ABI 106 (csrc/edge_mfma_f16x2.hip) on the same random tensors, converted to two
+fp16 planes here (bounds 12 x the maxima, about what the a-priori bound of the projection gives).
 """
 import os
 import sys
@@ -123,6 +126,34 @@ def main():
         _lib.check(lib.ampconv_bwd_edge_src(Qv, Kv, Vv, dOv, csr.cscptr.data_ptr(), csr.crow.data_ptr(),
                                             csr.cinv.data_ptr(), N, L, D, H, dKv, dVv, *hub('src', 2), sp[1],
                                             amax, dt, st), 'bwd_src')
+
+    if '--planes' in sys.argv:
+        import math
+
+        def to_planes(t2, bound):                  # [M, W] fp32 -> the 128-byte slots of include/ampconv.h
+            sc = 2.0 ** (14 - math.floor(math.log2(bound)))
+            xs = (t2 * sc).view(t2.size(0), -1, 32)
+            hi = xs.half()
+            lo = (xs - hi.float()).half()
+            return torch.cat([hi, lo], dim=2).contiguous().view(torch.float32).view(t2.size(0), -1)
+        mq, mg = float(qkv.abs().max()), float(dobar.abs().max())
+        bounds = torch.tensor([12 * mq, 12 * mg, mq, mg], device=dev)
+        pq, pg = to_planes(qkv, 12 * mq), to_planes(dobar, 12 * mg)
+        pQ, pK, pV = (F_._view(pq, i * D, L, dh) for i in range(3))
+        pG = F_._view(pg, 0, L, dh)
+
+        def fwd():
+            _lib.check(lib.ampconv_fwd_edge_planes(pQ, pK, pV, csr.rowptr.data_ptr(), csr.col.data_ptr(), N, L, D, H,
+                                                   F_._view(obar, 0, L, dh), *hub('dst', 1), bounds.data_ptr(), st), 'fwd')
+
+        def bwd_dst():
+            _lib.check(lib.ampconv_bwd_edge_dst_planes(pQ, pK, pV, pG, csr.rowptr.data_ptr(), csr.col.data_ptr(), N, L, D,
+                                                       H, dQv, *hub('dst', 1), bounds.data_ptr(), amax, st), 'bwd_dst')
+
+        def bwd_src():
+            _lib.check(lib.ampconv_bwd_edge_src_planes(pQ, pK, pV, pG, csr.cscptr.data_ptr(), csr.crow.data_ptr(), N, L, D,
+                                                       H, dKv, dVv, *hub('src', 2), bounds.data_ptr(), amax, st), 'bwd_src')
+        print('plane-format passes (fp16 planes, 16-bit matrix pipe)')
 
     for name, fn, nbytes, flops in (
             ('fwd_edge', fwd, (2 * E + 2 * N) * R, 4 * L * L * D * E),

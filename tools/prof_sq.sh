@@ -3,7 +3,7 @@
 #   tools/prof_sq.sh <tag> [bench_kernels args]   (environment: AMPCONV_LIB_PATH, AMPCONV_SRC_NT4, ...)
 # Counters only (no trace domains besides the kernel trace), two passes of <= 8 SQ counters.
 tag=$1; shift
-out=gpurun_out/sq_r4/$tag
+out=gpurun_out/${SQ_DIR:-sq_r5}/$tag
 mkdir -p $out
 cd /tmp 2>/dev/null; export TMPDIR=/tmp; cd - >/dev/null
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE \
