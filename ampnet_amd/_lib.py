@@ -84,9 +84,9 @@ SIGNATURES = {
     'ampconv_planes_supported': (_i32, [_i32, _i32, _i32]),
     'ampconv_fwd_edge_planes': (_i32, [View, View, View, _vp, _vp, _i64, _i32, _i32, _i32, View, _vp, _i64, _vp, _vp, _vp]),
     'ampconv_bwd_edge_dst_planes': (_i32, [View, View, View, View, _vp, _vp, _i64, _i32, _i32, _i32, View, _vp, _i64, _vp,
-                                           _vp, _vp, _vp]),
+                                           _vp, _vp, _vp, _vp, _vp]),
     'ampconv_bwd_edge_src_planes': (_i32, [View, View, View, View, _vp, _vp, _i64, _i32, _i32, _i32, View, View, _vp, _i64,
-                                           _vp, _vp, _vp, _vp]),
+                                           _vp, _vp, _vp, _vp, _vp]),
     'ampconv_proj_out_bound': (_i32, [_vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
     'ampconv_proj_rows_planes': (_i32, [_vp, _i64, _i64, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp, _vp,
                                         _i32, _vp]),

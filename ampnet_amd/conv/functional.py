@@ -500,8 +500,7 @@ class AMPConvFunction(torch.autograd.Function):
             # softmax statistics (normaliser, delta) per edge: a by-product of the destination
             # pass that saves the source pass its cross-lane reductions (include/ampconv.h)
             stats = spos = None
-            nstat = (lib.ampconv_softmax_stats_bytes(csr.num_edges, L, D, H, ctx.dtype)
-                     if SOFTMAX_STATS and not planes else 0)
+            nstat = lib.ampconv_softmax_stats_bytes(csr.num_edges, L, D, H, ctx.dtype) if SOFTMAX_STATS else 0
             if nstat:
                 stats = torch.empty(nstat // 4, dtype=torch.float32, device=dev)
                 spos = csr.csc_positions()
@@ -510,11 +509,13 @@ class AMPConvFunction(torch.autograd.Function):
                 # both passes on the 16-bit matrix pipe; each records the maximum of what it writes (ag[1]: all of dQKV)
                 _lib.check(lib.ampconv_bwd_edge_dst_planes(Qv, Kv, Vv, dOv, csr.rowptr.data_ptr(), csr.col.data_ptr(),
                                                            Nq, L, D, H, dQv, plan, nch, _ptr(ws), bounds.data_ptr(),
-                                                           ag[1].data_ptr(), _stream()), 'ampconv_bwd_edge_dst_planes')
+                                                           _ptr(spos), _ptr(stats), ag[1].data_ptr(), _stream()),
+                           'ampconv_bwd_edge_dst_planes')
                 plan, nch, ws = csr.hub_args('src', L, D, 2)
                 _lib.check(lib.ampconv_bwd_edge_src_planes(Qv, Kv, Vv, dOv, csr.cscptr.data_ptr(), csr.crow.data_ptr(),
                                                            Nk, L, D, H, dKv, dVv, plan, nch, _ptr(ws), bounds.data_ptr(),
-                                                           ag[1].data_ptr(), _stream()), 'ampconv_bwd_edge_src_planes')
+                                                           _ptr(stats), ag[1].data_ptr(), _stream()),
+                           'ampconv_bwd_edge_src_planes')
             else:
                 # (scaled projections: the operand maximum of the two products that consume dQKV.  The destination pass
                 # records the maximum of dQ as it stores; dK | dV: one pass below -- the fp32 source-pass kernels have no

@@ -21,9 +21,10 @@
 // transposed reads), channel-product fragments are one ds_read_b128 per plane, token-product fragments two
 // ds_read_b64_tr_b16 per plane, softmax results are split into two fp16 planes in registers and are the B operand of
 // the next product as they stand.  dObar arrives DIVIDED by the in-degree of its node (the producing projection's
-// epilogue does it), so neither backward pass carries a per-edge weight.  No softmax statistics hand-off: the passes
-// are built to sit at the gather rate, where 2 x 160 B per edge and head cost what they save (measured on the bf16
-// kernels).
+// epilogue does it), so neither backward pass carries a per-edge weight.  Softmax statistics (optional, as in the fp32
+// kernels: 20 log2-sum-exp + 20 delta floats per edge and head, filed at the edge's CSC position by the destination pass):
+// with them the source pass's softmax is element-wise -- its three 16-lane reductions per row are a third of its
+// vector instructions, and these passes are bound by vector issue and by the clock the chip holds under them.
 #include "mfma_tile.h"
 
 namespace {
@@ -207,8 +208,9 @@ __device__ __forceinline__ void cd_frag2(const f32x4 &t0, float t1_0, i32x4 &hi,
 // softmax over the 20 source tokens of one destination-token column; `sc` = log2e / sqrt(dh) / (scale of Q' K'^T) is
 // applied to the raw scores here, the result leaves multiplied by `mul`.  t0[q] = token 4 g + q, t1[0] = token 16 + g
 // (regs 1..3 of tile 1 replicate it and come out as 0)
+// Returns m * sc + log2(sum): P = exp2(S' * sc - that), what the source pass needs to rebuild P without reducing again.
 template <bool FULL>
-__device__ __forceinline__ void column_softmax(f32x4 &t0, f32x4 &t1, float sc, float mul, int L, int g) {
+__device__ __forceinline__ float column_softmax(f32x4 &t0, f32x4 &t1, float sc, float mul, int L, int g) {
   if (!FULL) {
 #pragma unroll
     for (int q = 0; q < 4; ++q)
@@ -227,6 +229,7 @@ __device__ __forceinline__ void column_softmax(f32x4 &t0, f32x4 &t1, float sc, f
   for (int q = 0; q < 4; ++q) t0[q] *= inv;
   t1[0] *= inv;
   t1[1] = t1[2] = t1[3] = 0.f;
+  return fmaf(m, sc, __builtin_amdgcn_logf(l));
 }
 
 struct Args {
@@ -235,6 +238,10 @@ struct Args {
   const float *bounds;                      // device: {bound of |Q|K|V|, bound of |dObar|: the planes' scales;
                                             //          recorded max |V|, recorded max |dObar|: the scale of dS}
   float *absmax;                            // or null: atomic max of the finite magnitudes written (backward passes)
+  // softmax statistics handed from the destination pass to the source pass (kStatsPerUnit floats per (CSC position,
+  // head): 20 log2-sum-exp values, then 20 delta values in the units of dP' = dO' V'^T), or null
+  const int32_t *spos;                      // CSR position -> CSC position (destination pass)
+  float *stats;
   HubArgs hub;
   int64_t n_units;
   int L, H;
@@ -355,7 +362,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void fwd_f16x2(Args a) {
 }
 
 // ---------------------------------------------------------------- backward, destination pass
-template <bool FULL>
+template <bool FULL, bool STATS>
 __global__ __launch_bounds__(64 * kWavesPerBlock, 3) void bwd_dst_f16x2(Args a) {
   __shared__ __attribute__((aligned(16))) char lds_all[kWavesPerBlock][2 * kTileBytes];
   const int lane = threadIdx.x & 63;
@@ -393,20 +400,25 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 3) void bwd_dst_f16x2(Args a) 
   PairRegsP kv;
   IdxWindow win;
   const unsigned krb = (unsigned)a.K.row_stride * 4u, vrb = (unsigned)a.V.row_stride * 4u;
+  // (STATS: the window's weight slot carries the bits of spos[p], the CSC position of the edge)
+  const float *sposf = reinterpret_cast<const float *>(a.spos);
+  float cposf = 0.f, cposf_next = 0.f;
   auto fetch = [&](int p) {
-    const int64_t s = idxwin_get<false>(win, a.idx, nullptr, p, end, lane, nullptr);
+    const int64_t s = idxwin_get<STATS>(win, a.idx, sposf, p, end, lane, &cposf_next);
     pair_load_p<FULL>(kv, slot_ptr(a.K, s, h), krb, slot_ptr(a.V, s, h), vrb, L, lane);
   };
   if (beg < end) {
-    idxwin_load<false>(win, a.idx, nullptr, beg, end, lane);
+    idxwin_load<STATS>(win, a.idx, sposf, beg, end, lane);
     fetch(beg);
   }
   for (int p = beg; p < end; ++p) {
     pair_to_lds_p<FULL>(Kt, kv, L, lane);
+    cposf = cposf_next;
     if (p + 1 < end) fetch(p + 1);
     __builtin_amdgcn_wave_barrier();
 
     f32x4 S[2][2], dP[2][2];
+    float lse[2], dlt[2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
       const i32x4 kh = rowfrag(Kt, mt, lane), kl = rowfrag(Kt + kLoOff, mt, lane);
@@ -420,11 +432,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 3) void bwd_dst_f16x2(Args a) 
     i32x4 sh[2], sl[2];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
-      column_softmax<FULL>(S[0][nt], S[1][nt], sc, 1.f, L, g);        // P^T; tile-1 regs 1..3 come out 0
+      lse[nt] = column_softmax<FULL>(S[0][nt], S[1][nt], sc, 1.f, L, g);        // P^T; tile-1 regs 1..3 come out 0
       float part = S[1][nt][0] * dP[1][nt][0];
 #pragma unroll
       for (int q = 0; q < 4; ++q) part = fmaf(S[0][nt][q], dP[0][nt][q], part);
       const float delta = groups_sum(part);
+      dlt[nt] = delta;
 #pragma unroll
       for (int q = 0; q < 4; ++q) S[0][nt][q] *= (dP[0][nt][q] - delta) * ss;      // dS^T in the unit's split scale
       S[1][nt][0] *= (dP[1][nt][0] - delta) * ss;
@@ -441,6 +454,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 3) void bwd_dst_f16x2(Args a) 
     for (int mc = 0; mc < 2; ++mc)
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) dQT[mc][nt] = mfma3(ch[mc], cl[mc], sh[nt], sl[nt], dQT[mc][nt]);
+    if (STATS) {
+      // every lane group holds the statistics of its column: lanes 0..15 have tokens 0..15 (tile 0), lanes 16..19
+      // (group 1, columns 0..3) tokens 16..19 (tile 1): two 80-byte stores per edge and head
+      float *st = a.stats + ((int64_t)__builtin_bit_cast(int, cposf) * a.H + h) * kStatsPerUnit;
+      if (lane < L) {
+        st[lane] = lane < 16 ? lse[0] : lse[1];
+        st[kLmax + lane] = lane < 16 ? dlt[0] : dlt[1];
+      }
+    }
     __builtin_amdgcn_wave_barrier();
   }
   // dQ = sum dS K / sqrt(dh): undo the split scale, the scales of dP' (Q|K|V and dObar) and of K'; the hub pass leaves
@@ -456,9 +478,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 3) void bwd_dst_f16x2(Args a) 
 // the difference between two and three waves per SIMD).  Their tokens sit on the MFMA COLUMNS, tile 1 in the quarter
 // map (column n <-> token 16 + (n >> 2): every tail token four times, no row of the 20-row image is read out of
 // range); the row softmax masks the replicas, the store takes the lanes n % 4 == 0.
-template <bool FULL>
+constexpr int kSrcLds = 4 * kTileBytes + 2 * kLmax * 4 + 32;      // four tile images + the edge's statistics (padded to 16)
+template <bool FULL, bool STATS>
 __global__ __launch_bounds__(64 * kWavesPerBlock, 3) void bwd_src_f16x2(Args a) {
-  __shared__ __attribute__((aligned(16))) char lds_all[kWavesPerBlock][4 * kTileBytes];
+  __shared__ __attribute__((aligned(16))) char lds_all[kWavesPerBlock][kSrcLds];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int64_t unit = (int64_t)blockIdx.x * kWavesPerBlock + wave;
@@ -490,9 +513,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 3) void bwd_src_f16x2(Args a) 
 
   IdxWindow win;
   const unsigned qrb = (unsigned)a.Q.row_stride * 4u, grb = (unsigned)a.dO.row_stride * 4u;
+  float *stl = reinterpret_cast<float *>(Vo + kTileBytes);      // the edge's 40 statistics, staged for the row reads
+  float sv = 0.f;                                               // lane l < 40: statistic l of the edge in flight
   auto fetch = [&](int p) {
     const int64_t d = idxwin_get<false>(win, a.idx, nullptr, p, end, lane, nullptr);
     pair_load_p<FULL>(qg, slot_ptr(a.Q, d, h), qrb, slot_ptr(a.dO, d, h), grb, L, lane);
+    if (STATS && lane < kStatsPerUnit) sv = a.stats[((int64_t)p * a.H + h) * kStatsPerUnit + lane];
   };
   if (beg < end) {
     idxwin_load<false>(win, a.idx, nullptr, beg, end, lane);
@@ -502,6 +528,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 3) void bwd_src_f16x2(Args a) 
   const bool v0 = FULL || n < L, v1 = (n & 3) == 0 && 16 + (n >> 2) < L;
   for (int p = beg; p < end; ++p) {
     pair_to_lds_p<FULL>(Qt, qg, L, lane);
+    if (STATS && lane < kStatsPerUnit) stl[lane] = sv;
     if (p + 1 < end) fetch(p + 1);
     __builtin_amdgcn_wave_barrier();
 
@@ -529,6 +556,28 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 3) void bwd_src_f16x2(Args a) 
     // row softmax over the source tokens (columns across the 16 lanes of a DPP row); rows: tile 0 reg q = destination
     // token 4 g + q, tile 1 reg 0 = token 16 + g (quarter map).  After this block S holds P * 2^14 (for dV) and dP holds
     // dS in the unit's split scale.
+    if (STATS) {
+      // element-wise with the statistics of the destination pass: rows of tile 0 = tokens 4 g .. 4 g + 3, tile 1 reg 0 =
+      // token 16 + g
+      const int g = lane >> 4;
+      const f32x4 l0 = *reinterpret_cast<const f32x4 *>(stl + 4 * g), d0 = *reinterpret_cast<const f32x4 *>(stl + kLmax + 4 * g);
+      const float l1 = stl[16 + g], d1 = stl[kLmax + 16 + g];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+        for (int q = 0; q < (mt == 0 ? 4 : 1); ++q) {
+          const float ls = mt == 0 ? l0[q] : l1, dl = mt == 0 ? d0[q] : d1;
+          // (rows of tokens >= L have no statistics: their weights are zero, not exp2 of whatever the buffer holds)
+          const bool vr = FULL || (mt == 0 ? 4 * g + q : 16 + g) < L;
+          const float s0 = (v0 && vr) ? S[mt][0][q] : kMasked, s1 = (v1 && vr) ? S[mt][1][q] : kMasked;
+          const float p0 = fast_exp2(fmaf(s0, sc, -ls)), p1 = fast_exp2(fmaf(s1, sc, -ls));
+          S[mt][0][q] = p0 * kPScale;
+          S[mt][1][q] = p1 * kPScale;
+          dP[mt][0][q] = p0 * (dP[mt][0][q] - dl) * ss;
+          dP[mt][1][q] = p1 * (dP[mt][1][q] - dl) * ss;
+        }
+      }
+    } else {
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
@@ -545,6 +594,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 3) void bwd_src_f16x2(Args a) 
         dP[mt][0][q] = p0 * (dP[mt][0][q] - delta) * ss;
         dP[mt][1][q] = p1 * (dP[mt][1][q] - delta) * ss;
       }
+    }
     }
     {
       i32x4 ph[2], pl[2], gh[2], gl[2];
@@ -647,8 +697,10 @@ extern "C" int ampconv_fwd_edge_planes(ampconv_view_t Q, ampconv_view_t K, ampco
 extern "C" int ampconv_bwd_edge_dst_planes(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V, ampconv_view_t dObar,
                                            const int32_t *rowptr, const int32_t *col, int64_t n_rows, int L, int D, int H,
                                            ampconv_view_t dQ, const void *hub_plan, int64_t hub_chunks, void *hub_ws,
-                                           const float *bounds, float *out_absmax, void *stream) {
+                                           const float *bounds, const int32_t *spos, float *stats, float *out_absmax,
+                                           void *stream) {
   if (int rc = check_shape(n_rows, L, D, H, bounds)) return rc;
+  if (stats && (!spos || (uintptr_t)stats % 16 != 0)) return AMPCONV_E_BADARG;
   if (n_rows == 0) return AMPCONV_OK;
   if (!plane_view_ok(Q) || !plane_view_ok(K) || !plane_view_ok(V) || !plane_view_ok(dObar) || !f32_view_ok(dQ) || !rowptr)
     return AMPCONV_E_BADARG;
@@ -656,29 +708,32 @@ extern "C" int ampconv_bwd_edge_dst_planes(ampconv_view_t Q, ampconv_view_t K, a
   Args a{};
   a.Q = Q; a.K = K; a.V = V; a.dO = dObar; a.O = dQ;
   a.ptr = rowptr; a.idx = col; a.bounds = bounds; a.absmax = out_absmax; a.L = L; a.H = H;
+  a.spos = spos; a.stats = stats;
   if (hub_plan && hub_chunks > 0 && hub_ws) {
     a.hub = HubArgs{(const int32_t *)hub_plan, 1};
     a.n_units = n_rows * H;
-    if (int rc = launch(a, L, bwd_dst_f16x2<true>, bwd_dst_f16x2<false>, st)) return rc;
+    if (int rc = (a.stats ? launch(a, L, bwd_dst_f16x2<true, true>, bwd_dst_f16x2<false, true>, st) : launch(a, L, bwd_dst_f16x2<true, false>, bwd_dst_f16x2<false, false>, st))) return rc;
     const ampconv_view_t P = partial_view(hub_ws, 0, hub_chunks, L, D, H);
     a.O = P;
     a.absmax = nullptr;                                // partial tiles: the combine pass records what it writes
     a.hub.mode = 2;
     a.n_units = hub_chunks * H;
-    if (int rc = launch(a, L, bwd_dst_f16x2<true>, bwd_dst_f16x2<false>, st)) return rc;
+    if (int rc = (a.stats ? launch(a, L, bwd_dst_f16x2<true, true>, bwd_dst_f16x2<false, true>, st) : launch(a, L, bwd_dst_f16x2<true, false>, bwd_dst_f16x2<false, false>, st))) return rc;
     return ampconv_hub_combine(hub_plan, hub_chunks, (const float *)P.ptr, dQ, nullptr, L, D, H, 1.f / sqrtf((float)DH),
                                0, st, out_absmax);
   }
   a.hub = HubArgs{nullptr, 0};
   a.n_units = n_rows * H;
-  return launch(a, L, bwd_dst_f16x2<true>, bwd_dst_f16x2<false>, st);
+  return (a.stats ? launch(a, L, bwd_dst_f16x2<true, true>, bwd_dst_f16x2<false, true>, st) : launch(a, L, bwd_dst_f16x2<true, false>, bwd_dst_f16x2<false, false>, st));
 }
 
 extern "C" int ampconv_bwd_edge_src_planes(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V, ampconv_view_t dObar,
                                            const int32_t *cscptr, const int32_t *crow, int64_t n_src, int L, int D, int H,
                                            ampconv_view_t dK, ampconv_view_t dV, const void *hub_plan, int64_t hub_chunks,
-                                           void *hub_ws, const float *bounds, float *out_absmax, void *stream) {
+                                           void *hub_ws, const float *bounds, const float *stats, float *out_absmax,
+                                           void *stream) {
   if (int rc = check_shape(n_src, L, D, H, bounds)) return rc;
+  if (stats && (uintptr_t)stats % 16 != 0) return AMPCONV_E_BADARG;
   if (n_src == 0) return AMPCONV_OK;
   if (!plane_view_ok(Q) || !plane_view_ok(K) || !plane_view_ok(V) || !plane_view_ok(dObar) || !f32_view_ok(dK) ||
       !f32_view_ok(dV) || !cscptr)
@@ -687,17 +742,18 @@ extern "C" int ampconv_bwd_edge_src_planes(ampconv_view_t Q, ampconv_view_t K, a
   Args a{};
   a.Q = Q; a.K = K; a.V = V; a.dO = dObar; a.dK = dK; a.dV = dV;
   a.ptr = cscptr; a.idx = crow; a.bounds = bounds; a.absmax = out_absmax; a.L = L; a.H = H;
+  a.stats = const_cast<float *>(stats);
   if (hub_plan && hub_chunks > 0 && hub_ws) {
     a.hub = HubArgs{(const int32_t *)hub_plan, 1};
     a.n_units = n_src * H;
-    if (int rc = launch(a, L, bwd_src_f16x2<true>, bwd_src_f16x2<false>, st)) return rc;
+    if (int rc = (a.stats ? launch(a, L, bwd_src_f16x2<true, true>, bwd_src_f16x2<false, true>, st) : launch(a, L, bwd_src_f16x2<true, false>, bwd_src_f16x2<false, false>, st))) return rc;
     const ampconv_view_t PK = partial_view(hub_ws, 0, hub_chunks, L, D, H), PV = partial_view(hub_ws, 1, hub_chunks, L, D, H);
     a.dK = PK;
     a.dV = PV;
     a.absmax = nullptr;
     a.hub.mode = 2;
     a.n_units = hub_chunks * H;
-    if (int rc = launch(a, L, bwd_src_f16x2<true>, bwd_src_f16x2<false>, st)) return rc;
+    if (int rc = (a.stats ? launch(a, L, bwd_src_f16x2<true, true>, bwd_src_f16x2<false, true>, st) : launch(a, L, bwd_src_f16x2<true, false>, bwd_src_f16x2<false, false>, st))) return rc;
     if (int rc = ampconv_hub_combine(hub_plan, hub_chunks, (const float *)PK.ptr, dK, nullptr, L, D, H,
                                      1.f / sqrtf((float)DH), 0, st, out_absmax))
       return rc;
@@ -705,5 +761,5 @@ extern "C" int ampconv_bwd_edge_src_planes(ampconv_view_t Q, ampconv_view_t K, a
   }
   a.hub = HubArgs{nullptr, 0};
   a.n_units = n_src * H;
-  return launch(a, L, bwd_src_f16x2<true>, bwd_src_f16x2<false>, st);
+  return (a.stats ? launch(a, L, bwd_src_f16x2<true, true>, bwd_src_f16x2<false, true>, st) : launch(a, L, bwd_src_f16x2<true, false>, bwd_src_f16x2<false, false>, st));
 }

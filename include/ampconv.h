@@ -192,7 +192,9 @@ int ampconv_bwd_edge_src(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
  * product is the fp32 sum of three v_mfma_f32_16x16x32_f16 partial products (dropped: lo x lo <= 2^-22 of the product),
  * softmax and all sums are fp32, the outputs (Obar, dQ, dK, dV) plain fp32 views.
  * dObar must arrive DIVIDED by the in-degree of its node (ampconv_proj_rows_planes, row_scale = 1): the passes carry no
- * per-edge weight.  No softmax statistics.  out_absmax as above (both backward passes record it themselves).
+ * per-edge weight.  Softmax statistics as above (`stats`: E * H * 40 floats, 16-byte aligned, or NULL; `spos` with
+ * them; delta is handed over in the units of the scaled dObar V^T product, which both passes share).  out_absmax as
+ * above (both backward passes record it themselves).
  * planes_supported: 1 if (L, D, H) is served.  Same accuracy class as the fp32 kernels on tensors whose rows lie
  * within ~2^12 of the tensor's maximum (ampconv_absmax_stats measures exactly that; callers fall back to the fp32
  * entry points otherwise).  */
@@ -205,12 +207,14 @@ int ampconv_bwd_edge_dst_planes(ampconv_view_t Q, ampconv_view_t K, ampconv_view
                                 ampconv_view_t dObar, const int32_t *rowptr, const int32_t *col,
                                 int64_t n_rows, int L, int D, int H, ampconv_view_t dQ,
                                 const void *hub_plan, int64_t hub_chunks, void *hub_ws,
-                                const float *bounds, float *out_absmax, void *stream);
+                                const float *bounds, const int32_t *spos, float *stats,
+                                float *out_absmax, void *stream);
 int ampconv_bwd_edge_src_planes(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
                                 ampconv_view_t dObar, const int32_t *cscptr, const int32_t *crow,
                                 int64_t n_src, int L, int D, int H, ampconv_view_t dK,
                                 ampconv_view_t dV, const void *hub_plan, int64_t hub_chunks,
-                                void *hub_ws, const float *bounds, float *out_absmax, void *stream);
+                                void *hub_ws, const float *bounds, const float *stats,
+                                float *out_absmax, void *stream);
 
 /* ---- per-edge side outputs, ORIGINAL edge order ------------------------------
  * attn_weights: W[e] = mean_h softmax_rows(Q[dst e,:,h] K[src e,:,h]^T/sqrt(dh)),

@@ -86,12 +86,14 @@ NAMES = ('y', 'dx', 'g_in_proj_weight', 'g_in_proj_bias', 'g_out_proj_weight', '
 @pytest.mark.parametrize('shape', [(1500, 15000, 20, 256, 8), (900, 9000, 20, 128, 4), (700, 6000, 13, 128, 4),
                                    (600, 5000, 17, 256, 8), (400, 3000, 5, 128, 4), (300, 2500, 1, 128, 4)],
                          ids=['cfg4_like', 'cora_like', 'L13', 'L17', 'L5', 'L1'])
-def test_plane_path_vs_fp64_oracle(shape, dev, monkeypatch):
+@pytest.mark.parametrize('stats', [True, False], ids=['stats', 'own_softmax'])
+def test_plane_path_vs_fp64_oracle(shape, stats, dev, monkeypatch):
     """The whole layer through the plane-format edge passes (forced onto small graphs), with long segments in both
     directions and isolated nodes, against the fp64 oracle at the flat fp32 tolerance; the three plane entry points
     are what ran."""
     from ampnet_amd.conv import functional as F_
     monkeypatch.setattr(F_, 'PROJ_SCALED_MIN_ELEMENTS', 0)
+    monkeypatch.setattr(F_, 'SOFTMAX_STATS', stats)          # hand-off of (log-sum-exp, delta) from the dst to the src pass
     N, E, L, D, H = shape
     layer, x, dy, ei = _make(N, E, L, D, H, dev)
     calls = _Calls(monkeypatch, PLANE_CALLS + F32_CALLS)

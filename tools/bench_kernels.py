@@ -148,11 +148,11 @@ def main():
 
         def bwd_dst():
             _lib.check(lib.ampconv_bwd_edge_dst_planes(pQ, pK, pV, pG, csr.rowptr.data_ptr(), csr.col.data_ptr(), N, L, D,
-                                                       H, dQv, *hub('dst', 1), bounds.data_ptr(), amax, st), 'bwd_dst')
+                                                       H, dQv, *hub('dst', 1), bounds.data_ptr(), *sp, amax, st), 'bwd_dst')
 
         def bwd_src():
             _lib.check(lib.ampconv_bwd_edge_src_planes(pQ, pK, pV, pG, csr.cscptr.data_ptr(), csr.crow.data_ptr(), N, L, D,
-                                                       H, dKv, dVv, *hub('src', 2), bounds.data_ptr(), amax, st), 'bwd_src')
+                                                       H, dKv, dVv, *hub('src', 2), bounds.data_ptr(), sp[1], amax, st), 'bwd_src')
         print('plane-format passes (fp16 planes, 16-bit matrix pipe)')
 
     for name, fn, nbytes, flops in (
