@@ -194,6 +194,15 @@ __device__ __forceinline__ i32x4 colfrag(const char *img, int mc, int lane) {
     __builtin_amdgcn_sched_barrier(0);                     \
   } while (0)
 
+// behind a group of MFMAs whose fragment registers the next group's transposed reads may take over: the last MFMA has
+// fetched its operands before a read redefines them (tools/scan_tr_hazard.py --gate, rule WAR)
+#define TR_WAR_GUARD()                         \
+  do {                                         \
+    __builtin_amdgcn_sched_barrier(0);         \
+    asm volatile("s_nop 7" ::: "memory");      \
+    __builtin_amdgcn_sched_barrier(0);         \
+  } while (0)
+
 // C/D registers (already in the split's units, |x| < 2^16) -> the two planes of a token-product fragment: slots 0..3 =
 // t0 (tokens 4 g + q), slot 4 = t1_0 (token 16 + g), slots 5..7 zero
 __device__ __forceinline__ void cd_frag2(const f32x4 &t0, float t1_0, i32x4 &hi, i32x4 &lo) {
@@ -610,6 +619,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 3) void bwd_src_f16x2(Args a) 
       for (int mc = 0; mc < 2; ++mc)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) dVT[mc][nt] = mfma3(gh[mc], gl[mc], ph[nt], pl[nt], dVT[mc][nt]);
+      TR_WAR_GUARD();
     }
     {
       i32x4 sh[2], sl[2], qh[2], ql[2];

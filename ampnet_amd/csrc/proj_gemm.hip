@@ -789,6 +789,13 @@ __global__ __launch_bounds__(64 * WI * WJ, 2) void proj_wgrad_kernel(WgradArgs a
 #pragma unroll
           for (int j = 0; j < NJW; ++j)
             acc[i + ii][j] = mfma_p<HP>(af[ii][kPA[HP][q]], bf[j][kPB[HP][q]], acc[i + ii][j]);
+#ifndef AMPCONV_WG_NOFENCE
+      // ... and the next round's (or stage's) reads do not redefine af[] / bf[] right behind the MFMA that reads them: the
+      // last MFMA of the round has fetched its operands by then (8 idle cycles; tools/scan_tr_hazard.py --gate, rule WAR)
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_nop 7" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#endif
     }
   };
   for (int s = 0; s < ns; s += NSET) {

@@ -558,6 +558,10 @@ __global__ __launch_bounds__(T == 256 ? 512 : 256, 2) void proj_wgrad_bf16_kerne
       for (int i = 0; i < NIW; ++i)
 #pragma unroll
         for (int j = 0; j < NJW; ++j) acc[i][j] = MFMA32(af[i], bf[j], acc[i][j]);
+      // (... and the next half stage's reads do not redefine a fragment register right behind the MFMA that reads it:
+      // tools/scan_tr_hazard.py --gate, rule WAR)
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_nop 7" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
     }
     if (do_cs) {

@@ -179,3 +179,34 @@ def test_register_budgets_of_the_kernels_that_must_not_spill():
     assert len(hot) == 3, hot
     for k in hot:
         assert usage[k]['spill'] == 0 and usage[k]['vgprs'] <= 168, (k, usage[k])
+
+
+def test_shipped_isa_keeps_the_transposed_read_fences():
+    """The ISA that __graft_entry__.build() keeps for every source that reads MFMA fragments with ds_read_b64_tr_b16
+    (build/obj/<source>-hip-amdgcn-amd-amdhsa-gfx950.s) against tools/scan_tr_hazard.py's gate: no MFMA consumes a
+    transposed fragment without a full lgkmcnt(0) drain in between, and no transposed read redefines a fragment register
+    within 8 issue cycles of the MFMA that reads it.  Those two things are what separates the weight-gradient build that
+    gave wrong sums (-DAMPCONV_WG_NOFENCE rebuilds it) from the one that does not; the fences in the
+    sources are scheduling requests, and this is the check that hipcc honoured them."""
+    import glob
+    import os
+    import sys
+    import pytest
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, 'tools'))
+    sys.path.insert(0, root)
+    import scan_tr_hazard
+    import __graft_entry__ as g
+    srcs = [s for s in sorted(glob.glob(os.path.join(g.CSRC, '*.hip'))) if g.uses_transposed_reads(s)]
+    assert len(srcs) >= 4, srcs                      # proj_gemm, proj_gemm_bf16, edge_mfma_bf16, edge_mfma_f16x2
+    objdir = os.path.join(root, 'build', 'obj')
+    if not glob.glob(os.path.join(objdir, '*.o')):
+        pytest.skip('no build/obj: run __graft_entry__.build() first (the GPU box receives the built library only)')
+    for s in srcs:
+        isa = os.path.join(objdir, os.path.basename(s)[:-4] + '-hip-amdgcn-amd-amdhsa-gfx950.s')
+        assert os.path.exists(isa), f'{isa} missing: rebuild with __graft_entry__.build(force=True)'
+        assert os.path.getmtime(isa) >= os.path.getmtime(s), f'{isa} is older than its source'
+        text = open(isa).read()
+        assert 'ds_read_b64_tr_b16' in text, isa
+        hits = scan_tr_hazard.gate(isa)
+        assert not hits, {k: v[:2] for k, v in hits.items()}

@@ -64,7 +64,7 @@ def main():
             return
         print(f'{name:34s} {t:8.2f} ms  {flops / t / 1e9:7.1f} TF  ({nprod * flops / t / 1e9:7.0f} TF bf16 issued)'
               + (f'  {nbytes / t / 1e9:6.2f} TB/s' if nbytes else '')
-              + (f'  err {err:.2e} (library {terr:.2e})' if err is not None else ''), flush=True)
+              + (f'  err {err:.2e}' + (f' (library {terr:.2e})' if terr else '') if err is not None else ''), flush=True)
 
     _timeit = timeit
 
@@ -87,6 +87,20 @@ def main():
     report('qkv  native', t, 2 * M * D * 3 * D, err(F_.proj_rows(x[:S], img, b_in, amax=ax), ref), err(torch.addmm(b_in, x[:S], w_in.t()), ref),
            nbytes=M * 4 * D * es)
     report('qkv  library (addmm)', timeit_lib(lambda: torch.addmm(b_in, x, w_in.t()), iters), 2 * M * D * 3 * D, nbytes=M * 4 * D * es)
+    if scaled and want('qkv'):      # the same product leaving as two fp16 planes (the format of csrc/edge_mfma_f16x2.hip)
+        bound = torch.empty(1, device=dev)
+        F_.proj_out_bound(w_in, False, b_in, ax, bound)
+        t = timeit(lambda: F_.proj_rows_planes(x, img, bound, b_in, amax=ax, out_amax=am_out, amax_col0=2 * D), iters)
+        back = F_.planes_to_f32(F_.proj_rows_planes(x[:S], img, bound, b_in, amax=ax), bound)
+        report('qkv  native, plane output', t, 2 * M * D * 3 * D, err(back, ref), None and 0.0, nbytes=M * 4 * D * es)
+        L = 20
+        deg = torch.randint(1, 20, (M // L + 1,), device=dev)
+        rowptr = torch.zeros(M // L + 2, dtype=torch.int32, device=dev)
+        rowptr[1:] = torch.cumsum(deg, 0).to(torch.int32)
+        img_ot = F_.proj_image(w_out, transpose=True)
+        F_.proj_out_bound(w_out, True, None, ax, bound)
+        t = timeit(lambda: F_.proj_rows_planes(x[: (M // L) * L], img_ot, bound, rowptr=rowptr, L=L, row_scale=1, amax=ax, out_amax=am_out), iters)
+        report('dObar native, plane output /deg', t, 2 * M * D * D, nbytes=M * 2 * D * es)
     # out-projection [M, D] x [D, D]
     img_o = F_.proj_image(w_out)
     report('out  native', timeit(lambda: F_.proj_rows(x, img_o, b_in[:D], amax=ax), iters) if want('out') else None, 2 * M * D * D, nbytes=M * 2 * D * es)
