@@ -12,6 +12,7 @@ from . import distributed
 from .module import AMPGCN, FeatureTokens
 from .sampler import GraphSAINTRandomWalkSampler
 from .partitioned import NodePartition, PartitionedAMPConv
+from .graphed import GraphedAMPConv
 
 __all__ = ['AMPConv', 'InvalidConfiguration', 'EdgeCSR', 'graph_cache', 'distributed', 'AMPGCN', 'FeatureTokens',
-           'GraphSAINTRandomWalkSampler', 'NodePartition', 'PartitionedAMPConv']
+           'GraphSAINTRandomWalkSampler', 'NodePartition', 'PartitionedAMPConv', 'GraphedAMPConv']

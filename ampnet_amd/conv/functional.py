@@ -362,7 +362,9 @@ class AMPConvFunction(torch.autograd.Function):
             am = bounds = None
             planes = False
             xkv2 = xq2 if shared else xkv.contiguous().view(Nk * L, D)
-            if native and PROJ_SCALED and xq.dtype == torch.float32 and xq2.numel() >= PROJ_SCALED_MIN_ELEMENTS:
+            # (the read-back rules the mode out while a HIP graph is being recorded: ampnet_amd/graphed.py is for small graphs)
+            if (native and PROJ_SCALED and xq.dtype == torch.float32 and xq2.numel() >= PROJ_SCALED_MIN_ELEMENTS
+                    and not torch.cuda.is_current_stream_capturing()):
                 st, narrow = operand_stats(xq2, key=xq)
                 stk = None
                 if narrow and not shared:

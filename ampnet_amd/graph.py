@@ -13,7 +13,9 @@ from . import _lib
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    """Raw hipStream_t of torch's current stream on the current device (the C-level accessors: the Stream object of
+    torch.cuda.current_stream() costs ~12 us per call, five calls per Cora-sized step)."""
+    return torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice())
 
 
 # node lists are worth their extra launches when at most this share of the nodes has any edge

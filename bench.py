@@ -616,6 +616,39 @@ def measure_full(workload, steps, warmup, args, rank, world, dev, dist_on, dt_na
     return out
 
 
+def measure_graphed(workload, steps, warmup, args, dev):
+    """The fixed-graph regime (the reference's full-graph Cora runs, experiments/cora_benchmark_full.py): forward and backward
+    of the layer recorded once as two HIP graphs (ampnet_amd.GraphedAMPConv) and replayed per step; the graph preparation
+    runs once, outside the steps -- unlike measure_full, whose every step builds its CSR / CSC (the GraphSAINT regime).
+    Same layer, same kernels, same results bit for bit (tests/test_gpu_parity.py::test_graphed_layer_matches_eager)."""
+    from ampnet_amd import GraphedAMPConv, graph_cache
+    N, E, L, D, H, desc = WORKLOADS[workload]
+    layer, _ = make_layer(D, H, torch.float32, dev, args, False)
+    x, ei, dy = make_batch(N, E, L, D, 1234, dev)
+    x.requires_grad_(True)
+    fast = GraphedAMPConv(layer, x, ei)
+
+    def step():
+        layer.zero_grad(set_to_none=True)
+        x.grad = None
+        fast(x).backward(dy)
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    del fast, x, dy, ei
+    graph_cache.clear()
+    return {'metric': 'AMPConv edges/sec (fwd+bwd), fixed graph, forward and backward replayed as HIP graphs',
+            'value': E * steps / dt, 'unit': 'edges/s', 'steps': steps, 'ms_per_step': 1e3 * dt / steps,
+            'config': {'workload': f'{workload}: {desc}; graph prepared once, outside the steps', 'N': N, 'E': E, 'L': L,
+                       'D': D, 'H': H}}
+
+
 def _projection_note(dt_name, gemm):
     """config.projections: which arithmetic the per-node projections of this line ran."""
     from ampnet_amd.conv import functional as F_
@@ -735,6 +768,8 @@ def main():
                 w: _brief(measure_full(w, k, 1 if k < 20 else 3, args, rank, world, dev, dist_on,
                                        'bf16' if w == 'cfg5' else 'f32'))
                 for w, k in extra}
+            # the same Cora-sized layer on a FIXED graph, its launches recorded and replayed (HIP graphs)
+            out['extra_workloads']['cora-graphed'] = measure_graphed('cora', 200 if args.workload == 'cfg4' else 5, 5, args, dev)
         if world == 1 and not args.no_cpu_baseline and not args.softmax_free and rank == 0:
             N, E, L, D, H, _ = WORKLOADS[args.workload]
             out['cpu_baseline'] = cpu_baseline(L, D, H, E / N)

@@ -1183,3 +1183,44 @@ def test_short_sequences_small_kernels(shape, dev, monkeypatch):
     tiles = run()
     for name, a, b in zip(names, small, tiles):
         assert_close_scaled(a, b, f'{name} (small vs tile kernels)', scaled=True if name == 'dx' else None)
+
+
+@pytest.mark.parametrize('path', [p for p in SINGLE if 'cora' in os.path.basename(p) or 'cfg4' in os.path.basename(p)][:2],
+                         ids=lambda p: os.path.basename(p)[:-4])
+def test_graphed_layer_matches_eager(path, dev):
+    """ampnet_amd.GraphedAMPConv: forward and backward of a layer on a fixed graph recorded as two HIP graphs and
+    replayed -- the reference's golden vectors through the captured path (same tolerance), bit-identical to the eager
+    path on fresh inputs, and replays follow new inputs and new parameter values."""
+    from ampnet_amd import GraphedAMPConv
+    g = load_golden(path)
+    layer = _layer(g, dev)
+    x = torch.from_numpy(g['x']).to(dev).requires_grad_(True)
+    ei = torch.from_numpy(g['edge_index']).to(dev)
+    dy = torch.from_numpy(g['dy']).to(dev)
+    fast = GraphedAMPConv(layer, x, ei)
+    layer.zero_grad(set_to_none=True)
+    y = fast(x)
+    (y * dy).sum().backward()
+    assert_close_scaled(y.detach().cpu().numpy(), g['y'], 'y')
+    assert_close_scaled(x.grad.cpu().numpy(), g['dx'], 'dx')
+    gw, gb, gow, gob = _grads(layer)
+    assert_close_scaled(gw, g['g_in_proj_weight'], 'g_in_proj_weight')
+    assert_close_scaled(gb, g['g_in_proj_bias'], 'g_in_proj_bias')
+    assert_close_scaled(gow, g['g_out_proj_weight'], 'g_out_proj_weight')
+    assert_close_scaled(gob, g['g_out_proj_bias'], 'g_out_proj_bias')
+    # fresh inputs and changed parameters: replay == eager, bit for bit
+    with torch.no_grad():
+        layer.multi_head_attention.in_proj_bias.add_(0.05)
+    x2 = (torch.randn_like(x) * 0.7).requires_grad_(True)
+    dy2 = torch.randn_like(dy)
+    layer.zero_grad(set_to_none=True)
+    y2 = fast(x2)
+    y2.backward(dy2)
+    got = (y2.detach().clone(), x2.grad.clone()) + tuple(torch.from_numpy(a) for a in _grads(layer))
+    x3 = x2.detach().clone().requires_grad_(True)
+    layer.zero_grad(set_to_none=True)
+    y3 = layer(x3, ei)
+    y3.backward(dy2)
+    want = (y3.detach(), x3.grad) + tuple(torch.from_numpy(a) for a in _grads(layer))
+    for a, b, name in zip(got, want, ('y', 'dx', 'gw', 'gb', 'gow', 'gob')):
+        assert torch.equal(a.cpu(), b.cpu()), name

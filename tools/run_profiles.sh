@@ -3,7 +3,7 @@
 # (separate: FETCH_SIZE / WRITE_SIZE do not fit one pass), kernel stats of cfg5 and the SQ counter passes.
 # Counters are collected with --kernel-trace only (no other trace domain).
 #   usage: tools/run_profiles.sh <tag> [part]     part: all (default) | bench | counters
-tag=${1:-r04}
+tag=${1:-r05}
 part=${2:-all}
 d=gpurun_out/prof_$tag
 mkdir -p $d
@@ -18,7 +18,9 @@ rm -f $d/saint_kernel_trace.csv
 fi
 if [ "$part" != bench ]; then
 {
-echo "## fp32 edge kernels (cfg4 shape: uniform graph, L=20 D=256 H=8)"
+echo "## plane-format edge kernels (cfg4 shape at 0.4 of its size: uniform graph 400 k / 4 M, L=20 D=256 H=8; statistics hand-off on)"
+bash tools/prof_sq.sh ${tag}_planes 400000 4000000 20 256 8 --planes
+echo "## fp32 edge kernels (uniform graph 100 k / 1 M, L=20 D=256 H=8)"
 bash tools/prof_sq.sh ${tag}_f32
 bash tools/prof_fp32_pipe.sh ${tag}_pipe_f32
 echo "## bf16 edge kernels (R-MAT, cfg5 shape at 1/4 size)"
@@ -35,7 +37,7 @@ echo "## bf16 projections"
 bash tools/prof_sq_proj.sh ${tag}_proj_bf16 8000000 256 --iters=2 --no-lib --bf16
 } > $d/sq_summary.txt 2>&1
 # the raw counter CSVs are large (gpurun copies back at most 64 MiB): the summary is what is kept
-rm -rf gpurun_out/sq_r4/${tag}_*
+rm -rf gpurun_out/sq_r4/${tag}_* gpurun_out/sq_r5/${tag}_*
 fi
 ls $d | head -40
 tail -60 $d/sq_summary.txt

@@ -17,8 +17,18 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNELS = {'ampconv_fwd_edge': 'fwd_mfma', 'ampconv_bwd_edge_dst': 'bwd_dst_mfma',
-           'ampconv_bwd_edge_src': 'bwd_src_mfma'}
+# device kernel behind each timed C-ABI call: the plane-format passes (round 5: csrc/edge_mfma_f16x2.hip) where they ran,
+# else the fp32-MFMA kernels (csrc/edge_mfma.hip)
+KERNEL_CANDIDATES = {'ampconv_fwd_edge': ('fwd_f16x2', 'fwd_mfma'), 'ampconv_bwd_edge_dst': ('bwd_dst_f16x2', 'bwd_dst_mfma'),
+                     'ampconv_bwd_edge_src': ('bwd_src_f16x2', 'bwd_src_mfma')}
+
+
+def pick_kernels(counter_csv):
+    names = {r['Kernel_Name'] for r in csv.DictReader(open(counter_csv))}
+    out = {}
+    for api, cands in KERNEL_CANDIDATES.items():
+        out[api] = next(c for c in cands if any(re.search(r'\b' + c + r'(_t4)?<', n) for n in names))
+    return out
 
 
 def bench_line(path):
@@ -87,8 +97,10 @@ def main():
         f.write(f"Bench line printed by this profiled run: {b['value'] / 1e6:.2f} M edges/s, {b['ms_per_step']:.1f} "
                 f"ms/step; HIP-event averages inside bench.py: fwd {ms['ampconv_fwd_edge']:.1f} / bwd_dst "
                 f"{ms['ampconv_bwd_edge_dst']:.1f} / bwd_src {ms['ampconv_bwd_edge_src']:.1f} ms.\n\n")
-        f.write('`proj_rows_kernel` / `proj_wgrad_kernel` = the node-phase projections (csrc/proj_gemm.hip: four row products and '
-                'two weight-gradient products per step); `__amd_rocclr_copyBuffer` and `distribution_elementwise...` are the '
+        f.write('`fwd_f16x2` / `bwd_dst_f16x2` / `bwd_src_f16x2` = the plane-format edge passes (csrc/edge_mfma_f16x2.hip); '
+                '`proj_rows_kernel<..., true, true>` = the two projections that leave as fp16 planes (Q|K|V, dObar), `<..., true, false>` '
+                'the two with fp32 output (out-projection, dX), `proj_wgrad_kernel` the two weight-gradient products (csrc/proj_gemm.hip); '
+                '`absmax_stats_kernel` = the range / maximum pass over dY (x: once, cached); `__amd_rocclr_copyBuffer` and `distribution_elementwise...` are the '
                 "bench's own data fill (make_batch: 1 GiB slabs of randn copied into x and dy), outside the timed steps.\n\n")
         f.write('| kernel | calls | avg ms | total ms | % |\n|---|---|---|---|---|\n')
         for r in rows[:22]:
@@ -108,7 +120,7 @@ def main():
                   'per MI355X_MICROARCH.md (gfx950 reports half of 16-B/lane coalesced reads); per launch',
           'kernels': {}}
     lines = []
-    for api, dk in KERNELS.items():
+    for api, dk in pick_kernels(os.path.join(d, 'fetch_counter_collection.csv')).items():
         fetch = counter(os.path.join(d, 'fetch_counter_collection.csv'), dk, 2)
         write = counter(os.path.join(d, 'write_counter_collection.csv'), dk, 2)
         traffic = (2 * fetch + write) * 1024
