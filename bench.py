@@ -679,13 +679,26 @@ def _node_phase_mfma(flops_proj, t_node, dt_name, gemm):
             'note': 'lower bound of the rate: node_phase_ms also holds the CSR build and glue; DESIGN.md 4a: power-limited'}
 
 
+INFINITY_CACHE_BYTES = 256 << 20     # MI355X_MICROARCH.md: die-level L3
+
+
 def _brief(m):
-    """What an extra workload contributes to the headline's line."""
+    """What an extra workload contributes to the headline's line.  A workload whose gathered rows (Q | K | V and dObar of
+    every node) fit the 256 MiB Infinity Cache is served on-die after the first touch: algorithmic bytes / time is then not
+    a share of the HBM roofline, so no such share is printed for it (`cache_resident`: true)."""
     r = m['roofline']
-    return {'workload': m['config']['workload'], 'dtype': m['dtype'], 'value': m['value'], 'unit': m['unit'],
-            'steps': m['steps'], 'ms_per_step': m['ms_per_step'], 'kernels_ms': m['kernels_ms'],
-            'edge_phase_frac_of_8TBps': m['edge_phase_hbm']['frac_of_8TBps'],
-            'dominant_kernel': {'kernel': r['kernel'], 'frac': r['frac'], 'avg_launch_ms': r['avg_launch_ms']}}
+    c = m['config']
+    gathered = c['N'] * c['L'] * c['D'] * 4 * (2 if m['dtype'] == 'bf16' else 4)     # Q|K|V + dObar rows
+    out = {'workload': c['workload'], 'dtype': m['dtype'], 'value': m['value'], 'unit': m['unit'],
+           'steps': m['steps'], 'ms_per_step': m['ms_per_step'], 'kernels_ms': m['kernels_ms'],
+           'edge_entry_points': c.get('edge_entry_points')}
+    if gathered <= INFINITY_CACHE_BYTES:
+        out['cache_resident'] = True
+        out['dominant_kernel'] = {'kernel': r['kernel'], 'avg_launch_ms': r['avg_launch_ms']}
+    else:
+        out['edge_phase_frac_of_8TBps'] = m['edge_phase_hbm']['frac_of_8TBps']
+        out['dominant_kernel'] = {'kernel': r['kernel'], 'frac': r['frac'], 'avg_launch_ms': r['avg_launch_ms']}
+    return out
 
 
 def main():

@@ -161,6 +161,6 @@ def test_model_matches_reference_fixture(path):
     for name, p in model.named_parameters():
         key = 'grad.' + name
         if key in g:
-            assert_close_scaled(p.grad.cpu().numpy(), g[key], key)
+            assert_close_scaled(p.grad.cpu().numpy(), g[key], key + '.grad')
         else:
             assert p.grad is None, name                       # cls_token: defined, never used (amp_gcn.py:55-57)
