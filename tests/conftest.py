@@ -45,7 +45,8 @@ def load_golden(path):
 # node-token rows, whose absolute tolerance scales with the magnitude of the gradient (the builder's amendment to 8c, stated
 # in DESIGN.md section 2) -- or when the caller says `scaled=True` with its reason at the call.  A new or misspelt label is
 # therefore tested at the STRICT flat bar (round-4 advisor finding: it used to fall into the loose class).
-_GRADIENT_LABEL = (r'(^|[\s:(])(p \+ )?(l\d_)?(g_(in|out)_proj_(weight|bias)|g_(in|out)_[wb]|gw|gb|gow|gob)\b'
+_GRADIENT_LABEL = (r'(^|[\s:(])(l\d_)?(g_(in|out)_proj_(weight|bias)|g_(in|out)_[wb]|g[wb]|go[wb]'       # g_in_proj_weight, gw, gob
+                   r'|[gd][Wb]_?(in|out|o)?)\b'                                                           # gWin, gb_in, dW_out, db_in
                    r'|parameter gradient|bias gradient|\.grad\b|^grad ')
 
 

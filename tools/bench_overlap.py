@@ -1,7 +1,7 @@
 """Developer experiment: do the fp32 projection GEMMs (matrix-pipe bound) and the edge kernels (HBM /
 latency bound, matrix pipe ~50 % busy) overlap when issued on two HIP streams?
 
-    python tools/bench_overlap.py [N E] [--native] [--edges-first] [--cu-split=64,96,128]
+    python tools/bench_overlap.py [N E] [--native [--scaled]] [--planes] [--edges-first] [--cu-split=64,96,128]
 Times (a) the two backward edge passes alone, (b) a set of GEMMs alone, (c) both concurrently.
 --cu-split=K,...: the same with CU-MASKED streams (hipExtStreamCreateWithCUMask): the projections on K of the 256 CUs,
 the edge passes on the other 256 - K (a power-limited GEMM on fewer CUs holds a higher clock, a
@@ -51,18 +51,44 @@ def main():
                                             csr.cinv.data_ptr(), N, L, D, H, dKv, dVv, None, 0, None, stats.data_ptr(), None,
                                             0, st), 'src')
 
+    if '--planes' in sys.argv:                       # round 5: the plane-format backward passes (16-bit matrix pipe, memory-bound)
+        import math
+
+        def to_planes(t2, bound):
+            sc = 2.0 ** (14 - math.floor(math.log2(bound)))
+            xs = (t2 * sc).view(t2.size(0), -1, 32)
+            hi = xs.half()
+            lo = (xs - hi.float()).half()
+            return torch.cat([hi, lo], dim=2).contiguous().view(torch.float32).view(t2.size(0), -1)
+        mq, mg = float(qkv.abs().max()), float(dobar.abs().max())
+        bounds = torch.tensor([12 * mq, 12 * mg, mq, mg], device=dev)
+        pq, pg = to_planes(qkv, 12 * mq), to_planes(dobar, 12 * mg)
+        pQ, pK, pV = (F_._view(pq, i * D, L, dh) for i in range(3))
+        pG = F_._view(pg, 0, L, dh)
+
+        def edges():                                 # noqa: F811
+            st = torch.cuda.current_stream().cuda_stream
+            _lib.check(lib.ampconv_bwd_edge_dst_planes(pQ, pK, pV, pG, csr.rowptr.data_ptr(), csr.col.data_ptr(), N, L, D, H,
+                                                       dQv, None, 0, None, bounds.data_ptr(), spos.data_ptr(),
+                                                       stats.data_ptr(), None, st), 'dst')
+            _lib.check(lib.ampconv_bwd_edge_src_planes(pQ, pK, pV, pG, csr.cscptr.data_ptr(), csr.crow.data_ptr(), N, L, D, H,
+                                                       dKv, dVv, None, 0, None, bounds.data_ptr(), stats.data_ptr(), None, st),
+                       'src')
     native = '--native' in sys.argv                  # libampconv's own projection kernels (bf16 matrix cores)
     img = F_.proj_image(w) if native else None
     dwo, cso = torch.empty(D, D, device=dev), torch.empty(D, device=dev)
+
+    scaled = '--scaled' in sys.argv                  # the projections' three-product mode (what large layers run)
+    ax, ag = (F_.absmax(x), F_.absmax(dobar)) if scaled else (None, None)
 
     def gemms(k):
         for i in range(k):
             if not native:
                 torch.mm(x, w, out=out1)             # [N L, D] x [D, D]: 2 N L D^2 flop each
             elif i % 2 == 0:
-                F_.proj_rows(x, img)
+                F_.proj_rows(x, img, amax=ax)
             else:
-                F_.proj_wgrad(x, dobar, dwo, cso)    # the weight-gradient kernel: the same flop count
+                F_.proj_wgrad(x, dobar, dwo, cso, amax=(ax, ag) if scaled else None)    # the weight-gradient kernel: the same flop count
 
     def timed(fn, iters=5):
         fn()
