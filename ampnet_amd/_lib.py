@@ -89,8 +89,8 @@ SIGNATURES = {
                                            _vp, _vp, _vp, _vp, _vp]),
     'ampconv_proj_out_bound': (_i32, [_vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
     'ampconv_proj_rows_planes': (_i32, [_vp, _i64, _i64, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp, _vp,
-                                        _i32, _vp]),
-    'ampconv_planes_to_f32': (_i32, [_vp, _i64, _i64, _i32, _vp, _vp, _i64, _vp]),
+                                        _i32, _i32, _vp]),
+    'ampconv_planes_to_f32': (_i32, [_vp, _i64, _i64, _i32, _i32, _vp, _vp, _i64, _vp]),
     'ampconv_absmax_stats': (_i32, [_vp, _i64, _i64, _i32, _vp, _vp]),
     'ampconv_active_nodes_workspace_bytes': (_sz, [_i64]),
     'ampconv_active_nodes': (_i32, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),

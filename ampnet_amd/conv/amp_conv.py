@@ -203,7 +203,7 @@ class AMPConv(MessagePassing):
         q_buf, kv_buf, edge_index, L, shared = self._attn_ctx
         if getattr(self, '_attn_plane_bounds', None) is not None:      # plane format -> fp32, once
             with torch.cuda.device(q_buf.device):
-                q_buf = F_.planes_to_f32(q_buf, self._attn_plane_bounds[0:1])
+                q_buf = F_.planes_to_f32(q_buf, self._attn_plane_bounds[0:1], self.embed_dim // self.num_heads)
             self._attn_ctx = (q_buf, kv_buf, edge_index, L, shared)
             self._attn_plane_bounds = None
         if q_buf.dtype != torch.float32:              # side outputs are served in fp32

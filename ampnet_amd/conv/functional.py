@@ -110,7 +110,7 @@ PROJ_SCALED = os.environ.get('AMPCONV_PROJ_SCALED', '1') != '0'
 PROJ_SCALED_MIN_ELEMENTS = 1 << 24
 
 
-# fp32 storage, scaled mode, L <= 20, head width 32, self-attention layers (xq is xkv): the edge passes run on the
+# fp32 storage, scaled mode, L <= 20, head width 32 or 16, self-attention layers (xq is xkv): the edge passes run on the
 # 16-bit matrix pipe -- the in-projection and dObar = dY Wo leave their kernels as two fp16 planes of the scaled value
 # (csrc/edge_mfma_f16x2.hip, include/ampconv.h "edge phase on fp16 PLANES"); '0': the fp32-MFMA edge kernels
 EDGE_PLANES = os.environ.get('AMPCONV_EDGE_PLANES', '1') != '0'
@@ -147,10 +147,10 @@ def operand_stats(t2, key=None):
     return st, narrow
 
 
-def planes_to_f32(buf2d, bound):
-    """fp32 copy of a projection buffer held in the plane format (side outputs, fall-backs)."""
+def planes_to_f32(buf2d, bound, dh=32):
+    """fp32 copy of a projection buffer held in the plane format with slots of `dh` channels (side outputs, fall-backs)."""
     out = torch.empty_like(buf2d)
-    _lib.check(_lib.load().ampconv_planes_to_f32(buf2d.data_ptr(), buf2d.stride(0), buf2d.size(0), buf2d.size(1),
+    _lib.check(_lib.load().ampconv_planes_to_f32(buf2d.data_ptr(), buf2d.stride(0), buf2d.size(0), buf2d.size(1), dh,
                                                  bound.data_ptr(), out.data_ptr(), out.stride(0), _stream()),
                'ampconv_planes_to_f32')
     return out
@@ -166,9 +166,10 @@ def proj_out_bound(W, transpose, bias, amax, out):
                                                   _stream()), 'ampconv_proj_out_bound')
 
 
-def proj_rows_planes(a2, image, bound, bias=None, rowptr=None, L=0, row_scale=0, amax=None, out_amax=None, amax_col0=0):
-    """proj_rows whose output leaves as two fp16 planes of value * 2^e(bound) in the 128-byte slots of the fp32 buffer
-    (include/ampconv.h).  row_scale = 1 (with rowptr): rows are divided by their node's in-degree (0 for none)."""
+def proj_rows_planes(a2, image, bound, bias=None, rowptr=None, L=0, row_scale=0, amax=None, out_amax=None, amax_col0=0,
+                     dh=32):
+    """proj_rows whose output leaves as two fp16 planes of value * 2^e(bound) in the 4 dh-byte head slots of the fp32 buffer
+    (include/ampconv.h; dh = 32 or 16).  row_scale = 1 (with rowptr): rows are divided by their node's in-degree (0 for none)."""
     lib = _lib.load()
     img, N, K, wdt = image
     assert a2.dim() == 2 and a2.size(1) == K and a2.stride(1) == 1 and a2.dtype == wdt == torch.float32
@@ -176,7 +177,7 @@ def proj_rows_planes(a2, image, bound, bias=None, rowptr=None, L=0, row_scale=0,
     out = torch.empty(a2.size(0), N, dtype=wdt, device=a2.device)
     _lib.check(lib.ampconv_proj_rows_planes(a2.data_ptr(), a2.stride(0), a2.size(0), K, img.data_ptr(), N, _ptr(bias),
                                             _ptr(rowptr), L, row_scale, out.data_ptr(), out.stride(0), amax.data_ptr(),
-                                            bound.data_ptr(), _ptr(out_amax), amax_col0, _stream()),
+                                            bound.data_ptr(), _ptr(out_amax), amax_col0, dh, _stream()),
                'ampconv_proj_rows_planes')
     return out
 
@@ -382,7 +383,7 @@ class AMPConvFunction(torch.autograd.Function):
                 # (max |x| times the largest absolute row sum of W, plus max |b|); the recorded maximum covers the V third
                 # only: it bounds Obar, a mean of convex combinations of V rows
                 proj_out_bound(w_in, False, b_in, am[0], bounds[0:1])
-                qkv = proj_rows_planes(xq2, imgs[0], bounds[0:1], b_in, amax=am[0], out_amax=am[1], amax_col0=2 * D)
+                qkv = proj_rows_planes(xq2, imgs[0], bounds[0:1], b_in, amax=am[0], out_amax=am[1], amax_col0=2 * D, dh=dh)
                 Qv, Kv, Vv = (_view(qkv, i * D, L, dh) for i in range(3))
                 kv = None
             elif shared:
@@ -461,7 +462,7 @@ class AMPConvFunction(torch.autograd.Function):
                     am = None
             planes = bounds is not None and ag is not None
             if bounds is not None and not planes:         # the saved projections as fp32 for the exact edge passes
-                qkv = planes_to_f32(qkv, bounds[0:1])
+                qkv = planes_to_f32(qkv, bounds[0:1], dh)
             sl = (lambda t, i: t[i]) if am is not None else (lambda t, i: None)
             pair = (lambda a, b: (a, b)) if am is not None else (lambda a, b: None)
             if native:
@@ -475,7 +476,7 @@ class AMPConvFunction(torch.autograd.Function):
                     proj_out_bound(w_out, True, None, ag[0], bounds[1:2])
                     bounds[3:4].zero_()
                     dobar = proj_rows_planes(dy2, ctx.images_t[-1], bounds[1:2], rowptr=csr.rowptr, L=L, row_scale=1,
-                                             amax=ag[0], out_amax=bounds[3:4])
+                                             amax=ag[0], out_amax=bounds[3:4], dh=dh)
                 else:
                     proj_wgrad(dy2, obar, dw_out, db_out, csr.rowptr, L, amax=pair(sl(ag, 0), sl(am, 1)))
                     dobar = proj_rows(dy2, ctx.images_t[-1], amax=sl(ag, 0))

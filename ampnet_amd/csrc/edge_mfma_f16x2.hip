@@ -39,6 +39,10 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr int kWavesPerBlock = 4;
 constexpr int DH = 32;
+// HALF (dh = 16, BASELINE config 3's head width): the head's slot is 64 bytes (16 hi, 16 lo); its 16 channels occupy the
+// lower half of every 32-channel plane row, the upper half is never written (the images are zeroed once per unit: the
+// 32-deep channel contraction is zero-padded) and only channel tile mc = 0 exists.  Half the bytes per (edge, head) at the
+// same vector work: these shapes are bound by instruction issue, not by HBM.
 constexpr int kRowBytes = DH * 2;                      // one plane of a token row
 constexpr int kPlaneBytes = kLmax * kRowBytes;         // 1280: one plane image
 // the lo image sits an odd multiple of 64 bytes behind the hi image: the 8 lanes that file one 128-byte row (4 hi
@@ -122,32 +126,35 @@ struct PairRegsP {
   i32x4 v[5];
 };
 
-template <bool FULL>
+template <bool FULL, bool HALF>
 __device__ __forceinline__ void pair_load_p(PairRegsP &t, const char *baseA, unsigned strideA, const char *baseB,
                                             unsigned strideB, int L, int lane) {
-  const int r = lane >> 3, q = lane & 7;
+  // dh = 32: 8 lanes per 128-byte slot row, 5 loads; HALF: 4 lanes per 64-byte slot row (chunks 0, 1 hi; 2, 3 lo), 3 loads
+  constexpr int LPR = HALF ? 4 : 8, RPL = 64 / LPR, NLD = HALF ? 3 : 5;
+  const int r = lane / LPR, q = lane % LPR;
 #pragma unroll
-  for (int i = 0; i < 5; ++i) {
-    const int R = r + 8 * i;
+  for (int i = 0; i < NLD; ++i) {
+    const int R = r + RPL * i;
     const bool isB = R >= kLmax;
     const int j = isB ? R - kLmax : R;
     // per-lane part as a 32-bit byte offset on top of a tile base that is uniform per edge (base stays in SGPRs)
     const unsigned off = (unsigned)j * (isB ? strideB : strideA) + 16u * (unsigned)q;
     const char *p = (isB ? baseB : baseA) + off;
-    if (FULL || j < L) t.v[i] = *reinterpret_cast<const i32x4 *>(p);
+    if (R < 2 * kLmax && (FULL || j < L)) t.v[i] = *reinterpret_cast<const i32x4 *>(p);
   }
 }
 
-template <bool FULL>
+template <bool FULL, bool HALF>
 __device__ __forceinline__ void pair_to_lds_p(char *tileA, const PairRegsP &t, int L, int lane) {
-  const int r = lane >> 3, q = lane & 7;
+  constexpr int LPR = HALF ? 4 : 8, RPL = 64 / LPR, NLD = HALF ? 3 : 5, CPP = LPR / 2;      // chunks per plane
+  const int r = lane / LPR, q = lane % LPR;
 #pragma unroll
-  for (int i = 0; i < 5; ++i) {
-    const int R = r + 8 * i;
+  for (int i = 0; i < NLD; ++i) {
+    const int R = r + RPL * i;
     const bool isB = R >= kLmax;
     const int j = isB ? R - kLmax : R;
-    if (FULL || j < L)
-      *reinterpret_cast<i32x4 *>(tileA + (isB ? kTileBytes : 0) + (q >= 4 ? kLoOff : 0) + plane_off(j, q & 3)) = t.v[i];
+    if (R < 2 * kLmax && (FULL || j < L))
+      *reinterpret_cast<i32x4 *>(tileA + (isB ? kTileBytes : 0) + (q >= CPP ? kLoOff : 0) + plane_off(j, q % CPP)) = t.v[i];
   }
 }
 
@@ -165,11 +172,12 @@ __device__ __forceinline__ i32x4 rowfrag(const char *img, int mt, int lane) {
 }
 // ... of column tile nt straight from global memory (the unit's own side, once per unit; plain map: column m of tile 1
 // is token 16 + m; token rows >= L read as zero).  `base` = the row-0 slot of the (node, head), `plane` = 0 / 64
+template <bool HALF>
 __device__ __forceinline__ i32x4 rowfrag_global(const char *base, unsigned row_bytes, int nt, int plane, int L, int lane) {
   const int m = lane & 15, kg = lane >> 4;
   const int j = nt == 0 ? m : 16 + m;
   i32x4 x = {0, 0, 0, 0};
-  if (j < L) x = *reinterpret_cast<const i32x4 *>(base + (unsigned)j * row_bytes + plane + 16 * kg);
+  if (j < L && (!HALF || kg < 2)) x = *reinterpret_cast<const i32x4 *>(base + (unsigned)j * row_bytes + plane + 16 * kg);
   return x;
 }
 // token-product fragment of channel tile mc of ONE plane image: k-slots 0..3 = tokens 4 kg .. 4 kg + 3, slot 4 = token
@@ -202,6 +210,10 @@ __device__ __forceinline__ i32x4 colfrag(const char *img, int mc, int lane) {
     asm volatile("s_nop 7" ::: "memory");      \
     __builtin_amdgcn_sched_barrier(0);         \
   } while (0)
+
+// in front of a group of transposed reads that follows MFMAs of another phase (their fragment registers may be taken
+// over): eight idle cycles and a compiler barrier for memory operations only -- the vector work around it still moves
+#define TR_PRE_READ() asm volatile("s_nop 7" ::: "memory")
 
 // C/D registers (already in the split's units, |x| < 2^16) -> the two planes of a token-product fragment: slots 0..3 =
 // t0 (tokens 4 g + q), slot 4 = t1_0 (token 16 + g), slots 5..7 zero
@@ -263,8 +275,8 @@ __device__ __forceinline__ const char *slot_ptr(const ampconv_view_t &v, int64_t
 // output tile store (fp32): C/D layout lane (n = lane & 15, g), reg q -> channel 4 g + q + 16 mc, token of column n of
 // tile nt: n / 16 + n (plain map) or, QUARTER (the source pass's own tokens sit on quarter-mapped columns), 16 + (n >> 2)
 // for the lanes n % 4 == 0 of tile 1.  Returns the largest finite magnitude stored.
-template <bool QUARTER>
-__device__ __forceinline__ float store_tile(const ampconv_view_t &v, int64_t node, int h, const f32x4 (&T)[2][2],
+template <bool QUARTER, int MC>
+__device__ __forceinline__ float store_tile(const ampconv_view_t &v, int64_t node, int h, const f32x4 (&T)[MC][2],
                                             float scale, int L, int lane) {
   const int g = lane >> 4, n = lane & 15;
   float m = 0.f;
@@ -273,7 +285,7 @@ __device__ __forceinline__ float store_tile(const ampconv_view_t &v, int64_t nod
     const int i = nt == 0 ? n : (QUARTER ? 16 + (n >> 2) : 16 + n);
     if (i < L && (nt == 0 || !QUARTER || (n & 3) == 0)) {
 #pragma unroll
-      for (int mc = 0; mc < 2; ++mc) {
+      for (int mc = 0; mc < MC; ++mc) {
         const float4 o = make_float4(T[mc][nt][0] * scale, T[mc][nt][1] * scale, T[mc][nt][2] * scale,
                                      T[mc][nt][3] * scale);
         const int64_t off = node * v.node_stride + (int64_t)h * v.head_stride + (int64_t)i * v.row_stride + 4 * g + 16 * mc;
@@ -285,16 +297,20 @@ __device__ __forceinline__ float store_tile(const ampconv_view_t &v, int64_t nod
   return m;
 }
 
+template <bool HALF>
 __device__ __forceinline__ void store_zero_tile(const ampconv_view_t &v, int64_t node, int h, int L, int lane) {
-  f32x4 Z[2][2];
+  constexpr int MC = HALF ? 1 : 2;
+  f32x4 Z[MC][2];
 #pragma unroll
-  for (int mc = 0; mc < 2; ++mc) Z[mc][0] = Z[mc][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-  store_tile<false>(v, node, h, Z, 0.f, L, lane);
+  for (int mc = 0; mc < MC; ++mc) Z[mc][0] = Z[mc][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  store_tile<false, MC>(v, node, h, Z, 0.f, L, lane);
 }
 
 // ---------------------------------------------------------------- forward
-template <bool FULL>
+template <bool FULL, bool HALF>
 __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void fwd_f16x2(Args a) {
+  constexpr int MC = HALF ? 1 : 2, kLo = HALF ? 32 : 64;          // channel tiles; byte offset of the lo plane in a slot
+  constexpr float kIs = HALF ? 0.25f : 0.17677669529663687f;     // 1 / sqrt(dh)
   __shared__ __attribute__((aligned(16))) char lds_all[kWavesPerBlock][2 * kTileBytes];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -303,11 +319,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void fwd_f16x2(Args a) {
   int64_t r, onode;
   int h, beg, end, deg;
   if (!map_unit(a.hub, a.ptr, unit, a.n_units, a.H, r, onode, h, beg, end, deg)) return;
-  if (beg >= end && a.hub.mode != 2) return store_zero_tile(a.O, onode, h, a.L, lane);
+  if (beg >= end && a.hub.mode != 2) return store_zero_tile<HALF>(a.O, onode, h, a.L, lane);
   const int L = a.L, g = lane >> 4;
   char *Kt = lds_all[wave], *Vt = Kt + kTileBytes;
   const float uq = 1.f / plane_scale(a.bounds[0]);           // exact: a power of two
-  const float sc = (kLog2e * 0.17677669529663687f * uq) * uq;   // log2e / sqrt(32) / (scale of Q' K'^T)
+  const float sc = (kLog2e * kIs * uq) * uq;   // log2e / sqrt(32) / (scale of Q' K'^T)
 
   i32x4 qh[2], ql[2];
   {
@@ -315,28 +331,28 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void fwd_f16x2(Args a) {
     const unsigned rb = (unsigned)a.Q.row_stride * 4u;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
-      qh[nt] = rowfrag_global(qb, rb, nt, 0, L, lane);
-      ql[nt] = rowfrag_global(qb, rb, nt, 64, L, lane);
+      qh[nt] = rowfrag_global<HALF>(qb, rb, nt, 0, L, lane);
+      ql[nt] = rowfrag_global<HALF>(qb, rb, nt, kLo, L, lane);
     }
   }
-  if (!FULL) lds_zero(Kt, 2 * kTileBytes, lane);
-  f32x4 OT[2][2];
+  if (!FULL || HALF) lds_zero(Kt, 2 * kTileBytes, lane);
+  f32x4 OT[MC][2];
 #pragma unroll
-  for (int mc = 0; mc < 2; ++mc) OT[mc][0] = OT[mc][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int mc = 0; mc < MC; ++mc) OT[mc][0] = OT[mc][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   PairRegsP kv;
   IdxWindow win;
   const unsigned krb = (unsigned)a.K.row_stride * 4u, vrb = (unsigned)a.V.row_stride * 4u;
   auto fetch = [&](int p) {
     const int64_t s = idxwin_get<false>(win, a.idx, nullptr, p, end, lane, nullptr);
-    pair_load_p<FULL>(kv, slot_ptr(a.K, s, h), krb, slot_ptr(a.V, s, h), vrb, L, lane);
+    pair_load_p<FULL, HALF>(kv, slot_ptr(a.K, s, h), krb, slot_ptr(a.V, s, h), vrb, L, lane);
   };
   if (beg < end) {
     idxwin_load<false>(win, a.idx, nullptr, beg, end, lane);
     fetch(beg);
   }
   for (int p = beg; p < end; ++p) {
-    pair_to_lds_p<FULL>(Kt, kv, L, lane);
+    pair_to_lds_p<FULL, HALF>(Kt, kv, L, lane);
     if (p + 1 < end) fetch(p + 1);
     __builtin_amdgcn_wave_barrier();
 
@@ -349,30 +365,32 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 4) void fwd_f16x2(Args a) {
     }
     i32x4 ph[2], pl[2];
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      column_softmax<FULL>(S[0][nt], S[1][nt], sc, kPScale, L, g);
-      cd_frag2(S[0][nt], S[1][nt][0], ph[nt], pl[nt]);
-    }
-    i32x4 vh[2], vl[2];
+    for (int nt = 0; nt < 2; ++nt) column_softmax<FULL>(S[0][nt], S[1][nt], sc, kPScale, L, g);
+    i32x4 vh[MC], vl[MC];
+    TR_PRE_READ();
 #pragma unroll
-    for (int mc = 0; mc < 2; ++mc) {
+    for (int mc = 0; mc < MC; ++mc) {
       vh[mc] = colfrag(Vt, mc, lane);
       vl[mc] = colfrag(Vt + kLoOff, mc, lane);
     }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) cd_frag2(S[0][nt], S[1][nt][0], ph[nt], pl[nt]);      // (in the shadow of the reads)
     TR_FRAG_FENCE();
 #pragma unroll
-    for (int mc = 0; mc < 2; ++mc)
+    for (int mc = 0; mc < MC; ++mc)
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) OT[mc][nt] = mfma3(vh[mc], vl[mc], ph[nt], pl[nt], OT[mc][nt]);
     __builtin_amdgcn_wave_barrier();
   }
   const bool hubp = a.hub.mode == 2;
-  store_tile<false>(a.O, onode, h, OT, kPUnscale * uq * (hubp ? 1.f : (deg > 0 ? 1.f / (float)deg : 0.f)), L, lane);
+  store_tile<false, MC>(a.O, onode, h, OT, kPUnscale * uq * (hubp ? 1.f : (deg > 0 ? 1.f / (float)deg : 0.f)), L, lane);
 }
 
 // ---------------------------------------------------------------- backward, destination pass
-template <bool FULL, bool STATS>
+template <bool FULL, bool STATS, bool HALF>
 __global__ __launch_bounds__(64 * kWavesPerBlock, 3) void bwd_dst_f16x2(Args a) {
+  constexpr int MC = HALF ? 1 : 2, kLo = HALF ? 32 : 64;
+  constexpr float kIs = HALF ? 0.25f : 0.17677669529663687f;
   __shared__ __attribute__((aligned(16))) char lds_all[kWavesPerBlock][2 * kTileBytes];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -381,11 +399,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 3) void bwd_dst_f16x2(Args a) 
   int64_t r, onode;
   int h, beg, end, deg;
   if (!map_unit(a.hub, a.ptr, unit, a.n_units, a.H, r, onode, h, beg, end, deg)) return;
-  if (beg >= end && a.hub.mode != 2) return store_zero_tile(a.O, onode, h, a.L, lane);
+  if (beg >= end && a.hub.mode != 2) return store_zero_tile<HALF>(a.O, onode, h, a.L, lane);
   const int L = a.L, g = lane >> 4;
   char *Kt = lds_all[wave], *Vt = Kt + kTileBytes;
   const float uq = 1.f / plane_scale(a.bounds[0]), ug = 1.f / plane_scale(a.bounds[1]);
-  const float sc = (kLog2e * 0.17677669529663687f * uq) * uq;
+  const float sc = (kLog2e * kIs * uq) * uq;
 
   i32x4 qh[2], ql[2], gh[2], gl[2];
   {
@@ -393,18 +411,18 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 3) void bwd_dst_f16x2(Args a) 
     const unsigned qrb = (unsigned)a.Q.row_stride * 4u, grb = (unsigned)a.dO.row_stride * 4u;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
-      qh[nt] = rowfrag_global(qb, qrb, nt, 0, L, lane);
-      ql[nt] = rowfrag_global(qb, qrb, nt, 64, L, lane);
-      gh[nt] = rowfrag_global(gb, grb, nt, 0, L, lane);
-      gl[nt] = rowfrag_global(gb, grb, nt, 64, L, lane);
+      qh[nt] = rowfrag_global<HALF>(qb, qrb, nt, 0, L, lane);
+      ql[nt] = rowfrag_global<HALF>(qb, qrb, nt, kLo, L, lane);
+      gh[nt] = rowfrag_global<HALF>(gb, grb, nt, 0, L, lane);
+      gl[nt] = rowfrag_global<HALF>(gb, grb, nt, kLo, L, lane);
     }
   }
   // dS scale of this unit: its own dObar rows against the bound of any V row
   const float ss = ds_scale(tile_max_norm2(gh[0], gh[1]), a.bounds[2] * plane_scale(a.bounds[0]));
-  if (!FULL) lds_zero(Kt, 2 * kTileBytes, lane);
-  f32x4 dQT[2][2];
+  if (!FULL || HALF) lds_zero(Kt, 2 * kTileBytes, lane);
+  f32x4 dQT[MC][2];
 #pragma unroll
-  for (int mc = 0; mc < 2; ++mc) dQT[mc][0] = dQT[mc][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int mc = 0; mc < MC; ++mc) dQT[mc][0] = dQT[mc][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   PairRegsP kv;
   IdxWindow win;
@@ -414,14 +432,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 3) void bwd_dst_f16x2(Args a) 
   float cposf = 0.f, cposf_next = 0.f;
   auto fetch = [&](int p) {
     const int64_t s = idxwin_get<STATS>(win, a.idx, sposf, p, end, lane, &cposf_next);
-    pair_load_p<FULL>(kv, slot_ptr(a.K, s, h), krb, slot_ptr(a.V, s, h), vrb, L, lane);
+    pair_load_p<FULL, HALF>(kv, slot_ptr(a.K, s, h), krb, slot_ptr(a.V, s, h), vrb, L, lane);
   };
   if (beg < end) {
     idxwin_load<STATS>(win, a.idx, sposf, beg, end, lane);
     fetch(beg);
   }
   for (int p = beg; p < end; ++p) {
-    pair_to_lds_p<FULL>(Kt, kv, L, lane);
+    pair_to_lds_p<FULL, HALF>(Kt, kv, L, lane);
     cposf = cposf_next;
     if (p + 1 < end) fetch(p + 1);
     __builtin_amdgcn_wave_barrier();
@@ -450,17 +468,19 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 3) void bwd_dst_f16x2(Args a) 
 #pragma unroll
       for (int q = 0; q < 4; ++q) S[0][nt][q] *= (dP[0][nt][q] - delta) * ss;      // dS^T in the unit's split scale
       S[1][nt][0] *= (dP[1][nt][0] - delta) * ss;
-      cd_frag2(S[0][nt], S[1][nt][0], sh[nt], sl[nt]);
     }
-    i32x4 ch[2], cl[2];
+    i32x4 ch[MC], cl[MC];
+    TR_PRE_READ();
 #pragma unroll
-    for (int mc = 0; mc < 2; ++mc) {
+    for (int mc = 0; mc < MC; ++mc) {
       ch[mc] = colfrag(Kt, mc, lane);
       cl[mc] = colfrag(Kt + kLoOff, mc, lane);
     }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) cd_frag2(S[0][nt], S[1][nt][0], sh[nt], sl[nt]);
     TR_FRAG_FENCE();
 #pragma unroll
-    for (int mc = 0; mc < 2; ++mc)
+    for (int mc = 0; mc < MC; ++mc)
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) dQT[mc][nt] = mfma3(ch[mc], cl[mc], sh[nt], sl[nt], dQT[mc][nt]);
     if (STATS) {
@@ -477,7 +497,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 3) void bwd_dst_f16x2(Args a) 
   // dQ = sum dS K / sqrt(dh): undo the split scale, the scales of dP' (Q|K|V and dObar) and of K'; the hub pass leaves
   // 1/sqrt(dh) to the combine pass
   const bool hubp = a.hub.mode == 2;
-  const float m = store_tile<false>(a.O, onode, h, dQT, (((1.f / ss) * uq) * ug) * uq * (hubp ? 1.f : 0.17677669529663687f),
+  const float m = store_tile<false, MC>(a.O, onode, h, dQT, (((1.f / ss) * uq) * ug) * uq * (hubp ? 1.f : kIs),
                                     L, lane);
   if (a.absmax) wave_record_absmax(a.absmax, m);
 }
@@ -488,8 +508,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 3) void bwd_dst_f16x2(Args a) 
 // map (column n <-> token 16 + (n >> 2): every tail token four times, no row of the 20-row image is read out of
 // range); the row softmax masks the replicas, the store takes the lanes n % 4 == 0.
 constexpr int kSrcLds = 4 * kTileBytes + 2 * kLmax * 4 + 32;      // four tile images + the edge's statistics (padded to 16)
-template <bool FULL, bool STATS>
+template <bool FULL, bool STATS, bool HALF>
 __global__ __launch_bounds__(64 * kWavesPerBlock, 3) void bwd_src_f16x2(Args a) {
+  constexpr int MC = HALF ? 1 : 2;
+  constexpr float kIs = HALF ? 0.25f : 0.17677669529663687f;
   __shared__ __attribute__((aligned(16))) char lds_all[kWavesPerBlock][kSrcLds];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -499,25 +521,25 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 3) void bwd_src_f16x2(Args a) 
   int h, beg, end, deg;
   if (!map_unit(a.hub, a.ptr, unit, a.n_units, a.H, s, onode, h, beg, end, deg)) return;
   if (beg >= end && a.hub.mode != 2) {
-    store_zero_tile(a.dK, onode, h, a.L, lane);
-    return store_zero_tile(a.dV, onode, h, a.L, lane);
+    store_zero_tile<HALF>(a.dK, onode, h, a.L, lane);
+    return store_zero_tile<HALF>(a.dV, onode, h, a.L, lane);
   }
   const int L = a.L, n = lane & 15;
   char *Qt = lds_all[wave], *Gt = Qt + kTileBytes, *Ko = Gt + kTileBytes, *Vo = Ko + kTileBytes;
   const float uq = 1.f / plane_scale(a.bounds[0]), ug = 1.f / plane_scale(a.bounds[1]);
-  const float sc = (kLog2e * 0.17677669529663687f * uq) * uq;
+  const float sc = (kLog2e * kIs * uq) * uq;
 
-  if (!FULL) lds_zero(Qt, 4 * kTileBytes, lane);
+  if (!FULL || HALF) lds_zero(Qt, 4 * kTileBytes, lane);
   PairRegsP qg;
-  pair_load_p<FULL>(qg, slot_ptr(a.K, s, h), (unsigned)a.K.row_stride * 4u, slot_ptr(a.V, s, h),
+  pair_load_p<FULL, HALF>(qg, slot_ptr(a.K, s, h), (unsigned)a.K.row_stride * 4u, slot_ptr(a.V, s, h),
                     (unsigned)a.V.row_stride * 4u, L, lane);
-  pair_to_lds_p<FULL>(Ko, qg, L, lane);
+  pair_to_lds_p<FULL, HALF>(Ko, qg, L, lane);
   __builtin_amdgcn_wave_barrier();
   // dS scale of this unit: its own V rows against the bound of any dObar row
   const float ss = ds_scale(tile_max_norm2(rowfrag(Vo, 0, lane), rowfrag(Vo, 1, lane)), a.bounds[3] * plane_scale(a.bounds[1]));
-  f32x4 dKT[2][2], dVT[2][2];
+  f32x4 dKT[MC][2], dVT[MC][2];
 #pragma unroll
-  for (int mc = 0; mc < 2; ++mc)
+  for (int mc = 0; mc < MC; ++mc)
     dKT[mc][0] = dKT[mc][1] = dVT[mc][0] = dVT[mc][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   IdxWindow win;
@@ -526,7 +548,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 3) void bwd_src_f16x2(Args a) 
   float sv = 0.f;                                               // lane l < 40: statistic l of the edge in flight
   auto fetch = [&](int p) {
     const int64_t d = idxwin_get<false>(win, a.idx, nullptr, p, end, lane, nullptr);
-    pair_load_p<FULL>(qg, slot_ptr(a.Q, d, h), qrb, slot_ptr(a.dO, d, h), grb, L, lane);
+    pair_load_p<FULL, HALF>(qg, slot_ptr(a.Q, d, h), qrb, slot_ptr(a.dO, d, h), grb, L, lane);
     if (STATS && lane < kStatsPerUnit) sv = a.stats[((int64_t)p * a.H + h) * kStatsPerUnit + lane];
   };
   if (beg < end) {
@@ -536,7 +558,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 3) void bwd_src_f16x2(Args a) 
   // own tokens on the columns: tile 0 column n = token n, tile 1 column n = token 16 + (n >> 2), one lane per token
   const bool v0 = FULL || n < L, v1 = (n & 3) == 0 && 16 + (n >> 2) < L;
   for (int p = beg; p < end; ++p) {
-    pair_to_lds_p<FULL>(Qt, qg, L, lane);
+    pair_to_lds_p<FULL, HALF>(Qt, qg, L, lane);
     if (STATS && lane < kStatsPerUnit) stl[lane] = sv;
     if (p + 1 < end) fetch(p + 1);
     __builtin_amdgcn_wave_barrier();
@@ -606,33 +628,34 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 3) void bwd_src_f16x2(Args a) 
     }
     }
     {
-      i32x4 ph[2], pl[2], gh[2], gl[2];
+      i32x4 ph[2], pl[2], gh[MC], gl[MC];
+      TR_PRE_READ();
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) cd_frag2(S[0][nt], S[1][nt][0], ph[nt], pl[nt]);
-#pragma unroll
-      for (int mc = 0; mc < 2; ++mc) {
+      for (int mc = 0; mc < MC; ++mc) {
         gh[mc] = colfrag(Gt, mc, lane);
         gl[mc] = colfrag(Gt + kLoOff, mc, lane);
       }
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) cd_frag2(S[0][nt], S[1][nt][0], ph[nt], pl[nt]);
       TR_FRAG_FENCE();
 #pragma unroll
-      for (int mc = 0; mc < 2; ++mc)
+      for (int mc = 0; mc < MC; ++mc)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) dVT[mc][nt] = mfma3(gh[mc], gl[mc], ph[nt], pl[nt], dVT[mc][nt]);
       TR_WAR_GUARD();
     }
     {
-      i32x4 sh[2], sl[2], qh[2], ql[2];
+      i32x4 sh[2], sl[2], qh[MC], ql[MC];
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) cd_frag2(dP[0][nt], dP[1][nt][0], sh[nt], sl[nt]);
-#pragma unroll
-      for (int mc = 0; mc < 2; ++mc) {
+      for (int mc = 0; mc < MC; ++mc) {
         qh[mc] = colfrag(Qt, mc, lane);
         ql[mc] = colfrag(Qt + kLoOff, mc, lane);
       }
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) cd_frag2(dP[0][nt], dP[1][nt][0], sh[nt], sl[nt]);
       TR_FRAG_FENCE();
 #pragma unroll
-      for (int mc = 0; mc < 2; ++mc)
+      for (int mc = 0; mc < MC; ++mc)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) dKT[mc][nt] = mfma3(qh[mc], ql[mc], sh[nt], sl[nt], dKT[mc][nt]);
     }
@@ -640,23 +663,42 @@ __global__ __launch_bounds__(64 * kWavesPerBlock, 3) void bwd_src_f16x2(Args a) 
   }
   // dK = sum dS^T Q / sqrt(dh), dV = sum P^T dObar (1/deg is inside dObar); the hub pass leaves 1/sqrt(dh) to the combine
   const bool hubp = a.hub.mode == 2;
-  float m = store_tile<true>(a.dK, onode, h, dKT, (((1.f / ss) * uq) * ug) * uq * (hubp ? 1.f : 0.17677669529663687f), L, lane);
-  m = fmaxf(m, store_tile<true>(a.dV, onode, h, dVT, kPUnscale * ug, L, lane));
+  float m = store_tile<true, MC>(a.dK, onode, h, dKT, (((1.f / ss) * uq) * ug) * uq * (hubp ? 1.f : kIs), L, lane);
+  m = fmaxf(m, store_tile<true, MC>(a.dV, onode, h, dVT, kPUnscale * ug, L, lane));
   if (a.absmax) wave_record_absmax(a.absmax, m);
 }
 
 typedef void (*EdgeKernel)(Args);
-int launch(Args &a, int L, EdgeKernel full, EdgeKernel ragged, hipStream_t stream) {
+// kernels[2 * half + full]
+int launch(Args &a, int L, bool half, EdgeKernel const (&kernels)[4], hipStream_t stream) {
   const int64_t blocks = (a.n_units + kWavesPerBlock - 1) / kWavesPerBlock;
   if (blocks > INT32_MAX) return AMPCONV_E_BADARG;
   const dim3 grid((unsigned)blocks), block(64 * kWavesPerBlock);
-  (L == kLmax ? full : ragged)<<<grid, block, 0, stream>>>(a);
+  kernels[2 * half + (L == kLmax)]<<<grid, block, 0, stream>>>(a);
   return ampconv_launch_status();
 }
+int launch_fwd(Args &a, int L, bool half, hipStream_t st) {
+  static const EdgeKernel k[4] = {fwd_f16x2<false, false>, fwd_f16x2<true, false>, fwd_f16x2<false, true>, fwd_f16x2<true, true>};
+  return launch(a, L, half, k, st);
+}
+int launch_dst(Args &a, int L, bool half, hipStream_t st) {
+  static const EdgeKernel ks[4] = {bwd_dst_f16x2<false, true, false>, bwd_dst_f16x2<true, true, false>,
+                                   bwd_dst_f16x2<false, true, true>, bwd_dst_f16x2<true, true, true>};
+  static const EdgeKernel kn[4] = {bwd_dst_f16x2<false, false, false>, bwd_dst_f16x2<true, false, false>,
+                                   bwd_dst_f16x2<false, false, true>, bwd_dst_f16x2<true, false, true>};
+  return a.stats ? launch(a, L, half, ks, st) : launch(a, L, half, kn, st);
+}
+int launch_src(Args &a, int L, bool half, hipStream_t st) {
+  static const EdgeKernel ks[4] = {bwd_src_f16x2<false, true, false>, bwd_src_f16x2<true, true, false>,
+                                   bwd_src_f16x2<false, true, true>, bwd_src_f16x2<true, true, true>};
+  static const EdgeKernel kn[4] = {bwd_src_f16x2<false, false, false>, bwd_src_f16x2<true, false, false>,
+                                   bwd_src_f16x2<false, false, true>, bwd_src_f16x2<true, false, true>};
+  return a.stats ? launch(a, L, half, ks, st) : launch(a, L, half, kn, st);
+}
 
-// planes: 16-byte aligned, the head's 32 channels one 128-byte slot, rows a whole number of 16-byte pieces apart
-inline bool plane_view_ok(const ampconv_view_t &v) {
-  return v.ptr && ((uintptr_t)v.ptr % 16 == 0) && v.head_stride == DH && (v.node_stride % 4 == 0) && (v.row_stride % 4 == 0);
+// planes: 16-byte aligned, the head's dh channels one 4 dh-byte slot, rows a whole number of 16-byte pieces apart
+inline bool plane_view_ok(const ampconv_view_t &v, int dh) {
+  return v.ptr && ((uintptr_t)v.ptr % 16 == 0) && v.head_stride == dh && (v.node_stride % 4 == 0) && (v.row_stride % 4 == 0);
 }
 inline bool f32_view_ok(const ampconv_view_t &v) {
   return v.ptr && ((uintptr_t)v.ptr % 16 == 0) && (v.head_stride % 4 == 0) && (v.node_stride % 4 == 0) && (v.row_stride % 4 == 0);
@@ -667,14 +709,14 @@ ampconv_view_t partial_view(void *ws, int64_t tile, int64_t n_chunks, int L, int
 }
 int check_shape(int64_t n, int L, int D, int H, const float *bounds) {
   if (L <= 0 || D <= 0 || H <= 0 || D % H != 0 || n < 0 || !bounds) return AMPCONV_E_BADARG;
-  if (L > kLmax || D / H != DH) return AMPCONV_E_DTYPE;
+  if (L > kLmax || (D / H != DH && D / H != DH / 2)) return AMPCONV_E_DTYPE;
   return AMPCONV_OK;
 }
 
 }  // namespace
 
 extern "C" int ampconv_planes_supported(int L, int D, int H) {
-  return L >= 1 && L <= kLmax && H > 0 && D % H == 0 && D / H == DH;
+  return L >= 1 && L <= kLmax && H > 0 && D % H == 0 && (D / H == DH || D / H == DH / 2);
 }
 
 extern "C" int ampconv_fwd_edge_planes(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V, const int32_t *rowptr,
@@ -683,7 +725,7 @@ extern "C" int ampconv_fwd_edge_planes(ampconv_view_t Q, ampconv_view_t K, ampco
                                        void *stream) {
   if (int rc = check_shape(n_rows, L, D, H, bounds)) return rc;
   if (n_rows == 0) return AMPCONV_OK;
-  if (!plane_view_ok(Q) || !plane_view_ok(K) || !plane_view_ok(V) || !f32_view_ok(O) || !rowptr) return AMPCONV_E_BADARG;
+  if (!plane_view_ok(Q, D / H) || !plane_view_ok(K, D / H) || !plane_view_ok(V, D / H) || !f32_view_ok(O) || !rowptr) return AMPCONV_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
   Args a{};
   a.Q = Q; a.K = K; a.V = V; a.O = O;
@@ -691,17 +733,17 @@ extern "C" int ampconv_fwd_edge_planes(ampconv_view_t Q, ampconv_view_t K, ampco
   if (hub_plan && hub_chunks > 0 && hub_ws) {          // long segments: main + hub + combine
     a.hub = HubArgs{(const int32_t *)hub_plan, 1};
     a.n_units = n_rows * H;
-    if (int rc = launch(a, L, fwd_f16x2<true>, fwd_f16x2<false>, st)) return rc;
+    if (int rc = launch_fwd(a, L, D / H == DH / 2, st)) return rc;
     const ampconv_view_t P = partial_view(hub_ws, 0, hub_chunks, L, D, H);
     a.O = P;
     a.hub.mode = 2;
     a.n_units = hub_chunks * H;
-    if (int rc = launch(a, L, fwd_f16x2<true>, fwd_f16x2<false>, st)) return rc;
+    if (int rc = launch_fwd(a, L, D / H == DH / 2, st)) return rc;
     return ampconv_hub_combine(hub_plan, hub_chunks, (const float *)P.ptr, O, rowptr, L, D, H, 1.f, 0, st);
   }
   a.hub = HubArgs{nullptr, 0};
   a.n_units = n_rows * H;
-  return launch(a, L, fwd_f16x2<true>, fwd_f16x2<false>, st);
+  return launch_fwd(a, L, D / H == DH / 2, st);
 }
 
 extern "C" int ampconv_bwd_edge_dst_planes(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V, ampconv_view_t dObar,
@@ -712,7 +754,7 @@ extern "C" int ampconv_bwd_edge_dst_planes(ampconv_view_t Q, ampconv_view_t K, a
   if (int rc = check_shape(n_rows, L, D, H, bounds)) return rc;
   if (stats && (!spos || (uintptr_t)stats % 16 != 0)) return AMPCONV_E_BADARG;
   if (n_rows == 0) return AMPCONV_OK;
-  if (!plane_view_ok(Q) || !plane_view_ok(K) || !plane_view_ok(V) || !plane_view_ok(dObar) || !f32_view_ok(dQ) || !rowptr)
+  if (!plane_view_ok(Q, D / H) || !plane_view_ok(K, D / H) || !plane_view_ok(V, D / H) || !plane_view_ok(dObar, D / H) || !f32_view_ok(dQ) || !rowptr)
     return AMPCONV_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
   Args a{};
@@ -722,19 +764,19 @@ extern "C" int ampconv_bwd_edge_dst_planes(ampconv_view_t Q, ampconv_view_t K, a
   if (hub_plan && hub_chunks > 0 && hub_ws) {
     a.hub = HubArgs{(const int32_t *)hub_plan, 1};
     a.n_units = n_rows * H;
-    if (int rc = (a.stats ? launch(a, L, bwd_dst_f16x2<true, true>, bwd_dst_f16x2<false, true>, st) : launch(a, L, bwd_dst_f16x2<true, false>, bwd_dst_f16x2<false, false>, st))) return rc;
+    if (int rc = launch_dst(a, L, D / H == DH / 2, st)) return rc;
     const ampconv_view_t P = partial_view(hub_ws, 0, hub_chunks, L, D, H);
     a.O = P;
     a.absmax = nullptr;                                // partial tiles: the combine pass records what it writes
     a.hub.mode = 2;
     a.n_units = hub_chunks * H;
-    if (int rc = (a.stats ? launch(a, L, bwd_dst_f16x2<true, true>, bwd_dst_f16x2<false, true>, st) : launch(a, L, bwd_dst_f16x2<true, false>, bwd_dst_f16x2<false, false>, st))) return rc;
-    return ampconv_hub_combine(hub_plan, hub_chunks, (const float *)P.ptr, dQ, nullptr, L, D, H, 1.f / sqrtf((float)DH),
+    if (int rc = launch_dst(a, L, D / H == DH / 2, st)) return rc;
+    return ampconv_hub_combine(hub_plan, hub_chunks, (const float *)P.ptr, dQ, nullptr, L, D, H, 1.f / sqrtf((float)(D / H)),
                                0, st, out_absmax);
   }
   a.hub = HubArgs{nullptr, 0};
   a.n_units = n_rows * H;
-  return (a.stats ? launch(a, L, bwd_dst_f16x2<true, true>, bwd_dst_f16x2<false, true>, st) : launch(a, L, bwd_dst_f16x2<true, false>, bwd_dst_f16x2<false, false>, st));
+  return launch_dst(a, L, D / H == DH / 2, st);
 }
 
 extern "C" int ampconv_bwd_edge_src_planes(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V, ampconv_view_t dObar,
@@ -745,7 +787,7 @@ extern "C" int ampconv_bwd_edge_src_planes(ampconv_view_t Q, ampconv_view_t K, a
   if (int rc = check_shape(n_src, L, D, H, bounds)) return rc;
   if (stats && (uintptr_t)stats % 16 != 0) return AMPCONV_E_BADARG;
   if (n_src == 0) return AMPCONV_OK;
-  if (!plane_view_ok(Q) || !plane_view_ok(K) || !plane_view_ok(V) || !plane_view_ok(dObar) || !f32_view_ok(dK) ||
+  if (!plane_view_ok(Q, D / H) || !plane_view_ok(K, D / H) || !plane_view_ok(V, D / H) || !plane_view_ok(dObar, D / H) || !f32_view_ok(dK) ||
       !f32_view_ok(dV) || !cscptr)
     return AMPCONV_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
@@ -756,20 +798,20 @@ extern "C" int ampconv_bwd_edge_src_planes(ampconv_view_t Q, ampconv_view_t K, a
   if (hub_plan && hub_chunks > 0 && hub_ws) {
     a.hub = HubArgs{(const int32_t *)hub_plan, 1};
     a.n_units = n_src * H;
-    if (int rc = (a.stats ? launch(a, L, bwd_src_f16x2<true, true>, bwd_src_f16x2<false, true>, st) : launch(a, L, bwd_src_f16x2<true, false>, bwd_src_f16x2<false, false>, st))) return rc;
+    if (int rc = launch_src(a, L, D / H == DH / 2, st)) return rc;
     const ampconv_view_t PK = partial_view(hub_ws, 0, hub_chunks, L, D, H), PV = partial_view(hub_ws, 1, hub_chunks, L, D, H);
     a.dK = PK;
     a.dV = PV;
     a.absmax = nullptr;
     a.hub.mode = 2;
     a.n_units = hub_chunks * H;
-    if (int rc = (a.stats ? launch(a, L, bwd_src_f16x2<true, true>, bwd_src_f16x2<false, true>, st) : launch(a, L, bwd_src_f16x2<true, false>, bwd_src_f16x2<false, false>, st))) return rc;
+    if (int rc = launch_src(a, L, D / H == DH / 2, st)) return rc;
     if (int rc = ampconv_hub_combine(hub_plan, hub_chunks, (const float *)PK.ptr, dK, nullptr, L, D, H,
-                                     1.f / sqrtf((float)DH), 0, st, out_absmax))
+                                     1.f / sqrtf((float)(D / H)), 0, st, out_absmax))
       return rc;
     return ampconv_hub_combine(hub_plan, hub_chunks, (const float *)PV.ptr, dV, nullptr, L, D, H, 1.f, 0, st, out_absmax);
   }
   a.hub = HubArgs{nullptr, 0};
   a.n_units = n_src * H;
-  return (a.stats ? launch(a, L, bwd_src_f16x2<true, true>, bwd_src_f16x2<false, true>, st) : launch(a, L, bwd_src_f16x2<true, false>, bwd_src_f16x2<false, false>, st));
+  return launch_src(a, L, D / H == DH / 2, st);
 }

@@ -241,6 +241,7 @@ struct RowsArgs {
   // PLANES (scaled mode only): `out` receives, per 32-column block, the two fp16 planes of value * plane_scale(*out_bound)
   // (the format of csrc/edge_mfma_f16x2.hip); out_bound: device float, an upper bound of the output's magnitudes
   const float *out_bound;
+  int plane_dh;               // ... channels per slot: 32 (128-byte slots) or 16 (64-byte slots: two heads per 32-column block)
   int row_scale;              // with rowptr: 0 = rows of nodes with an empty segment come out 0 (the mask),
                               // 1 = every row is DIVIDED by its node's segment length as well (1 / in-degree)
 };
@@ -509,6 +510,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void proj_rows_kernel(RowsArgs a) 
       auto store_planes = [&](auto ragged) {
         const float kso = ua * uw * so;
         const int pr = lane >> 2, pc = lane & 3, ps = (pr >> 1) & 1;
+        // byte offsets of this lane's 8 channels in the 128 bytes of the sub-tile row: slots of 32 channels hold
+        // [32 hi | 32 lo], slots of 16 channels [16 hi | 16 lo] twice
+        const int ohi = a.plane_dh == 32 ? 16 * pc : 64 * (pc >> 1) + 16 * (pc & 1), olo = ohi + 2 * a.plane_dh;
 #pragma unroll
         for (int i = 0; i < MTW; ++i) {
           const int rl0 = (MTW * wm + i) * 32;
@@ -534,9 +538,9 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void proj_rows_kernel(RowsArgs a) 
               const Pair3 p0 = split_pair_h(v0.x, v0.y, 1.f), p1 = split_pair_h(v0.z, v0.w, 1.f);
               const Pair3 p2 = split_pair_h(v1.x, v1.y, 1.f), p3 = split_pair_h(v1.z, v1.w, 1.f);
               if ((!decltype(ragged)::value || cur.row0 + rl0 + row < a.M) && (!RAGGED || colt < a.N)) {
-                char *o = reinterpret_cast<char *>(a.out + (cur.row0 + rl0 + row) * a.ldc + colt) + 16 * pc;
-                *reinterpret_cast<i32x4 *>(o) = i32x4{p0.h1, p1.h1, p2.h1, p3.h1};
-                *reinterpret_cast<i32x4 *>(o + 64) = i32x4{p0.h2, p1.h2, p2.h2, p3.h2};
+                char *o = reinterpret_cast<char *>(a.out + (cur.row0 + rl0 + row) * a.ldc + colt);
+                *reinterpret_cast<i32x4 *>(o + ohi) = i32x4{p0.h1, p1.h1, p2.h1, p3.h1};
+                *reinterpret_cast<i32x4 *>(o + olo) = i32x4{p0.h2, p1.h2, p2.h2, p3.h2};
                 if (rec) omax = finite_abs_max(finite_abs_max(omax, v0), v1);       // (in plane units: undone at the end)
               }
             }
@@ -964,7 +968,7 @@ extern "C" int ampconv_proj_weight_image(const void *W, int64_t stride_n, int64_
 // fp32 storage; out_bound != null: plane output (ampconv_proj_rows_planes)
 static int proj_rows_f32(const void *A_, int64_t lda, int64_t M, int K, const void *wimage, int N, const void *bias_,
                          const int32_t *rowptr, int L, void *out_, int64_t ldc, const float *a_absmax, float *out_absmax,
-                         int amax_col0, const float *out_bound, int row_scale, void *stream) {
+                         int amax_col0, const float *out_bound, int plane_dh, int row_scale, void *stream) {
   if (out_absmax && !a_absmax) return AMPCONV_E_BADARG;           // recorded by the scaled kernels only
   // planes: scaled mode, whole 128-byte slots, and the unpadded tile shapes only (N % 128 == 0, K % 32 == 0)
   if (out_bound && (!a_absmax || N % 128 || K % 32 || ldc % 32)) return AMPCONV_E_BADARG;
@@ -992,7 +996,7 @@ static int proj_rows_f32(const void *A_, int64_t lda, int64_t M, int K, const vo
   const char *img = (const char *)wimage;
   RowsArgs a{A, lda, M, K, N, hp ? img + image_half_offset(N, K) : img, bias, rowptr, L, out, ldc, (int)rts,
              rtp * (Np / bn), Kp, Np, a_absmax, (const float *)(img + image_amax_offset(N, K)) + kAmaxParts, out_absmax,
-             amax_col0, out_bound, row_scale};
+             amax_col0, out_bound, plane_dh, row_scale};
   const int n_cu = cu_count();
   // a multiple of 8: slot u of a workgroup keeps u % 8 (its XCD label), so "my next slot is invalid" means "nothing
   // further for me" only then (a.tiles is a multiple of 8 by construction)
@@ -1026,16 +1030,17 @@ extern "C" int ampconv_proj_rows(const void *A_, int64_t lda, int64_t M, int K, 
                                   (hipStream_t)stream);
   }
   if (dtype != AMPCONV_F32 || nodes) return AMPCONV_E_DTYPE;      // node lists: bf16 storage only
-  return proj_rows_f32(A_, lda, M, K, wimage, N, bias_, rowptr, L, out_, ldc, a_absmax, out_absmax, 0, nullptr, 0, stream);
+  return proj_rows_f32(A_, lda, M, K, wimage, N, bias_, rowptr, L, out_, ldc, a_absmax, out_absmax, 0, nullptr, 32, 0, stream);
 }
 
 extern "C" int ampconv_proj_rows_planes(const void *A, int64_t lda, int64_t M, int K, const void *wimage, int N,
                                         const void *bias, const int32_t *rowptr, int L, int row_scale, void *out,
                                         int64_t ldc, const float *a_absmax, const float *out_bound, float *out_absmax,
-                                        int absmax_col0, void *stream) {
-  if (!out_bound || !a_absmax || row_scale < 0 || row_scale > 1 || absmax_col0 < 0) return AMPCONV_E_BADARG;
+                                        int absmax_col0, int plane_dh, void *stream) {
+  if (!out_bound || !a_absmax || row_scale < 0 || row_scale > 1 || absmax_col0 < 0 || (plane_dh != 32 && plane_dh != 16))
+    return AMPCONV_E_BADARG;
   return proj_rows_f32(A, lda, M, K, wimage, N, bias, rowptr, L, out, ldc, a_absmax, out_absmax, absmax_col0, out_bound,
-                       row_scale, stream);
+                       plane_dh, row_scale, stream);
 }
 
 // bound of the magnitudes of out = A W^T + bias from the largest magnitude of A: a_absmax * max_n sum_k |W[n][k]| +
@@ -1076,16 +1081,17 @@ extern "C" int ampconv_proj_out_bound(const void *W, int64_t stride_n, int64_t s
 // plane slots -> fp32, in place layout (the reverse of the PLANES epilogue; the lazily served side outputs and the
 // fall-back paths read the projection buffer as fp32): X[M, K] with K a multiple of 32, rows ld floats apart
 namespace {
-__global__ __launch_bounds__(256) void planes_to_f32_kernel(const char *__restrict__ X, int64_t ld, int64_t M, int K32,
+__global__ __launch_bounds__(256) void planes_to_f32_kernel(const char *__restrict__ X, int64_t ld, int64_t M, int K8, int dh,
                                                             const float *__restrict__ bound, float *__restrict__ out,
                                                             int64_t ldo) {
   const float u = 1.f / plane_scale(*bound);
-  const int64_t total = M * K32 * 4;                       // 8-channel pieces
+  const int pps = dh / 8;                                  // 8-channel pieces per slot
+  const int64_t total = M * K8;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int64_t row = i / (K32 * 4);
-    const int r = (int)(i - row * (K32 * 4)), slot = r >> 2, c = r & 3;
-    const char *src = X + (row * ld + slot * 32) * 4 + 16 * c;
-    const uint4 h = *reinterpret_cast<const uint4 *>(src), l = *reinterpret_cast<const uint4 *>(src + 64);
+    const int64_t row = i / K8;
+    const int r = (int)(i - row * K8), slot = r / pps, c = r - slot * pps;
+    const char *src = X + (row * ld + (int64_t)slot * dh) * 4 + 16 * c;
+    const uint4 h = *reinterpret_cast<const uint4 *>(src), l = *reinterpret_cast<const uint4 *>(src + 2 * dh);
     const unsigned hu[4] = {h.x, h.y, h.z, h.w}, lu[4] = {l.x, l.y, l.z, l.w};
     float v[8];
 #pragma unroll
@@ -1094,23 +1100,25 @@ __global__ __launch_bounds__(256) void planes_to_f32_kernel(const char *__restri
       v[2 * k] = ((float)hv[0] + (float)lv[0]) * u;
       v[2 * k + 1] = ((float)hv[1] + (float)lv[1]) * u;
     }
-    float *o = out + row * ldo + slot * 32 + 8 * c;
+    float *o = out + row * ldo + slot * dh + 8 * c;
     *reinterpret_cast<float4 *>(o) = make_float4(v[0], v[1], v[2], v[3]);
     *reinterpret_cast<float4 *>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
   }
 }
 }  // namespace
 
-extern "C" int ampconv_planes_to_f32(const void *X, int64_t ld, int64_t M, int K, const float *bound, void *out,
+extern "C" int ampconv_planes_to_f32(const void *X, int64_t ld, int64_t M, int K, int plane_dh, const float *bound, void *out,
                                      int64_t ldo, void *stream) {
-  if (M < 0 || K <= 0 || K % 32 || ld < K || ldo < K || ld % 4 || ldo % 4 || !bound) return AMPCONV_E_BADARG;
+  if (M < 0 || K <= 0 || (plane_dh != 32 && plane_dh != 16) || K % plane_dh || ld < K || ldo < K || ld % 4 || ldo % 4 || !bound)
+    return AMPCONV_E_BADARG;
   if (M == 0) return AMPCONV_OK;
   if (!X || !out || (uintptr_t)X % 16 || (uintptr_t)out % 16) return AMPCONV_E_BADARG;
   const int64_t pieces = M * (K / 8);
   int64_t grid = (pieces + 255) / 256;
   const int64_t cap = (int64_t)cu_count() * 16;
   if (grid > cap) grid = cap;
-  planes_to_f32_kernel<<<(unsigned)grid, 256, 0, (hipStream_t)stream>>>((const char *)X, ld, M, K / 32, bound, (float *)out, ldo);
+  planes_to_f32_kernel<<<(unsigned)grid, 256, 0, (hipStream_t)stream>>>((const char *)X, ld, M, K / 8, plane_dh, bound,
+                                                                        (float *)out, ldo);
   return ampconv_launch_status();
 }
 

@@ -181,14 +181,14 @@ int ampconv_bwd_edge_src(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
 
 /* ---- edge phase on fp16 PLANES: fp32-grade results off the FP32 pipe (csrc/edge_mfma_f16x2.hip, ABI 106) --------
  * The same three passes (same reference arithmetic: torch functional.py:6578-6594 per edge, amp_conv.py:11, SURVEY.md
- * A.2) for L <= 20, dh = 32, with Q, K, V and dObar in the PLANE FORMAT: the 128-byte slot of the 32 fp32 channels of
- * one (token row, head) holds 32 fp16 `hi` then 32 fp16 `lo` with hi + lo = x * 2^e (to 2^-22 |x|, absolute 2^-25 in
+ * A.2) for L <= 20, dh = 32 or 16, with Q, K, V and dObar in the PLANE FORMAT: the 4 dh-byte slot of the dh fp32 channels
+ * of one (token row, head) holds dh fp16 `hi` then dh fp16 `lo` with hi + lo = x * 2^e (to 2^-22 |x|, absolute 2^-25 in
  * scaled units below that), ONE exponent per tensor: e = 14 - floor(log2 bound) for a device-side upper bound of the
  * tensor's magnitudes -- bounds[0] for Q | K | V (written by ONE ampconv_proj_rows_planes call), bounds[1] for dObar.
  * `bounds` (device, 4 floats) also carries what the backward passes scale dS = P (dP - delta) by before they split it:
  * bounds[2] = the largest |V| and bounds[3] = the largest |dObar| (true fp32 magnitudes, as recorded by the out_absmax
  * of the two ampconv_proj_rows_planes calls; any upper bound serves).  The forward pass reads bounds[0] only.
- * Views keep the strides, in 4-byte elements, of the fp32 tensor the planes replace; head_stride must be 32.  Every
+ * Views keep the strides, in 4-byte elements, of the fp32 tensor the planes replace; head_stride must be dh.  Every
  * product is the fp32 sum of three v_mfma_f32_16x16x32_f16 partial products (dropped: lo x lo <= 2^-22 of the product),
  * softmax and all sums are fp32, the outputs (Obar, dQ, dK, dV) plain fp32 views.
  * dObar must arrive DIVIDED by the in-degree of its node (ampconv_proj_rows_planes, row_scale = 1): the passes carry no
@@ -343,7 +343,7 @@ int ampconv_absmax(const void *X, int64_t ld, int64_t M, int K, int dtype, float
  * the plane format of the edge kernels above instead of fp32 -- same bytes, same layout of 128-byte slots.
  *   proj_out_bound  : out[0] = *a_absmax * max_n sum_k |B[n][k]| + max_n |bias[n]| (B as in proj_weight_image): an upper
  *                     bound of |A B^T + bias| that is known BEFORE the product runs; the scale of its planes
- *   proj_rows_planes: as proj_rows; `out_bound` = that device float; row_scale = 1 (with rowptr): rows are also DIVIDED
+ *   proj_rows_planes: as proj_rows; `out_bound` = that device float; plane_dh = 32 or 16: the slot width (head dimension); row_scale = 1 (with rowptr): rows are also DIVIDED
  *                     by their node's segment length (dObar / in-degree); out_absmax (may be NULL) records the largest
  *                     finite magnitude of the fp32 values behind the planes over the columns >= absmax_col0 only (the V
  *                     third of a packed in-projection bounds Obar, a mean of convex combinations of V rows)
@@ -357,9 +357,9 @@ int ampconv_proj_out_bound(const void *W, int64_t stride_n, int64_t stride_k, in
 int ampconv_proj_rows_planes(const void *A, int64_t lda, int64_t M, int K, const void *wimage, int N,
                              const void *bias, const int32_t *rowptr, int L, int row_scale, void *out,
                              int64_t ldc, const float *a_absmax, const float *out_bound,
-                             float *out_absmax, int absmax_col0, void *stream);
-int ampconv_planes_to_f32(const void *X, int64_t ld, int64_t M, int K, const float *bound, void *out,
-                          int64_t ldo, void *stream);
+                             float *out_absmax, int absmax_col0, int plane_dh, void *stream);
+int ampconv_planes_to_f32(const void *X, int64_t ld, int64_t M, int K, int plane_dh, const float *bound,
+                          void *out, int64_t ldo, void *stream);
 int ampconv_absmax_stats(const void *X, int64_t ld, int64_t M, int K, float *out, void *stream);
 
 /* ---- GraphSAINT random-walk sampler ("next" row: the step before the hot path) -------------

@@ -3,7 +3,7 @@ Q | K | V and dObar as two fp16 planes of the power-of-two-scaled value, every p
 partial products.  What it replaces in the reference is what the fp32 edge kernels replace (amp_conv.py:39 -> torch
 functional.py:6578-6594 and its autograd backward), so the checker is the same fp64 oracle at the same FLAT fp32
 tolerance; the golden vectors run through this path in tests/test_gpu_parity.py
-(test_golden_single_layer_scaled_projections: every fixture with dh = 32)."""
+(test_golden_single_layer_scaled_projections: every fixture with dh = 32 or 16 and embed_dim % 128 == 0)."""
 import numpy as np
 import pytest
 import torch
@@ -84,8 +84,9 @@ NAMES = ('y', 'dx', 'g_in_proj_weight', 'g_in_proj_bias', 'g_out_proj_weight', '
 
 
 @pytest.mark.parametrize('shape', [(1500, 15000, 20, 256, 8), (900, 9000, 20, 128, 4), (700, 6000, 13, 128, 4),
-                                   (600, 5000, 17, 256, 8), (400, 3000, 5, 128, 4), (300, 2500, 1, 128, 4)],
-                         ids=['cfg4_like', 'cora_like', 'L13', 'L17', 'L5', 'L1'])
+                                   (600, 5000, 17, 256, 8), (400, 3000, 5, 128, 4), (300, 2500, 1, 128, 4),
+                                   (1500, 9000, 20, 128, 8), (600, 5000, 17, 256, 16), (400, 3000, 3, 128, 8)],
+                         ids=['cfg4_like', 'cora_like', 'L13', 'L17', 'L5', 'L1', 'cfg3_like_dh16', 'L17_dh16', 'L3_dh16'])
 @pytest.mark.parametrize('stats', [True, False], ids=['stats', 'own_softmax'])
 def test_plane_path_vs_fp64_oracle(shape, stats, dev, monkeypatch):
     """The whole layer through the plane-format edge passes (forced onto small graphs), with long segments in both
@@ -226,7 +227,8 @@ def test_absmax_stats_and_the_stats_cache(dev):
     assert s3 is not s1 and float(s3[0]) == 2.0 * float(s1[0])
 
 
-def test_plane_projection_round_trip(dev):
+@pytest.mark.parametrize('dh', [32, 16])
+def test_plane_projection_round_trip(dh, dev):
     """ampconv_proj_rows_planes -> ampconv_planes_to_f32 equals the fp32-output scaled product to 2^-20 of the bound
     (two 11-bit planes), with bias, with the in-degree division (row_scale) and exact zero rows for empty segments;
     the recorded maximum covers the requested columns only."""
@@ -243,8 +245,8 @@ def test_plane_projection_round_trip(dev):
     ref = F_.proj_rows(a, img, b, amax=am)
     assert float(bound) >= float(ref.abs().max())
     rec = torch.zeros(1, device=dev)
-    pl = F_.proj_rows_planes(a, img, bound, b, amax=am, out_amax=rec, amax_col0=512)
-    back = F_.planes_to_f32(pl, bound)
+    pl = F_.proj_rows_planes(a, img, bound, b, amax=am, out_amax=rec, amax_col0=512, dh=dh)
+    back = F_.planes_to_f32(pl, bound, dh)
     err = float((back - ref).abs().max())
     print(f'[err] planes round trip: {err:.3e}, bound {float(bound):.3e}, max |out| {float(ref.abs().max()):.3e}')
     assert err <= float(bound) * 2.0 ** -20
@@ -254,8 +256,8 @@ def test_plane_projection_round_trip(dev):
     deg = torch.randint(0, 6, (nn,), generator=g)
     rowptr = torch.zeros(nn + 1, dtype=torch.int32)
     rowptr[1:] = torch.cumsum(deg, 0).to(torch.int32)
-    pl = F_.proj_rows_planes(a, img, bound, None, rowptr=rowptr.to(dev), L=L, row_scale=1, amax=am)
-    back = F_.planes_to_f32(pl, bound).cpu()
+    pl = F_.proj_rows_planes(a, img, bound, None, rowptr=rowptr.to(dev), L=L, row_scale=1, amax=am, dh=dh)
+    back = F_.planes_to_f32(pl, bound, dh).cpu()
     ref0 = F_.proj_rows(a, img, None, amax=am).cpu()
     inv = torch.where(deg > 0, 1.0 / deg.clamp(min=1).float(), torch.zeros(nn)).repeat_interleave(L)[:, None]
     assert float((back - ref0 * inv).abs().max()) <= float(bound) * 2.0 ** -20
