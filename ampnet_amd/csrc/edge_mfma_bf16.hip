@@ -12,6 +12,7 @@
 // and are the B operand of the next product as they stand (tokens 16..19 sit in lane group 0).
 // Scales that the fp32 kernels fold into operands (log2e/sqrt(dh), 1/deg) are applied to the fp32
 // accumulators instead.  Long segments (hubs) reduce into fp32 partial tiles (hub.hip).
+#include <cstdlib>
 #include "mfma_tile.h"
 
 namespace {
@@ -483,6 +484,177 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void bwd_src_bf16(Args a) {
   store_tile<HALF>(a.dV, onode, h, dVT, 1.f, hubp, L, lane);
 }
 
+// ---------------------------------------------------------------- backward, source pass, transposing variant (round 5)
+// The source pass needs two different axes of the 20 x 20 score tile: the softmax (and delta) sum over the SOURCE tokens
+// j, the products dV = P^T dO, dK = dS^T Q sum over the DESTINATION tokens i.  bwd_src_bf16 keeps the tile as S[i][j]
+// (i in the C/D registers: ready as the B operand of the products) and pays for the softmax with three 16-lane DPP
+// reductions per row -- ~200 of its ~260 vector instructions per (edge, head), and the pass is bound by vector issue
+// (profiles/r04_sq_counters.md: VALU active 0.82).  This variant computes the tile as S^T[j][i] -- own tokens on the MFMA
+// rows, as the forward and destination passes do: the softmax is in-lane plus two cross-group swaps per column -- and
+// turns P^T, dS^T round through a wave-private LDS image: each lane files its column as 8 + 2 bytes of row i, the B
+// fragments come back by ds_read_b64_tr_b16 with the k index (i) contiguous, and the A fragments (dO^T, Q^T) are cut from
+// 32-row images with the same contiguous k map.  Rows 20..31 of every image are zero (written once per unit).
+constexpr int kTile32 = 32 * kRowBytes;       // 2 KiB: 32 token rows
+
+template <bool FULL, bool HALF>
+__device__ __forceinline__ void pair_to_lds_h32(char *tileA, const PairRegsH &t, int L, int lane) {
+  const int r = lane >> 2, q = lane & 3;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int R = r + 16 * i;
+    const bool isB = R >= kLmax;
+    const int j = isB ? R - kLmax : R;
+    if ((R < 2 * kLmax) && (FULL || j < L))
+      *reinterpret_cast<i32x4 *>(tileA + (isB ? kTile32 : 0) + plane_off(j, q)) = t.v[i];
+  }
+}
+// channel-product fragment with the PLAIN column map (column n of tile 1 = token 16 + n; rows 20..31 of the image are zero)
+__device__ __forceinline__ i32x4 rowfrag_plain(const char *tile, int nt, int lane) {
+  const int n = lane & 15, kg = lane >> 4;
+  return *reinterpret_cast<const i32x4 *>(tile + plane_off(16 * nt + n, kg));
+}
+// ... of row tile mt straight from global memory with the quarter map (own side on the MFMA rows; once per unit)
+template <bool HALF>
+__device__ __forceinline__ i32x4 rowfrag_global_q(const bf16_t *base, int64_t row_stride, int mt, int L, int lane) {
+  const int m = lane & 15, kg = lane >> 4;
+  const int j = mt == 0 ? m : 16 + (m >> 2);
+  i32x4 x = {0, 0, 0, 0};
+  if (j < L && (!HALF || kg < 2)) x = *reinterpret_cast<const i32x4 *>(base + (int64_t)j * row_stride + 8 * kg);
+  return x;
+}
+// token-product fragment with the k index contiguous: slots 0..7 of lane group kg = token rows 8 kg .. 8 kg + 7 of a
+// 32-row image, 16-column block `blk` (channels of tile mc, or the source tokens of tile nt in a transposed image)
+__device__ __forceinline__ i32x4 colfrag32(const char *tile, int blk, int lane) {
+  const int q = (lane >> 2) & 3, pp = lane & 3, kg = lane >> 4;
+  const int ch = 2 * blk + (pp >> 1), half = (pp & 1) << 3;
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4 *)(tile + plane_off(8 * kg + q, ch) + half));
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s16x4 *)(tile + plane_off(8 * kg + 4 + q, ch) + half));
+  const i32x2 ai = __builtin_bit_cast(i32x2, a), bi = __builtin_bit_cast(i32x2, b);
+  return i32x4{ai[0], ai[1], bi[0], bi[1]};
+}
+// a lane's column of a C/D tile pair (t0[q] = own token 4 g + q, t1_0 = own token 16 + g) -> row i of the transposed image
+__device__ __forceinline__ void file_column(char *img, int i, const f32x4 &t0, float t1_0, int g) {
+  *reinterpret_cast<i32x2 *>(img + plane_off(i, g >> 1) + 8 * (g & 1)) = i32x2{cvt_pk_bf16(t0[0], t0[1]), cvt_pk_bf16(t0[2], t0[3])};
+  *reinterpret_cast<unsigned short *>(img + plane_off(i, 2) + 2 * g) = (unsigned short)cvt_pk_bf16(t1_0, 0.f);
+}
+
+template <bool FULL, bool HALF>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void bwd_src_bf16_tr(Args a) {
+  __shared__ __attribute__((aligned(16))) char lds_all[kWavesPerBlock][4 * kTile32];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t unit = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+  if (unit >= a.n_units) return;
+  int64_t s, onode;
+  int h, beg, end, deg;
+  if (!map_unit(a.hub, a.ptr, unit, a.n_units, a.H, s, onode, h, beg, end, deg)) return;
+  if (beg >= end && a.hub.mode != 2) {
+    store_zero_tile<HALF>(a.dK, onode, h, a.L, lane);
+    return store_zero_tile<HALF>(a.dV, onode, h, a.L, lane);
+  }
+  const int L = a.L, n = lane & 15, g = lane >> 4;
+  char *Qt = lds_all[wave], *Gt = Qt + kTile32, *Pi = Gt + kTile32, *Si = Pi + kTile32;
+
+  i32x4 kA[2], vA[2];
+  {
+    const bf16_t *kb = tile_ptr<const bf16_t>(a.K, s, h);
+    const bf16_t *vb = tile_ptr<const bf16_t>(a.V, s, h);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      kA[mt] = rowfrag_global_q<HALF>(kb, a.K.row_stride, mt, L, lane);
+      vA[mt] = rowfrag_global_q<HALF>(vb, a.V.row_stride, mt, L, lane);
+    }
+  }
+  {   // all four images zero once: rows >= L (>= 20) of the streamed tiles and of the transposed images are never written
+    int *z = reinterpret_cast<int *>(Qt);
+    for (int i = lane; i < 4 * kTile32 / 4; i += AMPCONV_WAVE) z[i] = 0;
+  }
+  f32x4 dKT[2][2], dVT[2][2];
+#pragma unroll
+  for (int mc = 0; mc < 2; ++mc)
+    dKT[mc][0] = dKT[mc][1] = dVT[mc][0] = dVT[mc][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  PairRegsH qg;
+  float inv = 0.f, inv_next = 0.f;
+  IdxWindow win;
+  auto fetch = [&](int p, float &w) {
+    const int64_t d = idxwin_get<true>(win, a.idx, a.cinv, p, end, lane, &w);
+    pair_load_h<FULL, HALF>(qg, tile_ptr<const bf16_t>(a.Q, d, h), a.Q.row_stride,
+                            tile_ptr<const bf16_t>(a.dO, d, h), a.dO.row_stride, L, lane);
+  };
+  if (beg < end) {
+    idxwin_load<true>(win, a.idx, a.cinv, beg, end, lane);
+    fetch(beg, inv_next);
+  }
+  for (int p = beg; p < end; ++p) {
+    pair_to_lds_h32<FULL, HALF>(Qt, qg, L, lane);
+    inv = inv_next;
+    if (p + 1 < end) fetch(p + 1, inv_next);
+    __builtin_amdgcn_wave_barrier();
+
+    // S^T = K Q^T and dP^T = V dO^T: own source tokens on the rows (quarter map), destination tokens on the columns
+    f32x4 S[2][2], dP[2][2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const i32x4 qB = rowfrag_plain(Qt, nt, lane), gB = rowfrag_plain(Gt, nt, lane);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        S[mt][nt] = MFMA_BF16(kA[mt], qB, (f32x4{0.f, 0.f, 0.f, 0.f}));
+        dP[mt][nt] = MFMA_BF16(vA[mt], gB, (f32x4{0.f, 0.f, 0.f, 0.f}));
+      }
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      column_softmax<FULL>(S[0][nt], S[1][nt], a.qscale, L, g);        // P^T; tile-1 regs 1..3 get weight 0
+      float part = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) part = fmaf(S[0][nt][q], dP[0][nt][q], fmaf(S[1][nt][q], dP[1][nt][q], part));
+      const float delta = groups_sum(part);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {                                     // dS^T and P^T, both with the edge's 1 / in-degree
+        dP[0][nt][q] = S[0][nt][q] * (dP[0][nt][q] - delta) * inv;
+        S[0][nt][q] *= inv;
+      }
+      dP[1][nt][0] = S[1][nt][0] * (dP[1][nt][0] - delta) * inv;
+      S[1][nt][0] *= inv;
+      // column i = 16 nt + n of the tile pair -> row i of the transposed images (tile 1: destination tokens 16..19 only)
+      const int i = 16 * nt + n;
+      if (i < kLmax && (FULL || i < L)) {
+        file_column(Pi, i, S[0][nt], S[1][nt][0], g);
+        file_column(Si, i, dP[0][nt], dP[1][nt][0], g);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    i32x4 pB[2], sB[2], gC[2], qC[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      pB[nt] = colfrag32(Pi, nt, lane);
+      sB[nt] = colfrag32(Si, nt, lane);
+    }
+#pragma unroll
+    for (int mc = 0; mc < (HALF ? 1 : 2); ++mc) {
+      gC[mc] = colfrag32(Gt, mc, lane);
+      qC[mc] = colfrag32(Qt, mc, lane);
+    }
+    TR_FRAG_FENCE();
+#pragma unroll
+    for (int mc = 0; mc < (HALF ? 1 : 2); ++mc) {
+      dVT[mc][0] = MFMA_BF16(gC[mc], pB[0], dVT[mc][0]);
+      dVT[mc][1] = MFMA_BF16(gC[mc], pB[1], dVT[mc][1]);
+      dKT[mc][0] = MFMA_BF16(qC[mc], sB[0], dKT[mc][0]);
+      dKT[mc][1] = MFMA_BF16(qC[mc], sB[1], dKT[mc][1]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_nop 7" ::: "memory");       // (the next edge's reads do not redefine fragment registers right behind these MFMAs)
+    __builtin_amdgcn_wave_barrier();
+  }
+  const bool hubp = a.hub.mode == 2;
+  store_tile<HALF>(a.dK, onode, h, dKT, hubp ? 1.f : a.oscale, hubp, L, lane);
+  store_tile<HALF>(a.dV, onode, h, dVT, 1.f, hubp, L, lane);
+}
+
 // kernels[2 * half + full]
 typedef void (*EdgeKernel)(Args);
 int launch(Args &a, int L, int D, int H, EdgeKernel const (&kernels)[4], hipStream_t stream) {
@@ -542,5 +714,12 @@ int ampconv_bwd_edge_src_bf16(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t
   a.ptr = cscptr; a.idx = crow; a.cinv = cinv; a.hub = hub;
   a.n_units = n_src * H; a.L = L; a.H = H;
   static const EdgeKernel kernels[4] = {bwd_src_bf16<false, false>, bwd_src_bf16<true, false>, bwd_src_bf16<false, true>, bwd_src_bf16<true, true>};
-  return launch(a, L, D, H, kernels, stream);
+  static const EdgeKernel kernels_tr[4] = {bwd_src_bf16_tr<false, false>, bwd_src_bf16_tr<true, false>, bwd_src_bf16_tr<false, true>,
+                                           bwd_src_bf16_tr<true, true>};
+  // developer switch: AMPCONV_BF16_SRC_TR=0 = the row-softmax kernel (DPP reductions), kept as the cross-check
+  static const bool tr = [] {
+    const char *e = getenv("AMPCONV_BF16_SRC_TR");
+    return !(e && e[0] == '0');
+  }();
+  return launch(a, L, D, H, tr ? kernels_tr : kernels, stream);
 }
