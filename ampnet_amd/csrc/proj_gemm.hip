@@ -248,8 +248,11 @@ struct RowsArgs {
 
 // RAGGED: K % 32 != 0 or N % BN != 0 (e.g. the reference's default embed_dim = 100): row loads beyond K read as zero,
 // columns beyond N are computed on the image's zero padding and not stored
+#ifndef AMPCONV_PROJ_ROWS_128_WAVES
+#define AMPCONV_PROJ_ROWS_128_WAVES 2      // (A/B: 3 = the 128 x 128 scaled shapes compiled for three workgroups per CU)
+#endif
 template <int BM, int BN, int WM, int WN, bool RAGGED, bool HP, bool PLANES = false>
-__global__ __launch_bounds__(64 * WM * WN, 2) void proj_rows_kernel(RowsArgs a) {
+__global__ __launch_bounds__(64 * WM * WN, (BM == 128 && BN == 128 && HP) ? AMPCONV_PROJ_ROWS_128_WAVES : 2) void proj_rows_kernel(RowsArgs a) {
   static_assert(!PLANES || HP, "plane output exists in the scaled mode only");
   constexpr int kNP = Pl<HP>::NP, kTile3 = Pl<HP>::kTile;
   constexpr int NW = WM * WN, NTHR = 64 * NW;
@@ -987,7 +990,7 @@ static int proj_rows_f32(const void *A_, int64_t lda, int64_t M, int K, const vo
   }();
   const int Np = (N + 127) / 128 * 128, Kp = (K + 31) / 32 * 32;
   const bool ragged = Np != N || Kp != K;
-  const int shape = Np % 256 ? 2 : variant;            // 0: 128 x 256 / 4 waves, 1: 256 x 256 / 8 waves, 2: 128 x 128 / 4 waves
+  const int shape = (Np % 256 || variant == 2) ? 2 : variant;      // 0: 128 x 256 / 4 waves, 1: 256 x 256 / 8 waves, 2: 128 x 128 / 4 waves
   const int bm = shape == 1 ? 256 : 128, bn = shape == 2 ? 128 : 256;
   const int64_t rts = (M + bm - 1) / bm;
   if (rts > (int64_t)INT32_MAX / 64) return AMPCONV_E_BADARG;
@@ -1000,7 +1003,7 @@ static int proj_rows_f32(const void *A_, int64_t lda, int64_t M, int K, const vo
   const int n_cu = cu_count();
   // a multiple of 8: slot u of a workgroup keeps u % 8 (its XCD label), so "my next slot is invalid" means "nothing
   // further for me" only then (a.tiles is a multiple of 8 by construction)
-  int64_t grid = (int64_t)n_cu * (shape == 1 ? 1 : 2) / kXcd * kXcd;
+  int64_t grid = (int64_t)n_cu * (shape == 1 ? 1 : (shape == 2 && hp ? AMPCONV_PROJ_ROWS_128_WAVES : 2)) / kXcd * kXcd;
   if (grid < kXcd) grid = kXcd;
   if (grid > a.tiles) grid = a.tiles;
   hipStream_t st = (hipStream_t)stream;
