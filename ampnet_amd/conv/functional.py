@@ -118,7 +118,7 @@ EDGE_PLANES = os.environ.get('AMPCONV_EDGE_PLANES', '1') != '0'
 # that have a head slot further down (ampconv_absmax_stats) take the exact kernels instead: six-product projections,
 # fp32 edge passes.  The price of knowing is one 8-byte read-back per operand (x: cached per tensor version; dY: per step)
 RANGE_LOG2 = 12
-_STATS_CACHE = {}         # id(tensor) -> (weakref, _version, stats tensor, narrow)
+_STATS_CACHE = {}         # id(tensor) -> (weakref, _version, stats tensor, narrow, (data_ptr, shape))
 
 
 def operand_stats(t2, key=None):
@@ -130,7 +130,8 @@ def operand_stats(t2, key=None):
     import weakref
     if key is not None:
         hit = _STATS_CACHE.get(id(key))
-        if hit is not None and hit[0]() is key and hit[1] == key._version and hit[2].device == t2.device:
+        if (hit is not None and hit[0]() is key and hit[1] == key._version and hit[4] == (key.data_ptr(), tuple(key.shape))
+                and hit[2].device == t2.device):
             return hit[2], hit[3]
     lib = _lib.load()
     t2 = _aligned(t2)
@@ -143,7 +144,7 @@ def operand_stats(t2, key=None):
         if len(_STATS_CACHE) >= 16:
             for k in [k for k, v in _STATS_CACHE.items() if v[0]() is None] or list(_STATS_CACHE)[:8]:
                 _STATS_CACHE.pop(k, None)
-        _STATS_CACHE[id(key)] = (weakref.ref(key), key._version, st, narrow)
+        _STATS_CACHE[id(key)] = (weakref.ref(key), key._version, st, narrow, (key.data_ptr(), tuple(key.shape)))
     return st, narrow
 
 
