@@ -69,6 +69,20 @@ struct HubArgs {
                            // 2: hub pass (one unit per (chunk, head), writes partial tiles)
 };
 
+// Workgroup-per-unit kernels: blockIdx -> unit such that the H heads of one row run on ONE XCD, back to back.
+// Workgroups go to the 8 XCDs round-robin, so with units in (row, head) order the heads of a row land on H different
+// XCDs: where a head's slice of a token row is shorter than a 128-byte line (dh = 50 fp32: 200 bytes at 8-byte alignment
+// = 2.6 lines) every L2 fetches the neighbours' bytes again.  Block b = 8 s + x (x = XCD, s = its slot
+// there) takes row 8 (s / H) + x, head s % H.  Launch xcd_grid() workgroups; returns -1 for the padding.
+__device__ __forceinline__ int64_t xcd_unit(int64_t b, int64_t n_units, int H) {
+  const int x = (int)(b & 7);
+  const int64_t s = b >> 3, rs = s / H;
+  const int h = (int)(s - rs * H);
+  const int64_t u = rs * 8 + x;
+  return u * H + h < n_units ? u * H + h : -1;
+}
+static inline int64_t xcd_grid(int64_t n_units, int H) { return ((n_units / H + 7) / 8) * 8 * H; }
+
 // unit -> (row, head, edge range); returns false if this wave has nothing to do.
 // Main pass of a graph WITH a long-segment plan (mode 1, i.e. a skewed degree distribution): the row order is a
 // pseudo-random permutation of the rows (scramble_row).  Workgroups go to the 8 XCDs round-robin, so with rows in
@@ -161,6 +175,20 @@ int ampconv_bwd_edge_src_block(ampconv_view_t Q, ampconv_view_t K, ampconv_view_
                                const int32_t *cscptr, const int32_t *crow, const float *cinv, int64_t n_src,
                                int L, int D, int H, ampconv_view_t dK, ampconv_view_t dV, HubArgs hub,
                                const float *stats, bool bf16, hipStream_t stream);
+
+// ---- the same path with 32 < dh <= 64, fp32 storage, on the 16-bit matrix pipe (edge_block_x3.hip: three bf16 planes per
+// fp32 value, six partial products); `vec` = vec_of() of the views (4 or 2 floats)
+bool ampconv_block_x3_supported(int L, int D, int H, bool bf16);
+int ampconv_fwd_edge_block_x3(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V, const int32_t *rowptr,
+                              const int32_t *col, const int32_t *qidx, int64_t n_rows, int L, int D, int H,
+                              ampconv_view_t O, HubArgs hub, int vec, hipStream_t stream);
+int ampconv_bwd_edge_dst_block_x3(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V, ampconv_view_t dO,
+                                  const int32_t *rowptr, const int32_t *col, int64_t n_rows, int L, int D, int H,
+                                  ampconv_view_t dQ, HubArgs hub, StatsArgs sa, int vec, hipStream_t stream);
+int ampconv_bwd_edge_src_block_x3(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V, ampconv_view_t dO,
+                                  const int32_t *cscptr, const int32_t *crow, const float *cinv, int64_t n_src, int L,
+                                  int D, int H, ampconv_view_t dK, ampconv_view_t dV, HubArgs hub, const float *stats,
+                                  int vec, hipStream_t stream);
 
 // ---- short token sequences (edge_small.hip): L <= 4, one wave per row, VALU only, fp32; views aligned to the lane's
 // vector width.  No softmax statistics.

@@ -576,6 +576,8 @@ int ampconv_fwd_edge_block(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
   a.ptr = rowptr; a.idx = col; a.qidx = qidx;
   const ampconv_view_t views[] = {Q, K, V, O};
   const int vec = vec_of(views, 4, a.dh, bf16 ? 2 : 4), dhp = a.dh > 32 ? 64 : 32;
+  if (ampconv_block_x3_supported(L, D, H, bf16))
+    return ampconv_fwd_edge_block_x3(Q, K, V, rowptr, col, qidx, n_rows, L, D, H, O, hub, vec, stream);
   return launch_block(a, dhp, KernelTable<FwdK>::get(dhp, vec, a.ntok), stream);
 }
 
@@ -589,6 +591,8 @@ int ampconv_bwd_edge_dst_block(ampconv_view_t Q, ampconv_view_t K, ampconv_view_
   a.oscale = 1.f / sqrtf((float)a.dh);
   const ampconv_view_t views[] = {Q, K, V, dO, dQ};
   const int vec = vec_of(views, 5, a.dh, bf16 ? 2 : 4), dhp = a.dh > 32 ? 64 : 32;
+  if (ampconv_block_x3_supported(L, D, H, bf16))
+    return ampconv_bwd_edge_dst_block_x3(Q, K, V, dO, rowptr, col, n_rows, L, D, H, dQ, hub, sa, vec, stream);
   return launch_block(a, dhp, sa.stats ? KernelTable<DstKS>::get(dhp, vec, a.ntok) : KernelTable<DstK>::get(dhp, vec, a.ntok),
                       stream);
 }
@@ -605,5 +609,7 @@ int ampconv_bwd_edge_src_block(ampconv_view_t Q, ampconv_view_t K, ampconv_view_
   a.oscale = 0.6931471805599453f;       // dK = ln2 * sum dS^T (Q * log2e / sqrt(dh))
   const ampconv_view_t views[] = {Q, K, V, dO, dK, dV};
   const int vec = vec_of(views, 6, a.dh, bf16 ? 2 : 4), dhp = a.dh > 32 ? 64 : 32;
+  if (ampconv_block_x3_supported(L, D, H, bf16))
+    return ampconv_bwd_edge_src_block_x3(Q, K, V, dO, cscptr, crow, cinv, n_src, L, D, H, dK, dV, hub, stats, vec, stream);
   return launch_block(a, dhp, KernelTable<SrcK>::get(dhp, vec, a.ntok), stream, 2 * 16 * a.ntok);
 }

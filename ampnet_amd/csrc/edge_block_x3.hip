@@ -1,0 +1,745 @@
+// Workgroup-per-unit edge kernels for the shapes of edge_block.hip with 32 < dh <= 64 and fp32 storage (the reference's
+// AMPGCN class defaults: L = 40, D = 100, H = 2 -> dh = 50, src/ampnet/module/amp_gcn.py:21-35), OFF the FP32 pipe:
+// every fp32 tile is split into THREE bf16 planes on its way into LDS
+//      x = h + m + l,   h = bf16(x), m = bf16(x - h), l = bf16(x - h - m)        (24 significand bits, no scale needed:
+//                                                                                 bf16 has fp32's exponent range)
+// and every product is the fp32 sum of six v_mfma_f32_16x16x32_bf16 partial products
+//      a b ~ a_l b_h + a_h b_l + a_m b_m + a_m b_h + a_h b_m + a_h b_h           (dropped: a_m b_l + a_l b_m + a_l b_l
+//                                                                                 <= 2^-24 |a b|)
+// -- 96 matrix-pipe cycles per 16 x 16 x 32 block instead of the 256 of eight v_mfma_f32_16x16x4_f32, and on the 16-bit
+// matrix pipe, which runs beside the vector ALU instead of on it.  Softmax, delta and all sums stay fp32; HBM traffic,
+// statistics hand-off and the long-segment plan are those of edge_block.hip (same entry points, same bytes).
+//
+// One WORKGROUP owns one (row, head) unit; wave w of its NT = ceil(L / 16) owns the unit's own tokens 16 w .. 16 w + 15
+// (the COLUMNS of every score tile), all waves share the LDS images of the streamed pair of tiles.  Per plane an image
+// is [16 NT token rows][64 channels] bf16 = 128-byte rows, 16-byte chunk c of row j stored at chunk c ^ 2 ((j >> 1) & 3):
+// the ds_read_b128 of the channel-product fragments and the ds_read_b64_tr_b16 of the token-product fragments are both
+// bank-conflict free (tools/lds_bank_check.py).
+// Reference arithmetic replaced: torch functional.py:6578-6594 per edge, the mean of amp_conv.py:11, and their autograd
+// backward -- as edge_block.hip.
+#include "mfma_tile.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+constexpr float kLog2eX = 1.4426950408889634f;
+constexpr int kRowB = 128;                 // one plane of a token row: 64 bf16 channels
+constexpr int kTileRowsB = 16 * kRowB;     // 16 token rows of one plane
+
+#define MFMA_X3(a, b, c) \
+  __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), (c), 0, 0, 0)
+
+struct Frag3 {
+  i32x4 h, m, l;
+};
+
+// the six partial products of one fp32-grade product, smallest first
+__device__ __forceinline__ f32x4 mfma6(const Frag3 &a, const Frag3 &b, f32x4 c) {
+  c = MFMA_X3(a.l, b.h, c);
+  c = MFMA_X3(a.h, b.l, c);
+  c = MFMA_X3(a.m, b.m, c);
+  c = MFMA_X3(a.m, b.h, c);
+  c = MFMA_X3(a.h, b.m, c);
+  return MFMA_X3(a.h, b.h, c);
+}
+
+__device__ __forceinline__ int pk_bf(float a, float b) {      // v_cvt_pk_bf16_f32 (RNE)
+  f32x2 v = {a, b};
+  return __builtin_bit_cast(int, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ float bfl(int u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float bfh(int u) { return __builtin_bit_cast(float, u & (int)0xFFFF0000u); }
+// (x0, x1) -> packed bf16 pairs of the three planes (the residuals are exact fp32 differences)
+__device__ __forceinline__ void split3(float x0, float x1, int &h, int &m, int &l) {
+  h = pk_bf(x0, x1);
+  float r0 = x0 - bfl(h), r1 = x1 - bfh(h);
+  m = pk_bf(r0, r1);
+  r0 -= bfl(m);
+  r1 -= bfh(m);
+  l = pk_bf(r0, r1);
+}
+
+// byte offset of 16-byte chunk `ch` (0..7) of token row j in a plane image
+__device__ __forceinline__ int xoff(int j, int ch) { return j * kRowB + ((ch ^ (((j >> 1) & 3) << 1)) << 4); }
+
+struct XArgs {
+  ampconv_view_t Q, K, V, dO, O, dK, dV;     // O = forward output / dQ
+  const int32_t *ptr, *idx, *qidx;
+  const float *cinv;
+  const int32_t *spos;
+  float *stats;
+  HubArgs hub;              // long-segment plan (hub.hip): mode 1 skips long rows, mode 2 = one unit per chunk
+  int64_t n_units;
+  int L, dh, H;
+  float qscale, oscale;
+};
+
+__device__ __forceinline__ const float *tile_of(const ampconv_view_t &v, int64_t n, int h) {
+  return reinterpret_cast<const float *>(v.ptr) + n * v.node_stride + (int64_t)h * v.head_stride;
+}
+
+// ---- cooperative staging of two [L x dh] fp32 tiles (A then B): global -> registers -> split -> three plane images
+// each.  Thread (r0 = tid / DVP, cv = tid % DVP) owns vector column cv (VEC floats) of rows r0 + i RS.
+template <int VEC, int NT>
+struct StageX {
+  static constexpr int DVP = 64 / VEC;                      // vector slots per padded row
+  static constexpr int RS = 64 * NT / DVP;                  // rows per pass
+  static constexpr int NP = (16 * NT + RS - 1) / RS;        // passes
+  float v[2][NP][VEC];
+};
+
+// Loads: raw buffer loads off a per-tile resource (base = the (node, head) tile, uniform; num_records = the bytes of the
+// tile that exist), ONE per-thread byte offset per tensor and a scalar offset per pass -- no per-lane address arithmetic,
+// no predicates: token rows >= L lie beyond num_records and channels >= dh carry an out-of-range offset, both read as 0
+// and are filed as the zero padding of the image.
+struct StageSrc {
+  unsigned voA, voB;        // byte offset of (row r0, channel c) in a tile of tensor A / B
+  int stepA, stepB;         // bytes between two passes (RS token rows)
+  int nrecA, nrecB;         // bytes from the tile's first element to the end of its last row
+};
+template <int VEC, int NT>
+__device__ __forceinline__ StageSrc stage_src(int sA, int sB, int L, int dh, int tid) {
+  using S = StageX<VEC, NT>;
+  const int cv = tid % S::DVP, r0 = tid / S::DVP, c = cv * VEC;
+  StageSrc q;
+  q.voA = c < dh ? (unsigned)(r0 * sA + c) * 4u : 0x80000000u;
+  q.voB = c < dh ? (unsigned)(r0 * sB + c) * 4u : 0x80000000u;
+  q.stepA = S::RS * sA * 4;
+  q.stepB = S::RS * sB * 4;
+  q.nrecA = ((L - 1) * sA + dh) * 4;
+  q.nrecB = ((L - 1) * sB + dh) * 4;
+  return q;
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const float *base, int nrec) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, nrec, 0x00020000);
+}
+
+template <int VEC, int NT>
+__device__ __forceinline__ void xstage_load(StageX<VEC, NT> &s, const float *A, const float *B, const StageSrc &q, int L) {
+  using S = StageX<VEC, NT>;
+  const __amdgpu_buffer_rsrc_t ra = tile_rsrc(A, q.nrecA), rb = tile_rsrc(B, q.nrecB);
+#pragma unroll
+  for (int i = 0; i < S::NP; ++i) {
+    if (i * S::RS < L) {                                    // (uniform: whole passes beyond L are not issued)
+      if constexpr (VEC == 4) {
+        // (bit_cast of the builtin's result as a whole: element access on the returned vector type picks element 0 for
+        // every index with this compiler)
+        const f32x4 x = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, q.voA, i * q.stepA, 0));
+        const f32x4 y = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, q.voB, i * q.stepB, 0));
+        s.v[0][i][0] = x[0]; s.v[0][i][1] = x[1]; s.v[0][i][2] = x[2]; s.v[0][i][3] = x[3];
+        s.v[1][i][0] = y[0]; s.v[1][i][1] = y[1]; s.v[1][i][2] = y[2]; s.v[1][i][3] = y[3];
+      } else {
+        const f32x2 x = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(ra, q.voA, i * q.stepA, 0));
+        const f32x2 y = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rb, q.voB, i * q.stepB, 0));
+        s.v[0][i][0] = x[0]; s.v[0][i][1] = x[1];
+        s.v[1][i][0] = y[0]; s.v[1][i][1] = y[1];
+      }
+    }
+  }
+}
+
+// LDS byte offsets of this thread's vector in the rows it stages (plane 0 of an image)
+template <int VEC, int NT>
+struct StageOffs {
+  int v[StageX<VEC, NT>::NP];
+};
+template <int VEC, int NT>
+__device__ __forceinline__ void xstage_offsets(StageOffs<VEC, NT> &lo, int tid) {
+  using S = StageX<VEC, NT>;
+  const int cv = tid % S::DVP, r0 = tid / S::DVP, c = cv * VEC;
+#pragma unroll
+  for (int i = 0; i < S::NP; ++i) lo.v[i] = xoff(r0 + i * S::RS, c >> 3) + (c & 7) * 2;
+}
+
+template <int VEC, int NT, bool SCALE>
+__device__ __forceinline__ void xstage_store(char *imgA, char *imgB, const StageX<VEC, NT> &s,
+                                             const StageOffs<VEC, NT> &lo, float mulA, float mulB, int L, int dh,
+                                             int tid) {
+  using S = StageX<VEC, NT>;
+  constexpr int PB = 16 * NT * kRowB;
+#pragma unroll
+  for (int i = 0; i < S::NP; ++i) {
+    if (i * S::RS < L) {
+      {                                                     // (lanes beyond the tile hold zeros: the image's padding)
+#pragma unroll
+        for (int x = 0; x < 2; ++x) {
+          char *img = (x ? imgB : imgA) + lo.v[i];
+          const float mul = x ? mulB : mulA;
+          if constexpr (VEC == 4) {
+            int h0, m0, l0, h1, m1, l1;
+            if (SCALE) {
+              split3(s.v[x][i][0] * mul, s.v[x][i][1] * mul, h0, m0, l0);
+              split3(s.v[x][i][2] * mul, s.v[x][i][3] * mul, h1, m1, l1);
+            } else {
+              split3(s.v[x][i][0], s.v[x][i][1], h0, m0, l0);
+              split3(s.v[x][i][2], s.v[x][i][3], h1, m1, l1);
+            }
+            *reinterpret_cast<i32x2 *>(img) = i32x2{h0, h1};
+            *reinterpret_cast<i32x2 *>(img + PB) = i32x2{m0, m1};
+            *reinterpret_cast<i32x2 *>(img + 2 * PB) = i32x2{l0, l1};
+          } else {
+            int h0, m0, l0;
+            if (SCALE) split3(s.v[x][i][0] * mul, s.v[x][i][1] * mul, h0, m0, l0);
+            else split3(s.v[x][i][0], s.v[x][i][1], h0, m0, l0);
+            *reinterpret_cast<int *>(img) = h0;
+            *reinterpret_cast<int *>(img + PB) = m0;
+            *reinterpret_cast<int *>(img + 2 * PB) = l0;
+          }
+        }
+      }
+    }
+  }
+}
+
+// the unit's own side as COLUMN fragments (B operand), once per unit from global memory: lane (n = lane & 15, kg) holds
+// channels 32 ks + 8 kg .. + 7 of token 16 wave + n, scaled, split; token rows >= L and channels >= dh read as zero.
+// Two steps, so that the loads are in flight while the unit's first tiles are requested (own_load), and are only waited
+// for behind that (own_split).
+struct OwnRaw {
+  float2 x[2][4];
+};
+__device__ __forceinline__ void own_load(OwnRaw &o, const float *base, int row_stride, int wave, int L, int dh, int lane) {
+  const int n = lane & 15, kg = lane >> 4, j = 16 * wave + n;
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int c = 32 * ks + 8 * kg + 2 * u;
+      o.x[ks][u] = make_float2(0.f, 0.f);
+      if (j < L && c < dh) o.x[ks][u] = *reinterpret_cast<const float2 *>(base + j * row_stride + c);
+    }
+  }
+}
+__device__ __forceinline__ void own_split(Frag3 (&f)[2], const OwnRaw &o, float mul) {
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    int h[4], m[4], l[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) split3(o.x[ks][u].x * mul, o.x[ks][u].y * mul, h[u], m[u], l[u]);
+    f[ks].h = i32x4{h[0], h[1], h[2], h[3]};
+    f[ks].m = i32x4{m[0], m[1], m[2], m[3]};
+    f[ks].l = i32x4{l[0], l[1], l[2], l[3]};
+  }
+}
+
+// channel-product fragment (A operand) of token tile t, k-step ks: `aks` = this lane's byte offset for that k-step
+template <int PB>
+__device__ __forceinline__ Frag3 rowfrag3(const char *img, int aks, int t) {
+  const char *p = img + aks + t * kTileRowsB;
+  return Frag3{*reinterpret_cast<const i32x4 *>(p), *reinterpret_cast<const i32x4 *>(p + PB),
+               *reinterpret_cast<const i32x4 *>(p + 2 * PB)};
+}
+
+__device__ __forceinline__ i32x2 tr64(const char *p) {
+  return __builtin_bit_cast(i32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4 *)p));
+}
+// token-product fragment (A operand, rows = channels 16 mc .. + 15) over the token tiles (2 pair, 2 pair + 1): k-slots
+// 0..3 = tokens 16 (2 pair) + 4 kg + 0..3, slots 4..7 = the same rows of the next tile (a last odd tile: its own values
+// again -- finite -- against zeros in the other operand).  `trb` = this lane's byte offset for channel tile mc.
+template <int NT, int PB>
+__device__ __forceinline__ Frag3 colfrag3(const char *img, int trb, int pair) {
+  const char *p = img + trb + 2 * pair * kTileRowsB;
+  const bool two = 2 * pair + 1 < NT;
+  const i32x2 a0 = tr64(p), a1 = tr64(p + PB), a2 = tr64(p + 2 * PB);
+  const i32x2 b0 = two ? tr64(p + kTileRowsB) : a0, b1 = two ? tr64(p + kTileRowsB + PB) : a1,
+              b2 = two ? tr64(p + kTileRowsB + 2 * PB) : a2;
+  return Frag3{i32x4{a0[0], a0[1], b0[0], b0[1]}, i32x4{a1[0], a1[1], b1[0], b1[1]}, i32x4{a2[0], a2[1], b2[0], b2[1]}};
+}
+// C/D tiles of a tile pair (lane (n, g), reg q of tile t = token 16 t + 4 g + q) -> the B operand of the token product
+template <int NT>
+__device__ __forceinline__ Frag3 cd_frag3(const f32x4 (&T)[NT], int pair) {
+  int h[4] = {0, 0, 0, 0}, m[4] = {0, 0, 0, 0}, l[4] = {0, 0, 0, 0};
+  const f32x4 a = T[2 * pair];
+  split3(a[0], a[1], h[0], m[0], l[0]);
+  split3(a[2], a[3], h[1], m[1], l[1]);
+  if (2 * pair + 1 < NT) {
+    const f32x4 b = T[2 * pair + 1 < NT ? 2 * pair + 1 : 0];
+    split3(b[0], b[1], h[2], m[2], l[2]);
+    split3(b[2], b[3], h[3], m[3], l[3]);
+  }
+  return Frag3{i32x4{h[0], h[1], h[2], h[3]}, i32x4{m[0], m[1], m[2], m[3]}, i32x4{l[0], l[1], l[2], l[3]}};
+}
+
+// every transposed fragment of a product group is in its registers before the group's first MFMA issues, and no
+// transposed read is scheduled in among the MFMAs (tests/test_abi.py scans the shipped ISA)
+#define X3_FRAG_FENCE()                                    \
+  do {                                                     \
+    __builtin_amdgcn_sched_barrier(0);                     \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     \
+    __builtin_amdgcn_sched_barrier(0);                     \
+  } while (0)
+// in front of a group of transposed reads that follows MFMAs (their fragment registers may be taken over)
+#define X3_PRE_READ()                          \
+  do {                                         \
+    __builtin_amdgcn_sched_barrier(0);         \
+    asm volatile("s_nop 7" ::: "memory");      \
+    __builtin_amdgcn_sched_barrier(0);         \
+  } while (0)
+
+// per-lane address parts of the fragment reads
+struct FragAddr {
+  int a[2];       // channel-product fragments, k-steps 0 / 1
+  int tr[4];      // token-product fragments, channel tiles 0..3
+};
+__device__ __forceinline__ FragAddr frag_addr(int lane) {
+  FragAddr fa;
+  const int m = lane & 15, kg = lane >> 4;
+  fa.a[0] = xoff(m, kg);
+  fa.a[1] = fa.a[0] ^ 64;                                   // chunk 4 + kg: the swizzle only touches bits 1..2
+  const int q = (lane >> 2) & 3, pp = lane & 3, row = 4 * kg + q;
+#pragma unroll
+  for (int mc = 0; mc < 4; ++mc) fa.tr[mc] = xoff(row, 2 * mc + (pp >> 1)) + ((pp & 1) << 3);
+  return fa;
+}
+
+// output: C/D tiles [channel tile mc] of this wave's token tile -> global rows (channels < dh, tokens < L).  Lane
+// (token n = lane & 15, g), register r of tile mc = channel 16 mc + 4 g + r
+template <int VEC>
+__device__ __forceinline__ void store_x3(const ampconv_view_t &v, int64_t node, int h, const f32x4 (&T)[4], float scale,
+                                         int tile, int L, int dh, int lane) {
+  const int i = (lane & 15) + 16 * tile, g = lane >> 4;
+  if (i >= L) return;
+  float *row = reinterpret_cast<float *>(v.ptr) + node * v.node_stride + (int64_t)h * v.head_stride + (int64_t)i * v.row_stride;
+#pragma unroll
+  for (int mc = 0; mc < 4; ++mc) {
+    const int c = 16 * mc + 4 * g;
+    const float x0 = T[mc][0] * scale, x1 = T[mc][1] * scale, x2 = T[mc][2] * scale, x3 = T[mc][3] * scale;
+    if constexpr (VEC == 4) {
+      if (c < dh) *reinterpret_cast<float4 *>(row + c) = make_float4(x0, x1, x2, x3);
+    } else {
+      if (c < dh) *reinterpret_cast<float2 *>(row + c) = make_float2(x0, x1);
+      if (c + 2 < dh) *reinterpret_cast<float2 *>(row + c + 2) = make_float2(x2, x3);
+    }
+  }
+}
+
+// softmax over the source tokens (MFMA rows of every token tile) of one destination-token column; returns m + log2(sum)
+template <int NT>
+__device__ __forceinline__ float x3_column_softmax(f32x4 (&S)[NT], int L, int g) {
+  float m = kNegBig;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (16 * t + 4 * g + q >= L) S[t][q] = kNegBig;
+      m = fmaxf(m, S[t][q]);
+    }
+  }
+  m = groups_max(m);
+  float l = 0.f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      S[t][q] = fast_exp2(S[t][q] - m);
+      l += S[t][q];
+    }
+  }
+  l = groups_sum(l);
+  const float inv = fast_rcp(l);
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) S[t][q] *= inv;
+  }
+  return m + __builtin_amdgcn_logf(l);
+}
+
+// the staging passes rewrite whole 64-channel rows (zeros in the padding) of every token row below RS ceil(L / RS); the
+// rows above that, in all six plane images, are zeroed once per unit
+template <int VEC, int NT>
+__device__ __forceinline__ void lds_zero_tail(char *p, int L, int tid) {
+  using S = StageX<VEC, NT>;
+  constexpr int PB = 16 * NT * kRowB;
+  const int zr = ((L + S::RS - 1) / S::RS) * S::RS, nrow = 16 * NT - zr;      // rows zr .. 16 NT - 1
+  for (int i = tid; i < 6 * nrow * (kRowB / 16); i += 64 * NT) {
+    const int plane = i / (nrow * (kRowB / 16)), rem = i - plane * (nrow * (kRowB / 16));
+    *reinterpret_cast<i32x4 *>(p + plane * PB + zr * kRowB + rem * 16) = i32x4{0, 0, 0, 0};
+  }
+}
+
+// ---------------------------------------------------------------- forward
+#ifndef AMPCONV_X3_FWD_WAVES      // developer A/B switches: minimum waves per SIMD; channel tiles per group of reads
+#define AMPCONV_X3_FWD_WAVES 3
+#endif
+#ifndef AMPCONV_X3_FWD_MCB
+#define AMPCONV_X3_FWD_MCB 1
+#endif
+template <int VEC, int NT>
+__global__ __launch_bounds__(64 * NT, AMPCONV_X3_FWD_WAVES) void fwd_x3(XArgs a) {
+  constexpr int MCB = AMPCONV_X3_FWD_MCB;
+  constexpr int PB = 16 * NT * kRowB, TB = 3 * PB, NPAIR = (NT + 1) / 2;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int64_t r, onode;
+  int h, beg, end, deg;
+  const int64_t unit = xcd_unit(blockIdx.x, a.n_units, a.H);
+  if (unit < 0 || !map_unit(a.hub, a.ptr, unit, a.n_units, a.H, r, onode, h, beg, end, deg)) return;
+  const int L = a.L, dh = a.dh, g = lane >> 4;
+  char *Kt = lds, *Vt = lds + TB;
+  const int64_t d = a.qidx ? a.qidx[r] : r;
+
+  IdxWindow win;
+  if (beg < end) idxwin_load<false>(win, a.idx, nullptr, beg, end, lane);      // (first: everything else waits for it)
+  OwnRaw qraw;
+  own_load(qraw, tile_of(a.Q, d, h), (int)a.Q.row_stride, wave, L, dh, lane);
+  f32x4 OT[4];
+#pragma unroll
+  for (int mc = 0; mc < 4; ++mc) OT[mc] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const FragAddr fa = frag_addr(lane);
+  StageOffs<VEC, NT> lo;
+  xstage_offsets<VEC, NT>(lo, tid);
+
+  StageX<VEC, NT> st;
+  const StageSrc sq = stage_src<VEC, NT>((int)a.K.row_stride, (int)a.V.row_stride, L, dh, tid);
+  auto fetch = [&](int p) {
+    const int64_t s = idxwin_get<false>(win, a.idx, nullptr, p, end, lane, nullptr);
+    xstage_load<VEC, NT>(st, tile_of(a.K, s, h), tile_of(a.V, s, h), sq, L);
+  };
+  if (beg < end) fetch(beg);
+  lds_zero_tail<VEC, NT>(lds, L, tid);
+  Frag3 qf[2];
+  own_split(qf, qraw, a.qscale);
+  __syncthreads();
+  for (int p = beg; p < end; ++p) {
+    xstage_store<VEC, NT, false>(Kt, Vt, st, lo, 1.f, 1.f, L, dh, tid);
+#ifndef AMPCONV_X3_NOLOADS          // developer probe: the first edge's tiles again and again (what does the compute side cost?)
+    if (p + 1 < end) fetch(p + 1);
+#endif
+    __syncthreads();
+
+#ifdef AMPCONV_X3_NOCOMPUTE          // developer probe: staging, LDS images and barriers only (what does the memory side cost?)
+    OT[0][0] += *reinterpret_cast<const float *>(Kt + 4 * tid) + *reinterpret_cast<const float *>(Vt + 4 * tid);
+    __syncthreads();
+    continue;
+#endif
+    f32x4 S[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      S[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) S[t] = mfma6(rowfrag3<PB>(Kt, fa.a[ks], t), qf[ks], S[t]);
+    }
+    x3_column_softmax<NT>(S, L, g);
+    Frag3 pf[NPAIR];
+#pragma unroll
+    for (int mb = 0; mb < 4 / MCB; ++mb) {                  // MCB channel tiles per group of transposed reads
+      X3_PRE_READ();
+      Frag3 vc[MCB][NPAIR];
+#pragma unroll
+      for (int u = 0; u < MCB; ++u)
+#pragma unroll
+        for (int i = 0; i < NPAIR; ++i) vc[u][i] = colfrag3<NT, PB>(Vt, fa.tr[MCB * mb + u], i);
+      if (mb == 0) {
+#pragma unroll
+        for (int i = 0; i < NPAIR; ++i) pf[i] = cd_frag3<NT>(S, i);      // (in the shadow of the reads)
+      }
+      X3_FRAG_FENCE();
+#pragma unroll
+      for (int u = 0; u < MCB; ++u)
+#pragma unroll
+        for (int i = 0; i < NPAIR; ++i) OT[MCB * mb + u] = mfma6(vc[u][i], pf[i], OT[MCB * mb + u]);
+    }
+    __syncthreads();
+  }
+  // hub pass: unnormalised partial tile, the combine pass applies 1/deg
+  store_x3<VEC>(a.O, onode, h, OT, a.hub.mode == 2 ? 1.f : (deg > 0 ? 1.f / (float)deg : 0.f), wave, L, dh, lane);
+}
+
+// ---------------------------------------------------------------- backward, destination pass
+#ifndef AMPCONV_X3_DST_WAVES
+#define AMPCONV_X3_DST_WAVES 2
+#endif
+#ifndef AMPCONV_X3_DST_MCB
+#define AMPCONV_X3_DST_MCB 2
+#endif
+#ifndef AMPCONV_X3_SRC_WAVES
+#define AMPCONV_X3_SRC_WAVES 2
+#endif
+template <int VEC, bool STATS, int NT>
+__global__ __launch_bounds__(64 * NT, AMPCONV_X3_DST_WAVES) void bwd_dst_x3(XArgs a) {
+  constexpr int MCB = AMPCONV_X3_DST_MCB;
+  constexpr int PB = 16 * NT * kRowB, TB = 3 * PB, NPAIR = (NT + 1) / 2;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int64_t r, onode;
+  int h, beg, end, deg;
+  const int64_t unit = xcd_unit(blockIdx.x, a.n_units, a.H);
+  if (unit < 0 || !map_unit(a.hub, a.ptr, unit, a.n_units, a.H, r, onode, h, beg, end, deg)) return;
+  const int L = a.L, dh = a.dh, g = lane >> 4;
+  char *Kt = lds, *Vt = lds + TB;
+  const float inv = deg > 0 ? 1.f / (float)deg : 0.f;       // dO is the gradient of the MEAN
+
+  IdxWindow win;
+  const float *wts = reinterpret_cast<const float *>(a.spos);
+  if (beg < end) idxwin_load<STATS>(win, a.idx, wts, beg, end, lane);
+  OwnRaw qraw, graw;
+  own_load(qraw, tile_of(a.Q, r, h), (int)a.Q.row_stride, wave, L, dh, lane);
+  own_load(graw, tile_of(a.dO, r, h), (int)a.dO.row_stride, wave, L, dh, lane);
+  f32x4 dQT[4];
+#pragma unroll
+  for (int mc = 0; mc < 4; ++mc) dQT[mc] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const FragAddr fa = frag_addr(lane);
+  StageOffs<VEC, NT> lo;
+  xstage_offsets<VEC, NT>(lo, tid);
+
+  StageX<VEC, NT> st;
+  float pos_next = 0.f;                      // STATS: CSC position (int bits) in the window's weight slot
+  const StageSrc sq = stage_src<VEC, NT>((int)a.K.row_stride, (int)a.V.row_stride, L, dh, tid);
+  auto fetch = [&](int p) {
+    const int64_t s = idxwin_get<STATS>(win, a.idx, wts, p, end, lane, &pos_next);
+    xstage_load<VEC, NT>(st, tile_of(a.K, s, h), tile_of(a.V, s, h), sq, L);
+  };
+  if (beg < end) fetch(beg);
+  lds_zero_tail<VEC, NT>(lds, L, tid);
+  Frag3 qf[2], gf[2];
+  own_split(qf, qraw, a.qscale);
+  own_split(gf, graw, inv);
+  __syncthreads();
+  constexpr int LS = 16 * NT;
+  for (int p = beg; p < end; ++p) {
+    xstage_store<VEC, NT, false>(Kt, Vt, st, lo, 1.f, 1.f, L, dh, tid);
+    float *sb = nullptr;
+    if (STATS) sb = a.stats + ((int64_t)__builtin_bit_cast(int, pos_next) * a.H + h) * (2 * LS);
+    if (p + 1 < end) fetch(p + 1);
+    __syncthreads();
+
+    f32x4 S[NT], dP[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      S[t] = dP[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        S[t] = mfma6(rowfrag3<PB>(Kt, fa.a[ks], t), qf[ks], S[t]);
+        dP[t] = mfma6(rowfrag3<PB>(Vt, fa.a[ks], t), gf[ks], dP[t]);
+      }
+    }
+    const float lse = x3_column_softmax<NT>(S, L, g);
+    float part = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) part = fmaf(S[t][q], dP[t][q], part);
+    }
+    const float delta = groups_sum(part);
+    if (STATS && g == 0) {                   // all LS columns: the source pass reads every one
+      sb[(lane & 15) + 16 * wave] = lse;
+      sb[LS + (lane & 15) + 16 * wave] = delta;
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) S[t][q] *= dP[t][q] - delta;       // dS
+    }
+    Frag3 sf[NPAIR];
+#pragma unroll
+    for (int mb = 0; mb < 4 / MCB; ++mb) {
+      X3_PRE_READ();
+      Frag3 kc[MCB][NPAIR];
+#pragma unroll
+      for (int u = 0; u < MCB; ++u)
+#pragma unroll
+        for (int i = 0; i < NPAIR; ++i) kc[u][i] = colfrag3<NT, PB>(Kt, fa.tr[MCB * mb + u], i);
+      if (mb == 0) {
+#pragma unroll
+        for (int i = 0; i < NPAIR; ++i) sf[i] = cd_frag3<NT>(S, i);
+      }
+      X3_FRAG_FENCE();
+#pragma unroll
+      for (int u = 0; u < MCB; ++u)
+#pragma unroll
+        for (int i = 0; i < NPAIR; ++i) dQT[MCB * mb + u] = mfma6(kc[u][i], sf[i], dQT[MCB * mb + u]);
+    }
+    __syncthreads();
+  }
+  store_x3<VEC>(a.O, onode, h, dQT, a.hub.mode == 2 ? 1.f : a.oscale, wave, L, dh, lane);
+}
+
+// ---------------------------------------------------------------- backward, source pass (needs the statistics)
+template <int VEC, int NT>
+__global__ __launch_bounds__(64 * NT, AMPCONV_X3_SRC_WAVES) void bwd_src_x3(XArgs a) {
+  constexpr int PB = 16 * NT * kRowB, TB = 3 * PB, NPAIR = (NT + 1) / 2;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int64_t s, onode;
+  int h, beg, end, deg;
+  const int64_t unit = xcd_unit(blockIdx.x, a.n_units, a.H);
+  if (unit < 0 || !map_unit(a.hub, a.ptr, unit, a.n_units, a.H, s, onode, h, beg, end, deg)) return;
+  const int L = a.L, dh = a.dh, g = lane >> 4, n = lane & 15;
+  char *Qt = lds, *Gt = lds + TB;
+
+  IdxWindow win;
+  if (beg < end) idxwin_load<true>(win, a.idx, a.cinv, beg, end, lane);
+  OwnRaw kraw, vraw;
+  own_load(kraw, tile_of(a.K, s, h), (int)a.K.row_stride, wave, L, dh, lane);
+  own_load(vraw, tile_of(a.V, s, h), (int)a.V.row_stride, wave, L, dh, lane);
+  f32x4 dKT[4], dVT[4];
+#pragma unroll
+  for (int mc = 0; mc < 4; ++mc) dKT[mc] = dVT[mc] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const FragAddr fa = frag_addr(lane);
+  StageOffs<VEC, NT> lo;
+  xstage_offsets<VEC, NT>(lo, tid);
+
+  StageX<VEC, NT> st;
+  float inv_next = 0.f;
+  // the edge's softmax statistics (2 LS floats, written by the destination pass at this CSC position) travel with its
+  // tiles: one float per thread, requested an edge ahead and handed to the waves through LDS
+  constexpr int LS = 16 * NT;
+  float *sl = reinterpret_cast<float *>(lds + 2 * TB);
+  float stat_next = 0.f;
+  const StageSrc sq = stage_src<VEC, NT>((int)a.Q.row_stride, (int)a.dO.row_stride, L, dh, tid);
+  auto fetch = [&](int p) {
+    const int64_t d = idxwin_get<true>(win, a.idx, a.cinv, p, end, lane, &inv_next);
+    if (tid < 2 * LS) stat_next = a.stats[((int64_t)p * a.H + h) * (2 * LS) + tid];
+    xstage_load<VEC, NT>(st, tile_of(a.Q, d, h), tile_of(a.dO, d, h), sq, L);
+  };
+  if (beg < end) fetch(beg);
+  lds_zero_tail<VEC, NT>(lds, L, tid);
+  Frag3 kf[2], vf[2];
+  own_split(kf, kraw, 1.f);
+  own_split(vf, vraw, 1.f);
+  __syncthreads();
+  const bool colok = n + 16 * wave < L;      // this lane's source token exists
+  for (int p = beg; p < end; ++p) {
+    xstage_store<VEC, NT, true>(Qt, Gt, st, lo, a.qscale, inv_next, L, dh, tid);
+    if (tid < 2 * LS) sl[tid] = stat_next;
+    if (p + 1 < end) fetch(p + 1);
+    __syncthreads();
+
+    f32x4 P[NT], dS[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {             // destination tokens 16 t + 4 g + q
+      const f32x4 l4 = *reinterpret_cast<const f32x4 *>(sl + 16 * t + 4 * g);
+      const f32x4 d4 = *reinterpret_cast<const f32x4 *>(sl + LS + 16 * t + 4 * g);
+      f32x4 S = f32x4{0.f, 0.f, 0.f, 0.f}, dP = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        S = mfma6(rowfrag3<PB>(Qt, fa.a[ks], t), kf[ks], S);
+        dP = mfma6(rowfrag3<PB>(Gt, fa.a[ks], t), vf[ks], dP);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float pr = colok ? fast_exp2(S[q] - l4[q]) : 0.f;
+        P[t][q] = pr;
+        dS[t][q] = pr * (dP[q] - d4[q]);
+      }
+    }
+    Frag3 pf[NPAIR], sf[NPAIR];
+#pragma unroll
+    for (int mc = 0; mc < 4; ++mc) {
+      X3_PRE_READ();
+      Frag3 gc[NPAIR], qc[NPAIR];
+#pragma unroll
+      for (int i = 0; i < NPAIR; ++i) {
+        gc[i] = colfrag3<NT, PB>(Gt, fa.tr[mc], i);
+        qc[i] = colfrag3<NT, PB>(Qt, fa.tr[mc], i);
+      }
+      if (mc == 0) {
+#pragma unroll
+        for (int i = 0; i < NPAIR; ++i) {
+          pf[i] = cd_frag3<NT>(P, i);
+          sf[i] = cd_frag3<NT>(dS, i);
+        }
+      }
+      X3_FRAG_FENCE();
+#pragma unroll
+      for (int i = 0; i < NPAIR; ++i) {
+        dVT[mc] = mfma6(gc[i], pf[i], dVT[mc]);
+        dKT[mc] = mfma6(qc[i], sf[i], dKT[mc]);
+      }
+    }
+    __syncthreads();
+  }
+  store_x3<VEC>(a.dK, onode, h, dKT, a.hub.mode == 2 ? 1.f : a.oscale, wave, L, dh, lane);
+  store_x3<VEC>(a.dV, onode, h, dVT, 1.f, wave, L, dh, lane);
+}
+
+typedef void (*X3Kernel)(XArgs);
+template <template <int, int> class F>
+X3Kernel x3_pick(int vec, int ntok) {
+  switch (ntok) {
+    case 1: return vec == 4 ? F<4, 1>::get() : F<2, 1>::get();
+    case 2: return vec == 4 ? F<4, 2>::get() : F<2, 2>::get();
+    case 3: return vec == 4 ? F<4, 3>::get() : F<2, 3>::get();
+    default: return vec == 4 ? F<4, 4>::get() : F<2, 4>::get();
+  }
+}
+template <int VEC, int NT> struct XFwd { static X3Kernel get() { return fwd_x3<VEC, NT>; } };
+template <int VEC, int NT> struct XDstS { static X3Kernel get() { return bwd_dst_x3<VEC, true, NT>; } };
+template <int VEC, int NT> struct XDst { static X3Kernel get() { return bwd_dst_x3<VEC, false, NT>; } };
+template <int VEC, int NT> struct XSrc { static X3Kernel get() { return bwd_src_x3<VEC, NT>; } };
+
+int launch_x3(const XArgs &a, int ntok, X3Kernel k, hipStream_t stream, int extra_bytes = 0) {
+  const int64_t nb = xcd_grid(a.n_units, a.H);
+  if (nb > INT32_MAX) return AMPCONV_E_BADARG;
+  const dim3 grid((unsigned)nb), block(64 * ntok);
+  const size_t shmem = (size_t)2 * 3 * 16 * ntok * kRowB + extra_bytes;
+  hipLaunchKernelGGL(k, grid, block, shmem, stream, a);
+  return ampconv_launch_status();
+}
+
+XArgs x3_args(int64_t n_rows, int L, int D, int H) {
+  XArgs a{};
+  a.L = L; a.dh = D / H; a.H = H;
+  a.n_units = n_rows * H;
+  a.qscale = kLog2eX / sqrtf((float)a.dh);
+  return a;
+}
+
+}  // namespace
+
+// developer A/B switch: AMPCONV_BLOCK_X3=0 keeps these shapes on the fp32-MFMA kernels of edge_block.hip
+bool ampconv_block_x3_supported(int L, int D, int H, bool bf16) {
+  static const bool on = [] {
+    const char *e = getenv("AMPCONV_BLOCK_X3");
+    return !(e && e[0] == '0');
+  }();
+  const int dh = D / H;
+  return on && !bf16 && L >= 1 && L <= 64 && dh > 32 && dh <= 64 && dh % 2 == 0;
+}
+
+int ampconv_fwd_edge_block_x3(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V, const int32_t *rowptr,
+                              const int32_t *col, const int32_t *qidx, int64_t n_rows, int L, int D, int H,
+                              ampconv_view_t O, HubArgs hub, int vec, hipStream_t stream) {
+  XArgs a = x3_args(n_rows, L, D, H);
+  a.hub = hub;
+  a.Q = Q; a.K = K; a.V = V; a.O = O;
+  a.ptr = rowptr; a.idx = col; a.qidx = qidx;
+  const int ntok = (L + 15) / 16;
+  return launch_x3(a, ntok, x3_pick<XFwd>(vec, ntok), stream);
+}
+
+int ampconv_bwd_edge_dst_block_x3(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V, ampconv_view_t dO,
+                                  const int32_t *rowptr, const int32_t *col, int64_t n_rows, int L, int D, int H,
+                                  ampconv_view_t dQ, HubArgs hub, StatsArgs sa, int vec, hipStream_t stream) {
+  XArgs a = x3_args(n_rows, L, D, H);
+  a.hub = hub;
+  a.Q = Q; a.K = K; a.V = V; a.dO = dO; a.O = dQ;
+  a.ptr = rowptr; a.idx = col; a.spos = sa.spos; a.stats = sa.stats;
+  a.oscale = 1.f / sqrtf((float)a.dh);
+  const int ntok = (L + 15) / 16;
+  return launch_x3(a, ntok, sa.stats ? x3_pick<XDstS>(vec, ntok) : x3_pick<XDst>(vec, ntok), stream);
+}
+
+int ampconv_bwd_edge_src_block_x3(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V, ampconv_view_t dO,
+                                  const int32_t *cscptr, const int32_t *crow, const float *cinv, int64_t n_src, int L,
+                                  int D, int H, ampconv_view_t dK, ampconv_view_t dV, HubArgs hub, const float *stats,
+                                  int vec, hipStream_t stream) {
+  if (!stats) return AMPCONV_E_BADARG;
+  XArgs a = x3_args(n_src, L, D, H);
+  a.hub = hub;
+  a.Q = Q; a.K = K; a.V = V; a.dO = dO; a.dK = dK; a.dV = dV;
+  a.ptr = cscptr; a.idx = crow; a.cinv = cinv; a.stats = const_cast<float *>(stats);
+  a.oscale = 0.6931471805599453f;       // dK = ln2 * sum dS^T (Q * log2e / sqrt(dh))
+  const int ntok = (L + 15) / 16;
+  return launch_x3(a, ntok, x3_pick<XSrc>(vec, ntok), stream, 2 * 16 * ntok * (int)sizeof(float));
+}
