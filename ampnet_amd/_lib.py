@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('AMPCONV_LIB_PATH', os.path.join(_HERE, 'libampconv.so'))   # override: dev A/B builds
 
-EXPECTED_ABI = 106          # AMPCONV_VERSION of include/ampconv.h this binding was written against
+EXPECTED_ABI = 107          # AMPCONV_VERSION of include/ampconv.h this binding was written against
 
 AMPCONV_F32 = 0
 AMPCONV_BF16 = 1
@@ -87,6 +87,12 @@ SIGNATURES = {
                                            _vp, _vp, _vp, _vp, _vp]),
     'ampconv_bwd_edge_src_planes': (_i32, [View, View, View, View, _vp, _vp, _i64, _i32, _i32, _i32, View, View, _vp, _i64,
                                            _vp, _vp, _vp, _vp, _vp]),
+    'ampconv_scaled_supported': (_i32, [_i32, _i32, _i32]),
+    'ampconv_fwd_edge_scaled': (_i32, [View, View, View, _vp, _vp, _i64, _i32, _i32, _i32, View, _vp, _i64, _vp, _vp, _vp]),
+    'ampconv_bwd_edge_dst_scaled': (_i32, [View, View, View, View, _vp, _vp, _i64, _i32, _i32, _i32, View, _vp, _i64, _vp,
+                                           _vp, _vp, _vp, _vp, _vp]),
+    'ampconv_bwd_edge_src_scaled': (_i32, [View, View, View, View, _vp, _vp, _vp, _i64, _i32, _i32, _i32, View, View, _vp,
+                                           _i64, _vp, _vp, _vp, _vp, _vp]),
     'ampconv_proj_out_bound': (_i32, [_vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
     'ampconv_proj_rows_planes': (_i32, [_vp, _i64, _i64, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _vp, _i64, _vp, _vp, _vp,
                                         _i32, _i32, _vp]),

@@ -188,6 +188,13 @@ def planes_ok(L, D, H, shared):
     return bool(EDGE_PLANES and shared and D % 128 == 0 and _lib.load().ampconv_planes_supported(L, D, H))
 
 
+def scaled_views_ok(L, D, H, shared):
+    """Do the bound-carrying fp32 entry points (include/ampconv.h, ampconv_*_edge_scaled: the workgroup-per-unit shapes,
+    e.g. the AMPGCN class defaults L = 40, D = 100, H = 2) serve this layer call?  Only with the scaled projections and
+    the statistics hand-off; the caller checks the former."""
+    return bool(EDGE_PLANES and SOFTMAX_STATS and shared and _lib.load().ampconv_scaled_supported(L, D, H))
+
+
 def absmax(t2, out=None, reset=False):
     """Largest finite magnitude of a 2-D tensor with contiguous rows, as a one-element device tensor (no host sync):
     the scale source of the fp32 projections' two-plane mode.  `out`: merge into an existing maximum (reset: zero it
@@ -362,7 +369,7 @@ class AMPConvFunction(torch.autograd.Function):
             # The scaled mode serves operands that lie within 2^RANGE_LOG2 of their maximum (operand_stats: one pass, one
             # 8-byte read-back, remembered per tensor version); anything wider takes the exact six-product kernels.
             am = bounds = None
-            planes = False
+            planes = scaledv = False
             xkv2 = xq2 if shared else xkv.contiguous().view(Nk * L, D)
             # (the read-back rules the mode out while a HIP graph is being recorded: ampnet_amd/graphed.py is for small graphs)
             if (native and PROJ_SCALED and xq.dtype == torch.float32 and xq2.numel() >= PROJ_SCALED_MIN_ELEMENTS
@@ -373,11 +380,14 @@ class AMPConvFunction(torch.autograd.Function):
                     stk, narrow = operand_stats(xkv2, key=xkv)
                 if narrow:
                     planes = planes_ok(L, D, H, shared)
+                    scaledv = not planes and scaled_views_ok(L, D, H, shared)
                     # device scalars of the plane format (include/ampconv.h): [bound of Q|K|V, bound of dObar, recorded
-                    # max |V|, recorded max |dObar|]; max |V| doubles as the operand maximum of Obar (am[1])
-                    bounds = torch.zeros(4, dtype=torch.float32, device=xq.device) if planes else None
-                    am = [st[0:1], bounds[2:3] if planes else torch.zeros(1, dtype=torch.float32, device=xq.device),
-                          None if shared else stk[0:1]]
+                    # max |V|, recorded max |dObar|]; max |V| doubles as the operand maximum of Obar (am[1]).
+                    # fp32 views with bounds (`scaledv`): the in-projection records max |Q|K|V| into bounds[0], which serves
+                    # as all of: the tensor's scale, the bound of |V|, and the operand maximum of Obar
+                    bounds = torch.zeros(4, dtype=torch.float32, device=xq.device) if planes or scaledv else None
+                    am = [st[0:1], bounds[2:3] if planes else bounds[0:1] if scaledv else
+                          torch.zeros(1, dtype=torch.float32, device=xq.device), None if shared else stk[0:1]]
             sl = (lambda i: am[i]) if am is not None else (lambda i: None)
             if planes:
                 # Q | K | V leave the in-projection as two fp16 planes scaled by a bound known before the product runs
@@ -409,6 +419,12 @@ class AMPConvFunction(torch.autograd.Function):
                 _lib.check(lib.ampconv_fwd_edge_planes(Qv, Kv, Vv, csr.rowptr.data_ptr(), csr.col.data_ptr(), Nq, L, D, H,
                                                        _view(obar, 0, L, dh), plan, nch, _ptr(ws), bounds.data_ptr(),
                                                        _stream()), 'ampconv_fwd_edge_planes')
+            elif scaledv:
+                bounds[2:3].copy_(bounds[0:1])
+                plan, nch, ws = csr.hub_args('dst', L, D, 1)
+                _lib.check(lib.ampconv_fwd_edge_scaled(Qv, Kv, Vv, csr.rowptr.data_ptr(), csr.col.data_ptr(), Nq, L, D, H,
+                                                       _view(obar, 0, L, dh), plan, nch, _ptr(ws), bounds.data_ptr(),
+                                                       _stream()), 'ampconv_fwd_edge_scaled')
             else:
                 edge_forward(Qv, Kv, Vv, csr, Nq, L, D, H, obar, dtype=dtype)
             if lists:       # the rows of the nodes with in-edges; the others are zeroed without being read
@@ -424,12 +440,12 @@ class AMPConvFunction(torch.autograd.Function):
         ctx.set_materialize_grads(False)     # no zero-filled [N*L, 3D] gradient for the qkv side output
         ctx.save_for_backward(xq2, xkv2, w_in, w_out, qkv, kv, obar)
         ctx.csr, ctx.dims, ctx.shared, ctx.dtype, ctx.gemm = csr, (Nq, Nk, L, D, H), shared, dtype, gemm
-        ctx.lists, ctx.amax, ctx.bounds = lists, am, bounds
+        ctx.lists, ctx.amax, ctx.bounds, ctx.plane_format = lists, am, bounds, planes
         ctx.images_t = imgs[len(imgs) // 2:] if imgs else None     # the transposed images, for the input gradients
         ctx.mark_non_differentiable(qkv)
         if kv is not None:
             ctx.mark_non_differentiable(kv)
-        if bounds is not None:              # plane format: the third output is what reads `qkv` back (planes_to_f32)
+        if planes:                          # plane format: the third output is what reads `qkv` back (planes_to_f32)
             ctx.mark_non_differentiable(bounds)
             return y.view(Nq, L * D), qkv, bounds
         return y.view(Nq, L * D), qkv, kv
@@ -461,8 +477,9 @@ class AMPConvFunction(torch.autograd.Function):
                     ag = [stg[0:1], torch.zeros(1, dtype=torch.float32, device=dev), None]
                 else:
                     am = None
-            planes = bounds is not None and ag is not None
-            if bounds is not None and not planes:         # the saved projections as fp32 for the exact edge passes
+            planes = ctx.plane_format and ag is not None
+            scaledv = bounds is not None and not ctx.plane_format and ag is not None
+            if ctx.plane_format and not planes:           # the saved projections as fp32 for the exact edge passes
                 qkv = planes_to_f32(qkv, bounds[0:1], dh)
             sl = (lambda t, i: t[i]) if am is not None else (lambda t, i: None)
             pair = (lambda a, b: (a, b)) if am is not None else (lambda a, b: None)
@@ -478,6 +495,11 @@ class AMPConvFunction(torch.autograd.Function):
                     bounds[3:4].zero_()
                     dobar = proj_rows_planes(dy2, ctx.images_t[-1], bounds[1:2], rowptr=csr.rowptr, L=L, row_scale=1,
                                              amax=ag[0], out_amax=bounds[3:4], dh=dh)
+                elif scaledv:   # fp32 dObar, its maximum recorded by the product that writes it (bounds[1]; [3]: a copy)
+                    proj_wgrad(dy2, obar, dw_out, db_out, csr.rowptr, L, amax=pair(sl(ag, 0), sl(am, 1)))
+                    bounds[1:2].zero_()
+                    dobar = proj_rows(dy2, ctx.images_t[-1], amax=ag[0], out_amax=bounds[1:2])
+                    bounds[3:4].copy_(bounds[1:2])
                 else:
                     proj_wgrad(dy2, obar, dw_out, db_out, csr.rowptr, L, amax=pair(sl(ag, 0), sl(am, 1)))
                     dobar = proj_rows(dy2, ctx.images_t[-1], amax=sl(ag, 0))
@@ -520,6 +542,16 @@ class AMPConvFunction(torch.autograd.Function):
                                                            Nk, L, D, H, dKv, dVv, plan, nch, _ptr(ws), bounds.data_ptr(),
                                                            _ptr(stats), ag[1].data_ptr(), _stream()),
                            'ampconv_bwd_edge_src_planes')
+            elif scaledv:
+                _lib.check(lib.ampconv_bwd_edge_dst_scaled(Qv, Kv, Vv, dOv, csr.rowptr.data_ptr(), csr.col.data_ptr(),
+                                                           Nq, L, D, H, dQv, plan, nch, _ptr(ws), bounds.data_ptr(),
+                                                           _ptr(spos), _ptr(stats), ag[1].data_ptr(), _stream()),
+                           'ampconv_bwd_edge_dst_scaled')
+                plan, nch, ws = csr.hub_args('src', L, D, 2)
+                _lib.check(lib.ampconv_bwd_edge_src_scaled(Qv, Kv, Vv, dOv, csr.cscptr.data_ptr(), csr.crow.data_ptr(),
+                                                           csr.cinv.data_ptr(), Nk, L, D, H, dKv, dVv, plan, nch, _ptr(ws),
+                                                           bounds.data_ptr(), _ptr(stats), ag[1].data_ptr(), _stream()),
+                           'ampconv_bwd_edge_src_scaled')
             else:
                 # (scaled projections: the operand maximum of the two products that consume dQKV.  The destination pass
                 # records the maximum of dQ as it stores; dK | dV: one pass below -- the fp32 source-pass kernels have no

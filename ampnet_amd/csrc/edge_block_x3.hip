@@ -78,6 +78,8 @@ struct XArgs {
   int64_t n_units;
   int L, dh, H;
   float qscale, oscale;
+  const float *bounds;      // scaled kernels: device {bound of |Q|K|V|, bound of |dObar|, recorded max |V|, recorded max |dObar|}
+  float *absmax;            // scaled backward kernels, or null: atomic max of the finite magnitudes written
 };
 
 __device__ __forceinline__ const float *tile_of(const ampconv_view_t &v, int64_t n, int h) {
@@ -301,22 +303,33 @@ __device__ __forceinline__ FragAddr frag_addr(int lane) {
 // output: C/D tiles [channel tile mc] of this wave's token tile -> global rows (channels < dh, tokens < L).  Lane
 // (token n = lane & 15, g), register r of tile mc = channel 16 mc + 4 g + r
 template <int VEC>
-__device__ __forceinline__ void store_x3(const ampconv_view_t &v, int64_t node, int h, const f32x4 (&T)[4], float scale,
-                                         int tile, int L, int dh, int lane) {
+__device__ __forceinline__ float store_x3(const ampconv_view_t &v, int64_t node, int h, const f32x4 (&T)[4], float scale,
+                                          int tile, int L, int dh, int lane) {
   const int i = (lane & 15) + 16 * tile, g = lane >> 4;
-  if (i >= L) return;
+  float mx = 0.f;                      // largest finite magnitude stored (the scaled backward kernels record it)
+  if (i >= L) return mx;
   float *row = reinterpret_cast<float *>(v.ptr) + node * v.node_stride + (int64_t)h * v.head_stride + (int64_t)i * v.row_stride;
 #pragma unroll
   for (int mc = 0; mc < 4; ++mc) {
     const int c = 16 * mc + 4 * g;
     const float x0 = T[mc][0] * scale, x1 = T[mc][1] * scale, x2 = T[mc][2] * scale, x3 = T[mc][3] * scale;
     if constexpr (VEC == 4) {
-      if (c < dh) *reinterpret_cast<float4 *>(row + c) = make_float4(x0, x1, x2, x3);
+      if (c < dh) {
+        *reinterpret_cast<float4 *>(row + c) = make_float4(x0, x1, x2, x3);
+        mx = finite_abs_max(mx, make_float4(x0, x1, x2, x3));
+      }
     } else {
-      if (c < dh) *reinterpret_cast<float2 *>(row + c) = make_float2(x0, x1);
-      if (c + 2 < dh) *reinterpret_cast<float2 *>(row + c + 2) = make_float2(x2, x3);
+      if (c < dh) {
+        *reinterpret_cast<float2 *>(row + c) = make_float2(x0, x1);
+        mx = fmaxf(mx, fmaxf(finite_abs(x0), finite_abs(x1)));
+      }
+      if (c + 2 < dh) {
+        *reinterpret_cast<float2 *>(row + c + 2) = make_float2(x2, x3);
+        mx = fmaxf(mx, fmaxf(finite_abs(x2), finite_abs(x3)));
+      }
     }
   }
+  return mx;
 }
 
 // softmax over the source tokens (MFMA rows of every token tile) of one destination-token column; returns m + log2(sum)
@@ -352,13 +365,13 @@ __device__ __forceinline__ float x3_column_softmax(f32x4 (&S)[NT], int L, int g)
 }
 
 // the staging passes rewrite whole 64-channel rows (zeros in the padding) of every token row below RS ceil(L / RS); the
-// rows above that, in all six plane images, are zeroed once per unit
-template <int VEC, int NT>
+// rows above that, in all plane images, are zeroed once per unit
+template <int VEC, int NT, int NPLANES = 6>
 __device__ __forceinline__ void lds_zero_tail(char *p, int L, int tid) {
   using S = StageX<VEC, NT>;
   constexpr int PB = 16 * NT * kRowB;
   const int zr = ((L + S::RS - 1) / S::RS) * S::RS, nrow = 16 * NT - zr;      // rows zr .. 16 NT - 1
-  for (int i = tid; i < 6 * nrow * (kRowB / 16); i += 64 * NT) {
+  for (int i = tid; i < NPLANES * nrow * (kRowB / 16); i += 64 * NT) {
     const int plane = i / (nrow * (kRowB / 16)), rem = i - plane * (nrow * (kRowB / 16));
     *reinterpret_cast<i32x4 *>(p + plane * PB + zr * kRowB + rem * 16) = i32x4{0, 0, 0, 0};
   }
@@ -663,6 +676,518 @@ __global__ __launch_bounds__(64 * NT, AMPCONV_X3_SRC_WAVES) void bwd_src_x3(XArg
   store_x3<VEC>(a.dV, onode, h, dVT, 1.f, wave, L, dh, lane);
 }
 
+// =====================================================================================================================
+// The same three passes on TWO fp16 planes of the power-of-two-SCALED value (entry points ampconv_*_edge_scaled): with
+// a device-side bound of the operands' magnitudes -- the a-priori bound of the projection that produced them, as for the
+// plane-format kernels of edge_mfma_f16x2.hip -- x 2^e = hi + lo with |x 2^e| < 2^15 needs two 16-bit
+// planes instead of three and three partial products instead of six:
+//      a b ~ a_lo b_hi + a_hi b_lo + a_hi b_hi        (dropped: a_lo b_lo <= 2^-22 |a b|)
+// Half the matrix-pipe cycles, two thirds of the split's vector instructions and of the LDS traffic of the bf16 version.
+// The scale bookkeeping is that of edge_mfma_f16x2.hip: scores meet their scale inside the exponential, P is split as
+// P 2^14, dS with one power of two per WAVE from what the wave can see (Cauchy-Schwarz: its own side's largest token-row
+// norm, sqrt(64) x the recorded maximum of the streamed tensor); dObar is divided by the in-degree here (own side: once
+// per unit, streamed side: in the staging pass), the statistics hand-off carries delta in the units of dP' = dO' V'^T.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+#define MFMA_XH(a, b, c) \
+  __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), (c), 0, 0, 0)
+
+constexpr float kPScaleX = 16384.f, kPUnscaleX = 1.f / 16384.f;
+constexpr float kMaskedX = -__builtin_inff();     // (scores meet their scale inside the exponential: a finite mask could be scaled back into range)
+
+struct Frag2 {
+  i32x4 h, l;
+};
+__device__ __forceinline__ f32x4 mfma3h(const Frag2 &a, const Frag2 &b, f32x4 c) {
+  c = MFMA_XH(a.l, b.h, c);
+  c = MFMA_XH(a.h, b.l, c);
+  return MFMA_XH(a.h, b.h, c);
+}
+// 2^(14 - floor(log2 bound)), exponent field clamped (the function of proj_gemm.hip / edge_mfma_f16x2.hip)
+__device__ __forceinline__ float plane_scale_x(float bound) {
+  int e = (int)((__builtin_bit_cast(unsigned, bound) >> 23) & 0xFFu);
+  e = e < 15 ? 15 : (e > 254 ? 254 : e);
+  return __builtin_bit_cast(float, (unsigned)(268 - e) << 23);
+}
+__device__ __forceinline__ int pk_h(float a, float b) {      // v_cvt_pk_f16_f32 (RNE)
+  f32x2 v = {a, b};
+  return __builtin_bit_cast(int, __builtin_convertvector(v, f16x2));
+}
+// (x0, x1), already scaled, |x| < 2^16 -> packed fp16 pairs of the two planes
+__device__ __forceinline__ void split2h(float x0, float x1, int &h, int &l) {
+  h = pk_h(x0, x1);
+  const f16x2 hv = __builtin_bit_cast(f16x2, h);
+  l = pk_h(x0 - (float)hv[0], x1 - (float)hv[1]);
+}
+__device__ __forceinline__ float frag_sumsq_h(const i32x4 &f) {
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const f16x2 v = __builtin_bit_cast(f16x2, f[k]);
+    s = __builtin_amdgcn_fdot2(v, v, s, false);
+  }
+  return s;
+}
+// largest token-row norm^2 of the wave's own 16 tokens (hi planes of its two k-step fragments): wave-uniform
+__device__ __forceinline__ float own_max_norm2(const Frag2 (&f)[2]) {
+  const float t = groups_sum(frag_sumsq_h(f[0].h) + frag_sumsq_h(f[1].h));
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, row16_max(t))));
+}
+// scale of dS for a wave whose own side has largest row norm^2 `own2` and whose streamed side is bounded by `other` per
+// element (both in plane units, 64 channels): dS * scale < 2^15
+__device__ __forceinline__ float ds_scale_x(float own2, float other) {
+  return plane_scale_x(2.f * __builtin_sqrtf(own2) * (8.f * other));
+}
+
+template <int VEC, int NT>
+__device__ __forceinline__ void xstage_store_h(char *imgA, char *imgB, const StageX<VEC, NT> &s,
+                                               const StageOffs<VEC, NT> &lo, float mulA, float mulB, int L) {
+  using S = StageX<VEC, NT>;
+  constexpr int PB = 16 * NT * kRowB;
+#pragma unroll
+  for (int i = 0; i < S::NP; ++i) {
+    if (i * S::RS < L) {
+#pragma unroll
+      for (int x = 0; x < 2; ++x) {
+        char *img = (x ? imgB : imgA) + lo.v[i];
+        const float mul = x ? mulB : mulA;
+        if constexpr (VEC == 4) {
+          int h0, l0, h1, l1;
+          split2h(s.v[x][i][0] * mul, s.v[x][i][1] * mul, h0, l0);
+          split2h(s.v[x][i][2] * mul, s.v[x][i][3] * mul, h1, l1);
+          *reinterpret_cast<i32x2 *>(img) = i32x2{h0, h1};
+          *reinterpret_cast<i32x2 *>(img + PB) = i32x2{l0, l1};
+        } else {
+          int h0, l0;
+          split2h(s.v[x][i][0] * mul, s.v[x][i][1] * mul, h0, l0);
+          *reinterpret_cast<int *>(img) = h0;
+          *reinterpret_cast<int *>(img + PB) = l0;
+        }
+      }
+    }
+  }
+}
+__device__ __forceinline__ void own_split_h(Frag2 (&f)[2], const OwnRaw &o, float mul) {
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    int h[4], l[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) split2h(o.x[ks][u].x * mul, o.x[ks][u].y * mul, h[u], l[u]);
+    f[ks].h = i32x4{h[0], h[1], h[2], h[3]};
+    f[ks].l = i32x4{l[0], l[1], l[2], l[3]};
+  }
+}
+template <int PB>
+__device__ __forceinline__ Frag2 rowfrag2(const char *img, int aks, int t) {
+  const char *p = img + aks + t * kTileRowsB;
+  return Frag2{*reinterpret_cast<const i32x4 *>(p), *reinterpret_cast<const i32x4 *>(p + PB)};
+}
+template <int NT, int PB>
+__device__ __forceinline__ Frag2 colfrag2(const char *img, int trb, int pair) {
+  const char *p = img + trb + 2 * pair * kTileRowsB;
+  const bool two = 2 * pair + 1 < NT;
+  const i32x2 a0 = tr64(p), a1 = tr64(p + PB);
+  const i32x2 b0 = two ? tr64(p + kTileRowsB) : a0, b1 = two ? tr64(p + kTileRowsB + PB) : a1;
+  return Frag2{i32x4{a0[0], a0[1], b0[0], b0[1]}, i32x4{a1[0], a1[1], b1[0], b1[1]}};
+}
+// C/D tiles of a tile pair (already in the split's units, |x| < 2^16) -> the B operand of the token product
+template <int NT>
+__device__ __forceinline__ Frag2 cd_frag2h(const f32x4 (&T)[NT], int pair) {
+  int h[4] = {0, 0, 0, 0}, l[4] = {0, 0, 0, 0};
+  const f32x4 a = T[2 * pair];
+  split2h(a[0], a[1], h[0], l[0]);
+  split2h(a[2], a[3], h[1], l[1]);
+  if (2 * pair + 1 < NT) {
+    const f32x4 b = T[2 * pair + 1 < NT ? 2 * pair + 1 : 0];
+    split2h(b[0], b[1], h[2], l[2]);
+    split2h(b[2], b[3], h[3], l[3]);
+  }
+  return Frag2{i32x4{h[0], h[1], h[2], h[3]}, i32x4{l[0], l[1], l[2], l[3]}};
+}
+// softmax over the source tokens of one destination-token column on RAW scores: `sc` = log2e / sqrt(dh) / (scale of
+// Q' K'^T) is applied here, the weights leave multiplied by `mul`.  Returns m sc + log2(sum): P = exp2(S' sc - that).
+template <int NT>
+__device__ __forceinline__ float xh_column_softmax(f32x4 (&S)[NT], float sc, float mul, int L, int g) {
+  float m = kMaskedX;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (16 * t + 4 * g + q >= L) S[t][q] = kMaskedX;
+      m = fmaxf(m, S[t][q]);
+    }
+  }
+  m = groups_max(m);
+  float l = 0.f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      S[t][q] = fast_exp2((S[t][q] - m) * sc);
+      l += S[t][q];
+    }
+  }
+  l = groups_sum(l);
+  const float inv = fast_rcp(l) * mul;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) S[t][q] *= inv;
+  }
+  return fmaf(m, sc, __builtin_amdgcn_logf(l));
+}
+
+#ifndef AMPCONV_XH_FWD_MCB
+#define AMPCONV_XH_FWD_MCB 1
+#endif
+#ifndef AMPCONV_XH_DST_MCB
+#define AMPCONV_XH_DST_MCB 1
+#endif
+#ifndef AMPCONV_XH_FWD_WAVES
+#define AMPCONV_XH_FWD_WAVES 4
+#endif
+#ifndef AMPCONV_XH_DST_WAVES
+#define AMPCONV_XH_DST_WAVES 3
+#endif
+#ifndef AMPCONV_XH_SRC_WAVES
+#define AMPCONV_XH_SRC_WAVES 3
+#endif
+#ifndef AMPCONV_XH_SRC_PAIRS
+#define AMPCONV_XH_SRC_PAIRS 1
+#endif
+
+// ---------------------------------------------------------------- forward (scaled)
+template <int VEC, int NT>
+__global__ __launch_bounds__(64 * NT, AMPCONV_XH_FWD_WAVES) void fwd_xh(XArgs a) {
+  constexpr int MCB = AMPCONV_XH_FWD_MCB;
+  constexpr int PB = 16 * NT * kRowB, TB = 2 * PB, NPAIR = (NT + 1) / 2;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int64_t r, onode;
+  int h, beg, end, deg;
+  const int64_t unit = xcd_unit(blockIdx.x, a.n_units, a.H);
+  if (unit < 0 || !map_unit(a.hub, a.ptr, unit, a.n_units, a.H, r, onode, h, beg, end, deg)) return;
+  const int L = a.L, dh = a.dh, g = lane >> 4;
+  char *Kt = lds, *Vt = lds + TB;
+  const float sq = plane_scale_x(a.bounds[0]), uq = 1.f / sq;      // (powers of two: exact)
+  const float sc = (a.qscale * uq) * uq;                            // log2e / sqrt(dh) / (scale of Q' K'^T)
+
+  IdxWindow win;
+  if (beg < end) idxwin_load<false>(win, a.idx, nullptr, beg, end, lane);
+  OwnRaw qraw;
+  own_load(qraw, tile_of(a.Q, r, h), (int)a.Q.row_stride, wave, L, dh, lane);
+  f32x4 OT[4];
+#pragma unroll
+  for (int mc = 0; mc < 4; ++mc) OT[mc] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const FragAddr fa = frag_addr(lane);
+  StageOffs<VEC, NT> lo;
+  xstage_offsets<VEC, NT>(lo, tid);
+
+  StageX<VEC, NT> st;
+  const StageSrc sq_ = stage_src<VEC, NT>((int)a.K.row_stride, (int)a.V.row_stride, L, dh, tid);
+  auto fetch = [&](int p) {
+    const int64_t s = idxwin_get<false>(win, a.idx, nullptr, p, end, lane, nullptr);
+    xstage_load<VEC, NT>(st, tile_of(a.K, s, h), tile_of(a.V, s, h), sq_, L);
+  };
+  if (beg < end) fetch(beg);
+  lds_zero_tail<VEC, NT, 4>(lds, L, tid);
+  Frag2 qf[2];
+  own_split_h(qf, qraw, sq);
+  __syncthreads();
+  for (int p = beg; p < end; ++p) {
+    xstage_store_h<VEC, NT>(Kt, Vt, st, lo, sq, sq, L);
+    if (p + 1 < end) fetch(p + 1);
+    __syncthreads();
+
+    f32x4 S[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      S[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) S[t] = mfma3h(rowfrag2<PB>(Kt, fa.a[ks], t), qf[ks], S[t]);
+    }
+    xh_column_softmax<NT>(S, sc, kPScaleX, L, g);
+    Frag2 pf[NPAIR];
+#pragma unroll
+    for (int mb = 0; mb < 4 / MCB; ++mb) {
+      X3_PRE_READ();
+      Frag2 vc[MCB][NPAIR];
+#pragma unroll
+      for (int u = 0; u < MCB; ++u)
+#pragma unroll
+        for (int i = 0; i < NPAIR; ++i) vc[u][i] = colfrag2<NT, PB>(Vt, fa.tr[MCB * mb + u], i);
+      if (mb == 0) {
+#pragma unroll
+        for (int i = 0; i < NPAIR; ++i) pf[i] = cd_frag2h<NT>(S, i);      // (in the shadow of the reads)
+      }
+      X3_FRAG_FENCE();
+#pragma unroll
+      for (int u = 0; u < MCB; ++u)
+#pragma unroll
+        for (int i = 0; i < NPAIR; ++i) OT[MCB * mb + u] = mfma3h(vc[u][i], pf[i], OT[MCB * mb + u]);
+    }
+    __syncthreads();
+  }
+  store_x3<VEC>(a.O, onode, h, OT, kPUnscaleX * uq * (a.hub.mode == 2 ? 1.f : (deg > 0 ? 1.f / (float)deg : 0.f)), wave, L, dh,
+                lane);
+}
+
+// ---------------------------------------------------------------- backward, destination pass (scaled)
+template <int VEC, bool STATS, int NT>
+__global__ __launch_bounds__(64 * NT, AMPCONV_XH_DST_WAVES) void bwd_dst_xh(XArgs a) {
+  constexpr int MCB = AMPCONV_XH_DST_MCB;
+  constexpr int PB = 16 * NT * kRowB, TB = 2 * PB, NPAIR = (NT + 1) / 2;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int64_t r, onode;
+  int h, beg, end, deg;
+  const int64_t unit = xcd_unit(blockIdx.x, a.n_units, a.H);
+  if (unit < 0 || !map_unit(a.hub, a.ptr, unit, a.n_units, a.H, r, onode, h, beg, end, deg)) return;
+  const int L = a.L, dh = a.dh, g = lane >> 4;
+  char *Kt = lds, *Vt = lds + TB;
+  const float inv = deg > 0 ? 1.f / (float)deg : 0.f;       // dO is the gradient of the MEAN
+  const float sq = plane_scale_x(a.bounds[0]), uq = 1.f / sq, sg = plane_scale_x(a.bounds[1]), ug = 1.f / sg;
+  const float sc = (a.qscale * uq) * uq;
+
+  IdxWindow win;
+  const float *wts = reinterpret_cast<const float *>(a.spos);
+  if (beg < end) idxwin_load<STATS>(win, a.idx, wts, beg, end, lane);
+  OwnRaw qraw, graw;
+  own_load(qraw, tile_of(a.Q, r, h), (int)a.Q.row_stride, wave, L, dh, lane);
+  own_load(graw, tile_of(a.dO, r, h), (int)a.dO.row_stride, wave, L, dh, lane);
+  f32x4 dQT[4];
+#pragma unroll
+  for (int mc = 0; mc < 4; ++mc) dQT[mc] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const FragAddr fa = frag_addr(lane);
+  StageOffs<VEC, NT> lo;
+  xstage_offsets<VEC, NT>(lo, tid);
+
+  StageX<VEC, NT> st;
+  float pos_next = 0.f;                      // STATS: CSC position (int bits) in the window's weight slot
+  const StageSrc sq_ = stage_src<VEC, NT>((int)a.K.row_stride, (int)a.V.row_stride, L, dh, tid);
+  auto fetch = [&](int p) {
+    const int64_t s = idxwin_get<STATS>(win, a.idx, wts, p, end, lane, &pos_next);
+    xstage_load<VEC, NT>(st, tile_of(a.K, s, h), tile_of(a.V, s, h), sq_, L);
+  };
+  if (beg < end) fetch(beg);
+  lds_zero_tail<VEC, NT, 4>(lds, L, tid);
+  Frag2 qf[2], gf[2];
+  own_split_h(qf, qraw, sq);
+  own_split_h(gf, graw, inv * sg);
+  // dS = P (dP' - delta'), |dP'_ij| <= |dO'_i| |V'_j|: this wave's dO' rows, any V' row
+  const float sd = ds_scale_x(own_max_norm2(gf), a.bounds[2] * sq), usd = 1.f / sd;
+  __syncthreads();
+  constexpr int LS = 16 * NT;
+  for (int p = beg; p < end; ++p) {
+    xstage_store_h<VEC, NT>(Kt, Vt, st, lo, sq, sq, L);
+    float *sb = nullptr;
+    if (STATS) sb = a.stats + ((int64_t)__builtin_bit_cast(int, pos_next) * a.H + h) * (2 * LS);
+    if (p + 1 < end) fetch(p + 1);
+    __syncthreads();
+
+    f32x4 S[NT], dP[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      S[t] = dP[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        S[t] = mfma3h(rowfrag2<PB>(Kt, fa.a[ks], t), qf[ks], S[t]);
+        dP[t] = mfma3h(rowfrag2<PB>(Vt, fa.a[ks], t), gf[ks], dP[t]);
+      }
+    }
+    const float lse2 = xh_column_softmax<NT>(S, sc, 1.f, L, g);
+    float part = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) part = fmaf(S[t][q], dP[t][q], part);
+    }
+    const float delta = groups_sum(part);
+    if (STATS && g == 0) {                   // all LS columns: the source pass reads every one
+      sb[(lane & 15) + 16 * wave] = lse2;
+      sb[LS + (lane & 15) + 16 * wave] = delta;
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) S[t][q] *= (dP[t][q] - delta) * sd;       // dS in the split's units
+    }
+    Frag2 sf[NPAIR];
+#pragma unroll
+    for (int mb = 0; mb < 4 / MCB; ++mb) {
+      X3_PRE_READ();
+      Frag2 kc[MCB][NPAIR];
+#pragma unroll
+      for (int u = 0; u < MCB; ++u)
+#pragma unroll
+        for (int i = 0; i < NPAIR; ++i) kc[u][i] = colfrag2<NT, PB>(Kt, fa.tr[MCB * mb + u], i);
+      if (mb == 0) {
+#pragma unroll
+        for (int i = 0; i < NPAIR; ++i) sf[i] = cd_frag2h<NT>(S, i);
+      }
+      X3_FRAG_FENCE();
+#pragma unroll
+      for (int u = 0; u < MCB; ++u)
+#pragma unroll
+        for (int i = 0; i < NPAIR; ++i) dQT[MCB * mb + u] = mfma3h(kc[u][i], sf[i], dQT[MCB * mb + u]);
+    }
+    __syncthreads();
+  }
+  // partial tiles of a long row leave in the units the combine pass expects (it applies 1 / sqrt(dh))
+  const float mx = store_x3<VEC>(a.O, onode, h, dQT, (a.hub.mode == 2 ? 1.f : a.oscale) * (((uq * uq) * ug) * usd), wave, L, dh,
+                                 lane);
+  if (a.absmax) wave_record_absmax(a.absmax, mx);
+}
+
+// ---------------------------------------------------------------- backward, source pass (scaled; needs the statistics)
+template <int VEC, int NT>
+__global__ __launch_bounds__(64 * NT, AMPCONV_XH_SRC_WAVES) void bwd_src_xh(XArgs a) {
+  constexpr int PB = 16 * NT * kRowB, TB = 2 * PB, NPAIR = (NT + 1) / 2;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int64_t s, onode;
+  int h, beg, end, deg;
+  const int64_t unit = xcd_unit(blockIdx.x, a.n_units, a.H);
+  if (unit < 0 || !map_unit(a.hub, a.ptr, unit, a.n_units, a.H, s, onode, h, beg, end, deg)) return;
+  const int L = a.L, dh = a.dh, g = lane >> 4, n = lane & 15;
+  char *Qt = lds, *Gt = lds + TB;
+  const float sq = plane_scale_x(a.bounds[0]), uq = 1.f / sq, sg = plane_scale_x(a.bounds[1]), ug = 1.f / sg;
+  const float sc = (a.qscale * uq) * uq;
+
+  IdxWindow win;
+  if (beg < end) idxwin_load<true>(win, a.idx, a.cinv, beg, end, lane);
+  OwnRaw kraw, vraw;
+  own_load(kraw, tile_of(a.K, s, h), (int)a.K.row_stride, wave, L, dh, lane);
+  own_load(vraw, tile_of(a.V, s, h), (int)a.V.row_stride, wave, L, dh, lane);
+  f32x4 dKT[4], dVT[4];
+#pragma unroll
+  for (int mc = 0; mc < 4; ++mc) dKT[mc] = dVT[mc] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const FragAddr fa = frag_addr(lane);
+  StageOffs<VEC, NT> lo;
+  xstage_offsets<VEC, NT>(lo, tid);
+
+  StageX<VEC, NT> st;
+  float inv_next = 0.f;
+  constexpr int LS = 16 * NT;
+  float *sl = reinterpret_cast<float *>(lds + 2 * TB);
+  float stat_next = 0.f;
+  const StageSrc sq_ = stage_src<VEC, NT>((int)a.Q.row_stride, (int)a.dO.row_stride, L, dh, tid);
+  auto fetch = [&](int p) {
+    const int64_t d = idxwin_get<true>(win, a.idx, a.cinv, p, end, lane, &inv_next);
+    if (tid < 2 * LS) stat_next = a.stats[((int64_t)p * a.H + h) * (2 * LS) + tid];
+    xstage_load<VEC, NT>(st, tile_of(a.Q, d, h), tile_of(a.dO, d, h), sq_, L);
+  };
+  if (beg < end) fetch(beg);
+  lds_zero_tail<VEC, NT, 4>(lds, L, tid);
+  Frag2 kf[2], vf[2];
+  own_split_h(kf, kraw, sq);
+  own_split_h(vf, vraw, sq);
+  // |dP'_ij| <= |dO'_i| |V'_j|: any dO' row (its elements are bounded by the recorded maximum), this wave's V' rows
+  const float sd = ds_scale_x(own_max_norm2(vf), a.bounds[3] * sg), usd = 1.f / sd;
+  __syncthreads();
+  const bool colok = n + 16 * wave < L;      // this lane's source token exists
+  for (int p = beg; p < end; ++p) {
+    xstage_store_h<VEC, NT>(Qt, Gt, st, lo, sq, inv_next * sg, L);
+    if (tid < 2 * LS) sl[tid] = stat_next;
+    if (p + 1 < end) fetch(p + 1);
+    __syncthreads();
+
+#if AMPCONV_XH_SRC_PAIRS
+    // one pair of destination-token tiles at a time: scores, weights and their split live for one pair only (registers:
+    // three waves per SIMD), at the price of a group of transposed reads per (pair, channel tile)
+#pragma unroll
+    for (int i = 0; i < NPAIR; ++i) {
+      f32x4 P[2], dS[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int t = 2 * i + u;
+        P[u] = dS[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (t < NT) {
+          const f32x4 l4 = *reinterpret_cast<const f32x4 *>(sl + 16 * t + 4 * g);
+          const f32x4 d4 = *reinterpret_cast<const f32x4 *>(sl + LS + 16 * t + 4 * g);
+          f32x4 S = f32x4{0.f, 0.f, 0.f, 0.f}, dP = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            S = mfma3h(rowfrag2<PB>(Qt, fa.a[ks], t), kf[ks], S);
+            dP = mfma3h(rowfrag2<PB>(Gt, fa.a[ks], t), vf[ks], dP);
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float pr = colok ? fast_exp2(fmaf(S[q], sc, -l4[q])) : 0.f;
+            P[u][q] = pr * kPScaleX;
+            dS[u][q] = (pr * sd) * (dP[q] - d4[q]);
+          }
+        }
+      }
+      Frag2 pf, sf;
+#pragma unroll
+      for (int mc = 0; mc < 4; ++mc) {
+        X3_PRE_READ();
+        const Frag2 gc = colfrag2<NT, PB>(Gt, fa.tr[mc], i), qc = colfrag2<NT, PB>(Qt, fa.tr[mc], i);
+        if (mc == 0) {
+          pf = cd_frag2h<2>(P, 0);
+          sf = cd_frag2h<2>(dS, 0);
+        }
+        X3_FRAG_FENCE();
+        dVT[mc] = mfma3h(gc, pf, dVT[mc]);
+        dKT[mc] = mfma3h(qc, sf, dKT[mc]);
+      }
+    }
+#else
+    f32x4 P[NT], dS[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {             // destination tokens 16 t + 4 g + q
+      const f32x4 l4 = *reinterpret_cast<const f32x4 *>(sl + 16 * t + 4 * g);
+      const f32x4 d4 = *reinterpret_cast<const f32x4 *>(sl + LS + 16 * t + 4 * g);
+      f32x4 S = f32x4{0.f, 0.f, 0.f, 0.f}, dP = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        S = mfma3h(rowfrag2<PB>(Qt, fa.a[ks], t), kf[ks], S);
+        dP = mfma3h(rowfrag2<PB>(Gt, fa.a[ks], t), vf[ks], dP);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float pr = colok ? fast_exp2(fmaf(S[q], sc, -l4[q])) : 0.f;
+        P[t][q] = pr * kPScaleX;
+        dS[t][q] = (pr * sd) * (dP[q] - d4[q]);
+      }
+    }
+    Frag2 pf[NPAIR], sf[NPAIR];
+#pragma unroll
+    for (int mc = 0; mc < 4; ++mc) {
+      X3_PRE_READ();
+      Frag2 gc[NPAIR], qc[NPAIR];
+#pragma unroll
+      for (int i = 0; i < NPAIR; ++i) {
+        gc[i] = colfrag2<NT, PB>(Gt, fa.tr[mc], i);
+        qc[i] = colfrag2<NT, PB>(Qt, fa.tr[mc], i);
+      }
+      if (mc == 0) {
+#pragma unroll
+        for (int i = 0; i < NPAIR; ++i) {
+          pf[i] = cd_frag2h<NT>(P, i);
+          sf[i] = cd_frag2h<NT>(dS, i);
+        }
+      }
+      X3_FRAG_FENCE();
+#pragma unroll
+      for (int i = 0; i < NPAIR; ++i) {
+        dVT[mc] = mfma3h(gc[i], pf[i], dVT[mc]);
+        dKT[mc] = mfma3h(qc[i], sf[i], dKT[mc]);
+      }
+    }
+#endif
+    __syncthreads();
+  }
+  float mx = store_x3<VEC>(a.dK, onode, h, dKT, (a.hub.mode == 2 ? 1.f : a.oscale) * (((uq * uq) * ug) * usd), wave, L, dh, lane);
+  mx = fmaxf(mx, store_x3<VEC>(a.dV, onode, h, dVT, kPUnscaleX * ug, wave, L, dh, lane));
+  if (a.absmax) wave_record_absmax(a.absmax, mx);
+}
+
 typedef void (*X3Kernel)(XArgs);
 template <template <int, int> class F>
 X3Kernel x3_pick(int vec, int ntok) {
@@ -677,12 +1202,16 @@ template <int VEC, int NT> struct XFwd { static X3Kernel get() { return fwd_x3<V
 template <int VEC, int NT> struct XDstS { static X3Kernel get() { return bwd_dst_x3<VEC, true, NT>; } };
 template <int VEC, int NT> struct XDst { static X3Kernel get() { return bwd_dst_x3<VEC, false, NT>; } };
 template <int VEC, int NT> struct XSrc { static X3Kernel get() { return bwd_src_x3<VEC, NT>; } };
+template <int VEC, int NT> struct HFwd { static X3Kernel get() { return fwd_xh<VEC, NT>; } };
+template <int VEC, int NT> struct HDstS { static X3Kernel get() { return bwd_dst_xh<VEC, true, NT>; } };
+template <int VEC, int NT> struct HDst { static X3Kernel get() { return bwd_dst_xh<VEC, false, NT>; } };
+template <int VEC, int NT> struct HSrc { static X3Kernel get() { return bwd_src_xh<VEC, NT>; } };
 
-int launch_x3(const XArgs &a, int ntok, X3Kernel k, hipStream_t stream, int extra_bytes = 0) {
+int launch_x3(const XArgs &a, int ntok, X3Kernel k, hipStream_t stream, int extra_bytes = 0, int planes = 3) {
   const int64_t nb = xcd_grid(a.n_units, a.H);
   if (nb > INT32_MAX) return AMPCONV_E_BADARG;
   const dim3 grid((unsigned)nb), block(64 * ntok);
-  const size_t shmem = (size_t)2 * 3 * 16 * ntok * kRowB + extra_bytes;
+  const size_t shmem = (size_t)2 * planes * 16 * ntok * kRowB + extra_bytes;
   hipLaunchKernelGGL(k, grid, block, shmem, stream, a);
   return ampconv_launch_status();
 }
@@ -742,4 +1271,131 @@ int ampconv_bwd_edge_src_block_x3(ampconv_view_t Q, ampconv_view_t K, ampconv_vi
   a.oscale = 0.6931471805599453f;       // dK = ln2 * sum dS^T (Q * log2e / sqrt(dh))
   const int ntok = (L + 15) / 16;
   return launch_x3(a, ntok, x3_pick<XSrc>(vec, ntok), stream, 2 * 16 * ntok * (int)sizeof(float));
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// C-ABI of the scaled kernels (include/ampconv.h, "edge phase on fp32 views with operand bounds")
+namespace {
+// views of two-float vectors at least: rows, heads and nodes an even number of elements apart, 8-byte aligned base
+int x3_vec(const ampconv_view_t *views, int n, int dh) {
+  int vec = dh % 4 == 0 ? 4 : 2;
+  for (int i = 0; i < n; ++i) {
+    const ampconv_view_t &v = views[i];
+    if (!v.ptr) return 0;
+    while (vec > 1 && (((uintptr_t)v.ptr % (4 * vec)) || v.node_stride % vec || v.row_stride % vec || v.head_stride % vec))
+      vec >>= 1;
+  }
+  return vec;
+}
+ampconv_view_t x3_partial_view(void *ws, int64_t tile, int64_t n_chunks, int L, int D, int H) {
+  return ampconv_view_t{(float *)ws + tile * n_chunks * L * D, (int64_t)L * D, (int64_t)D, (int64_t)(D / H)};
+}
+int x3_check(int64_t n, int L, int D, int H, const float *bounds) {
+  if (L <= 0 || D <= 0 || H <= 0 || D % H != 0 || n < 0 || !bounds) return AMPCONV_E_BADARG;
+  if (!ampconv_scaled_supported(L, D, H)) return AMPCONV_E_DTYPE;
+  return AMPCONV_OK;
+}
+}  // namespace
+
+extern "C" int ampconv_scaled_supported(int L, int D, int H) {
+  if (L < 1 || D < 1 || H < 1 || D % H != 0) return 0;
+  const int dh = D / H;
+  return L <= 64 && dh > 32 && dh <= 64 && dh % 2 == 0;
+}
+
+extern "C" int ampconv_fwd_edge_scaled(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V, const int32_t *rowptr,
+                                       const int32_t *col, int64_t n_rows, int L, int D, int H, ampconv_view_t O,
+                                       const void *hub_plan, int64_t hub_chunks, void *hub_ws, const float *bounds,
+                                       void *stream) {
+  if (int rc = x3_check(n_rows, L, D, H, bounds)) return rc;
+  if (n_rows == 0) return AMPCONV_OK;
+  const ampconv_view_t views[] = {Q, K, V, O};
+  const int vec = x3_vec(views, 4, D / H), ntok = (L + 15) / 16;
+  if (vec < 2 || !rowptr) return AMPCONV_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  XArgs a = x3_args(n_rows, L, D, H);
+  a.Q = Q; a.K = K; a.V = V; a.O = O;
+  a.ptr = rowptr; a.idx = col; a.bounds = bounds;
+  if (hub_plan && hub_chunks > 0 && hub_ws) {          // long segments: main + hub + combine
+    a.hub = HubArgs{(const int32_t *)hub_plan, 1};
+    if (int rc = launch_x3(a, ntok, x3_pick<HFwd>(vec, ntok), st, 0, 2)) return rc;
+    const ampconv_view_t P = x3_partial_view(hub_ws, 0, hub_chunks, L, D, H);
+    a.O = P;
+    a.hub.mode = 2;
+    a.n_units = hub_chunks * H;
+    const ampconv_view_t pviews[] = {Q, K, V, P};
+    const int pvec = x3_vec(pviews, 4, D / H);
+    if (int rc = launch_x3(a, ntok, x3_pick<HFwd>(pvec, ntok), st, 0, 2)) return rc;
+    return ampconv_hub_combine(hub_plan, hub_chunks, (const float *)P.ptr, O, rowptr, L, D, H, 1.f, 0, st);
+  }
+  return launch_x3(a, ntok, x3_pick<HFwd>(vec, ntok), st, 0, 2);
+}
+
+extern "C" int ampconv_bwd_edge_dst_scaled(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V, ampconv_view_t dObar,
+                                           const int32_t *rowptr, const int32_t *col, int64_t n_rows, int L, int D, int H,
+                                           ampconv_view_t dQ, const void *hub_plan, int64_t hub_chunks, void *hub_ws,
+                                           const float *bounds, const int32_t *spos, float *stats, float *out_absmax,
+                                           void *stream) {
+  if (int rc = x3_check(n_rows, L, D, H, bounds)) return rc;
+  if (stats && (!spos || (uintptr_t)stats % 16 != 0)) return AMPCONV_E_BADARG;
+  if (n_rows == 0) return AMPCONV_OK;
+  const ampconv_view_t views[] = {Q, K, V, dObar, dQ};
+  const int vec = x3_vec(views, 5, D / H), ntok = (L + 15) / 16;
+  if (vec < 2 || !rowptr) return AMPCONV_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  XArgs a = x3_args(n_rows, L, D, H);
+  a.Q = Q; a.K = K; a.V = V; a.dO = dObar; a.O = dQ;
+  a.ptr = rowptr; a.idx = col; a.bounds = bounds; a.absmax = out_absmax;
+  a.spos = spos; a.stats = stats;
+  a.oscale = 1.f / sqrtf((float)a.dh);
+  auto pick = [&](int v) { return stats ? x3_pick<HDstS>(v, ntok) : x3_pick<HDst>(v, ntok); };
+  if (hub_plan && hub_chunks > 0 && hub_ws) {
+    a.hub = HubArgs{(const int32_t *)hub_plan, 1};
+    if (int rc = launch_x3(a, ntok, pick(vec), st, 0, 2)) return rc;
+    const ampconv_view_t P = x3_partial_view(hub_ws, 0, hub_chunks, L, D, H);
+    a.O = P;
+    a.absmax = nullptr;                                // partial tiles: the combine pass records what it writes
+    a.hub.mode = 2;
+    a.n_units = hub_chunks * H;
+    const ampconv_view_t pviews[] = {Q, K, V, dObar, P};
+    if (int rc = launch_x3(a, ntok, pick(x3_vec(pviews, 5, D / H)), st, 0, 2)) return rc;
+    return ampconv_hub_combine(hub_plan, hub_chunks, (const float *)P.ptr, dQ, nullptr, L, D, H, a.oscale, 0, st, out_absmax);
+  }
+  return launch_x3(a, ntok, pick(vec), st, 0, 2);
+}
+
+extern "C" int ampconv_bwd_edge_src_scaled(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V, ampconv_view_t dObar,
+                                           const int32_t *cscptr, const int32_t *crow, const float *cinv, int64_t n_src,
+                                           int L, int D, int H, ampconv_view_t dK, ampconv_view_t dV, const void *hub_plan,
+                                           int64_t hub_chunks, void *hub_ws, const float *bounds, const float *stats,
+                                           float *out_absmax, void *stream) {
+  if (int rc = x3_check(n_src, L, D, H, bounds)) return rc;
+  if (!stats || (uintptr_t)stats % 16 != 0 || !cinv) return AMPCONV_E_BADARG;      // this pass exists only with the hand-off
+  if (n_src == 0) return AMPCONV_OK;
+  const ampconv_view_t views[] = {Q, K, V, dObar, dK, dV};
+  const int vec = x3_vec(views, 6, D / H), ntok = (L + 15) / 16;
+  if (vec < 2 || !cscptr) return AMPCONV_E_BADARG;
+  hipStream_t st = (hipStream_t)stream;
+  XArgs a = x3_args(n_src, L, D, H);
+  a.Q = Q; a.K = K; a.V = V; a.dO = dObar; a.dK = dK; a.dV = dV;
+  a.ptr = cscptr; a.idx = crow; a.cinv = cinv; a.bounds = bounds; a.absmax = out_absmax;
+  a.stats = const_cast<float *>(stats);
+  a.oscale = 1.f / sqrtf((float)a.dh);
+  const int extra = 2 * 16 * ntok * (int)sizeof(float);
+  if (hub_plan && hub_chunks > 0 && hub_ws) {
+    a.hub = HubArgs{(const int32_t *)hub_plan, 1};
+    if (int rc = launch_x3(a, ntok, x3_pick<HSrc>(vec, ntok), st, extra, 2)) return rc;
+    const ampconv_view_t PK = x3_partial_view(hub_ws, 0, hub_chunks, L, D, H), PV = x3_partial_view(hub_ws, 1, hub_chunks, L, D, H);
+    a.dK = PK;
+    a.dV = PV;
+    a.absmax = nullptr;
+    a.hub.mode = 2;
+    a.n_units = hub_chunks * H;
+    const ampconv_view_t pviews[] = {Q, K, V, dObar, PK, PV};
+    if (int rc = launch_x3(a, ntok, x3_pick<HSrc>(x3_vec(pviews, 6, D / H), ntok), st, extra, 2)) return rc;
+    if (int rc = ampconv_hub_combine(hub_plan, hub_chunks, (const float *)PK.ptr, dK, nullptr, L, D, H, a.oscale, 0, st, out_absmax))
+      return rc;
+    return ampconv_hub_combine(hub_plan, hub_chunks, (const float *)PV.ptr, dV, nullptr, L, D, H, 1.f, 0, st, out_absmax);
+  }
+  return launch_x3(a, ntok, x3_pick<HSrc>(vec, ntok), st, extra, 2);
 }

@@ -77,8 +77,9 @@ class KernelTimer:
         self.enabled = False
 
     def wrap(self, lib, name, key=None):
-        """Events around C entry point `name`, filed under `key` (the plane-format edge passes of ABI 106 are filed under
-        the name of the fp32 entry point whose work they do; `entry_points` keeps what really ran)."""
+        """Events around C entry point `name`, filed under `key` (the plane-format edge passes of ABI 106 and the
+        bound-carrying fp32-view passes of ABI 107 are filed under the name of the fp32 entry point whose work they do;
+        `entry_points` keeps what really ran)."""
         fn = getattr(lib, name)
         key = key or name
 
@@ -105,6 +106,7 @@ class TimedLib:
         for n in ('ampconv_fwd_edge', 'ampconv_bwd_edge_dst', 'ampconv_bwd_edge_src'):
             setattr(self, n, timer.wrap(lib, n))
             setattr(self, n + '_planes', timer.wrap(lib, n + '_planes', key=n))
+            setattr(self, n + '_scaled', timer.wrap(lib, n + '_scaled', key=n))
 
     def __getattr__(self, name):
         return getattr(self._lib, name)
@@ -555,7 +557,7 @@ def measure_full(workload, steps, warmup, args, rank, world, dev, dist_on, dt_na
     if lists:      # in-projection + its two gradients over the nodes with any edge, out-projection + its two over the receivers
         flops_proj = L * D * D * (18 * lists['any'] + 6 * lists['in'])
     mfma_peak = MFMA_PEAK_TFLOPS[dt_name]
-    planes_ran = any(n.endswith('_planes') for n in timer.entry_points)
+    planes_ran = any(n.endswith(('_planes', '_scaled')) for n in timer.entry_points)
     # the arithmetic peak of the dominant EDGE kernel: fp32-input MFMA = the vector rate; the plane-format passes issue
     # three 16-bit matrix products per fp32 product
     edge_peak = MFMA_PEAK_TFLOPS['bf16'] / 3 if planes_ran else mfma_peak

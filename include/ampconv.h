@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define AMPCONV_VERSION 106
+#define AMPCONV_VERSION 107
 
 enum {
   AMPCONV_OK = 0,
@@ -215,6 +215,37 @@ int ampconv_bwd_edge_src_planes(ampconv_view_t Q, ampconv_view_t K, ampconv_view
                                 ampconv_view_t dV, const void *hub_plan, int64_t hub_chunks,
                                 void *hub_ws, const float *bounds, const float *stats,
                                 float *out_absmax, void *stream);
+
+/* ---- edge phase on fp32 VIEWS with operand bounds: the workgroup-per-unit shapes off the FP32 pipe (csrc/edge_block_x3.hip,
+ * ABI 107) ----------------------------------------------------------------------------------------------------------
+ * The same three passes for L <= 64, even 32 < dh <= 64 (the reference's AMPGCN class defaults L = 40, D = 100, H = 2:
+ * src/ampnet/module/amp_gcn.py:21-35) on plain fp32 views -- what ampconv_fwd_edge / _bwd_edge_dst / _bwd_edge_src take --
+ * plus the `bounds` of the plane-format entry points above: bounds[0] >= max |Q|K|V|, bounds[1] >= max |dObar|,
+ * bounds[2] >= max |V|, bounds[3] >= max |dObar| (device, 4 floats; the forward pass reads bounds[0] only).  With them
+ * the kernels split every fp32 tile, on its way into LDS, into TWO fp16 planes of x * 2^(14 - floor(log2 bound)) and
+ * run each product as three v_mfma_f32_16x16x32_f16 partial products (half the matrix-pipe cycles and two thirds of
+ * the vector instructions of the bound-free kernels behind the fp32 entry points, which split into three bf16 planes).
+ * dObar is the gradient of the mean as in the fp32 entry points (the passes apply 1 / in-degree; `cinv` as in
+ * ampconv_bwd_edge_src).  Softmax statistics: ampconv_softmax_stats_bytes(E, L, D, H, AMPCONV_F32) bytes, REQUIRED by
+ * the source pass, delta in the units of the scaled dObar V^T product.  out_absmax as above.  Same accuracy class as the
+ * fp32 kernels on tensors whose rows lie within ~2^12 of the tensor's maximum (see ampconv_planes_supported).  */
+int ampconv_scaled_supported(int L, int D, int H);
+int ampconv_fwd_edge_scaled(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
+                            const int32_t *rowptr, const int32_t *col, int64_t n_rows, int L, int D,
+                            int H, ampconv_view_t O, const void *hub_plan, int64_t hub_chunks,
+                            void *hub_ws, const float *bounds, void *stream);
+int ampconv_bwd_edge_dst_scaled(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
+                                ampconv_view_t dObar, const int32_t *rowptr, const int32_t *col,
+                                int64_t n_rows, int L, int D, int H, ampconv_view_t dQ,
+                                const void *hub_plan, int64_t hub_chunks, void *hub_ws,
+                                const float *bounds, const int32_t *spos, float *stats,
+                                float *out_absmax, void *stream);
+int ampconv_bwd_edge_src_scaled(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
+                                ampconv_view_t dObar, const int32_t *cscptr, const int32_t *crow,
+                                const float *cinv, int64_t n_src, int L, int D, int H,
+                                ampconv_view_t dK, ampconv_view_t dV, const void *hub_plan,
+                                int64_t hub_chunks, void *hub_ws, const float *bounds,
+                                const float *stats, float *out_absmax, void *stream);
 
 /* ---- per-edge side outputs, ORIGINAL edge order ------------------------------
  * attn_weights: W[e] = mean_h softmax_rows(Q[dst e,:,h] K[src e,:,h]^T/sqrt(dh)),

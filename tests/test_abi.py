@@ -182,6 +182,13 @@ def test_register_budgets_of_the_kernels_that_must_not_spill():
         assert len(ks) == variants, (name, ks)           # {2, 4 floats per lane} x {1..4 token tiles} (x {statistics})
         for k in ks:
             assert usage[k]['spill'] == 0 and usage[k]['vgprs'] <= budget, (k, usage[k])
+    # ... and their two-plane fp16 siblings behind the bound-carrying entry points (ampconv_*_edge_scaled): forward at four
+    # waves per SIMD, both backward passes at three
+    for name, budget, variants in (('fwd_xh', 128, 8), ('bwd_dst_xh', 168, 16), ('bwd_src_xh', 168, 8)):
+        ks = [k for k in usage if name in k]
+        assert len(ks) == variants, (name, ks)
+        for k in ks:
+            assert usage[k]['spill'] == 0 and usage[k]['vgprs'] <= budget, (k, usage[k])
     hot = [k for k in usage if ('bwd_src_mfma_t4ILi32ELb1ELb1E' in k or 'bwd_dst_mfma_t4ILi32ELb1ELb1ELb1E' in k
                                 or 'fwd_mfma_t4ILi32ELb1ELb1E' in k)]
     assert len(hot) == 3, hot

@@ -1,0 +1,173 @@
+"""GPU parity of the workgroup-per-unit edge kernels off the FP32 pipe (csrc/edge_block_x3.hip): 32 < dh <= 64, L <= 64,
+fp32 storage -- the reference's AMPGCN class defaults L = 40, D = 100, H = 2 (src/ampnet/module/amp_gcn.py:21-35).
+Two arithmetic variants behind two sets of entry points:
+  * ampconv_fwd_edge / _bwd_edge_dst / _bwd_edge_src (no bounds): three bf16 planes, six partial products;
+  * ampconv_*_edge_scaled (operand bounds; what a layer call takes in the scaled mode): two fp16 planes of the
+    power-of-two-scaled value, three partial products.
+What they replace in the reference is what every edge kernel replaces (amp_conv.py:39 -> torch functional.py:6578-6594
+and its autograd backward), so the checker is the fp64 oracle at the FLAT fp32 tolerance."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_close_scaled
+from test_gpu_planes import _Calls, _make, _oracle, _run, NAMES, F32_CALLS
+
+pytestmark = pytest.mark.gpu
+
+SCALED_CALLS = ('ampconv_fwd_edge_scaled', 'ampconv_bwd_edge_dst_scaled', 'ampconv_bwd_edge_src_scaled')
+
+
+@pytest.fixture(scope='module')
+def dev():
+    assert torch.cuda.is_available()
+    from ampnet_amd import _lib
+    _lib.load()
+    return torch.device('cuda:0')
+
+
+SHAPES = [(500, 5000, 40, 100, 2), (400, 4000, 24, 128, 2), (300, 2500, 64, 128, 2), (400, 3000, 33, 72, 2),
+          (300, 2500, 7, 100, 2), (300, 2500, 16, 68, 2)]
+IDS = ['class_default_L40_dh50', 'L24_dh64', 'L64_dh64', 'L33_dh36', 'L7_dh50', 'L16_dh34']
+
+
+@pytest.mark.parametrize('shape', SHAPES, ids=IDS)
+@pytest.mark.parametrize('scaled', [True, False], ids=['fp16x2_scaled', 'bf16x3'])
+def test_block_path_vs_fp64_oracle(shape, scaled, dev, monkeypatch):
+    """The whole layer (long segments in both directions, isolated nodes) against the fp64 oracle, once through the
+    bound-carrying entry points (the scaled mode forced onto a small graph), once through the plain fp32 ones."""
+    from ampnet_amd.conv import functional as F_
+    monkeypatch.setattr(F_, 'PROJ_SCALED_MIN_ELEMENTS', 0 if scaled else 1 << 62)
+    N, E, L, D, H = shape
+    layer, x, dy, ei = _make(N, E, L, D, H, dev)
+    calls = _Calls(monkeypatch, SCALED_CALLS + F32_CALLS)
+    got = _run(layer, x, dy, ei, dev)
+    ran, idle = (SCALED_CALLS, F32_CALLS) if scaled else (F32_CALLS, SCALED_CALLS)
+    assert all(calls.n[k] == 1 for k in ran) and all(calls.n[k] == 0 for k in idle), calls.n
+    want = _oracle(layer, x, dy, ei, H)
+    for name, a, b in zip(NAMES, got, want):
+        assert_close_scaled(a, b, name)
+    assert (got[0][N - 20:] == 0).all(), 'rows with no in-edge must be exactly 0'
+
+
+def test_block_path_error_table_vs_fp64(dev, monkeypatch):
+    """max error / max entry against fp64 at the class-default shape: both 16-bit variants next to the fp32-MFMA kernels
+    they replace (AMPCONV_BLOCK_X3=0 is read once per process, so those run through the generic switch's sibling: the
+    numbers of the fp32 kernels are in DESIGN.md 4d); both must stay under the bar the fp32 path is held to (5e-6)."""
+    from ampnet_amd.conv import functional as F_
+    N, E, L, D, H = 800, 8000, 40, 100, 2
+    layer, x, dy, ei = _make(N, E, L, D, H, dev, seed=31, x_scale=2.0, hub=False)
+    want = _oracle(layer, x, dy, ei, H)
+    rows = {}
+    for scaled in (True, False):
+        monkeypatch.setattr(F_, 'PROJ_SCALED_MIN_ELEMENTS', 0 if scaled else 1 << 62)
+        got = _run(layer, x, dy, ei, dev)
+        rows[scaled] = [float(np.abs(a - b).max() / np.abs(b).max()) for a, b in zip(got, want)]
+    for i, name in enumerate(NAMES):
+        print(f'[err] {name}: fp16x2 scaled {rows[True][i]:.2e}   bf16x3 {rows[False][i]:.2e}')
+    assert max(rows[True][:2]) < 5e-6 and max(rows[False][:2]) < 5e-6, rows
+
+
+def test_block_scaled_large_scores(dev, monkeypatch):
+    """Saturated softmaxes: the scores meet their scale only inside the exponential, the masks are -inf."""
+    from ampnet_amd.conv import functional as F_
+    monkeypatch.setattr(F_, 'PROJ_SCALED_MIN_ELEMENTS', 0)
+    N, E, L, D, H = 300, 3000, 40, 100, 2
+    layer, x, dy, ei = _make(N, E, L, D, H, dev, seed=5, x_scale=12.0)
+    want = _oracle(layer, x, dy, ei, H)
+    got = _run(layer, x, dy, ei, dev)
+    assert np.isfinite(got[0]).all() and np.isfinite(got[1]).all()
+    for name, a, b in zip(NAMES, got, want):
+        assert_close_scaled(a, b, name, atol=3e-5, rtol=3e-4, scaled=True)     # (the bar of the fp32 kernels' large-score test)
+
+
+def test_block_scaled_is_reproducible_and_records_the_maximum(dev, monkeypatch):
+    """Bitwise the same twice (no atomics in the data path), and the backward passes' recorded maximum of dQ | dK | dV is
+    the true one (it scales the products that consume dQKV)."""
+    from ampnet_amd import _lib, EdgeCSR
+    from ampnet_amd.conv import functional as F_
+    lib = _lib.load()
+    N, E, L, D, H = 300, 3000, 40, 100, 2
+    dh = D // H
+    g = torch.Generator(device='cpu').manual_seed(9)
+    qkv = torch.randn(N * L, 3 * D, generator=g).to(dev)
+    dobar = torch.randn(N * L, D, generator=g).to(dev)
+    ei = torch.randint(0, N, (2, E), generator=g)
+    ei[1, :400] = 3
+    ei[0, 400:800] = 5
+    csr = EdgeCSR(ei.to(dev), N)
+    Qv, Kv, Vv = (F_._view(qkv, i * D, L, dh) for i in range(3))
+    dOv = F_._view(dobar, 0, L, dh)
+    mq, mg = float(qkv.abs().max()), float(dobar.abs().max())
+    bounds = torch.tensor([mq, mg, mq, mg], device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    nstat = lib.ampconv_softmax_stats_bytes(E, L, D, H, _lib.AMPCONV_F32)
+    spos = csr.csc_positions()
+
+    def run():
+        obar = torch.empty(N * L, D, device=dev)
+        dqkv = torch.empty(N * L, 3 * D, device=dev)
+        stats = torch.empty(nstat // 4, device=dev)
+        rec = torch.zeros(1, device=dev)
+        dQv, dKv, dVv = (F_._view(dqkv, i * D, L, dh) for i in range(3))
+        plan, nch, ws = csr.hub_args('dst', L, D, 1)
+        _lib.check(lib.ampconv_fwd_edge_scaled(Qv, Kv, Vv, csr.rowptr.data_ptr(), csr.col.data_ptr(), N, L, D, H,
+                                               F_._view(obar, 0, L, dh), plan, nch, F_._ptr(ws), bounds.data_ptr(), st), 'fwd')
+        _lib.check(lib.ampconv_bwd_edge_dst_scaled(Qv, Kv, Vv, dOv, csr.rowptr.data_ptr(), csr.col.data_ptr(), N, L, D, H, dQv,
+                                                   plan, nch, F_._ptr(ws), bounds.data_ptr(), spos.data_ptr(),
+                                                   stats.data_ptr(), rec.data_ptr(), st), 'dst')
+        plan, nch, ws = csr.hub_args('src', L, D, 2)
+        _lib.check(lib.ampconv_bwd_edge_src_scaled(Qv, Kv, Vv, dOv, csr.cscptr.data_ptr(), csr.crow.data_ptr(),
+                                                   csr.cinv.data_ptr(), N, L, D, H, dKv, dVv, plan, nch, F_._ptr(ws),
+                                                   bounds.data_ptr(), stats.data_ptr(), rec.data_ptr(), st), 'src')
+        torch.cuda.synchronize()
+        return obar, dqkv, rec
+    a, b = run(), run()
+    assert csr.hub_dst_chunks > 0 and csr.hub_src_chunks > 0
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert float(a[2]) == float(a[1].abs().max())
+    # ... and they agree with the bound-free kernels on the same tensors
+    obar = torch.empty(N * L, D, device=dev)
+    plan, nch, ws = csr.hub_args('dst', L, D, 1)
+    _lib.check(lib.ampconv_fwd_edge(Qv, Kv, Vv, csr.rowptr.data_ptr(), csr.col.data_ptr(), None, N, L, D, H,
+                                    F_._view(obar, 0, L, dh), plan, nch, F_._ptr(ws), _lib.AMPCONV_F32, st), 'fwd32')
+    assert_close_scaled(a[0].cpu().numpy(), obar.cpu().numpy(), 'Obar (scaled vs bf16x3 kernels)')
+
+
+def test_block_scaled_entry_points_reject_what_they_do_not_serve(dev):
+    from ampnet_amd import _lib
+    lib = _lib.load()
+    assert lib.ampconv_scaled_supported(40, 100, 2) == 1 and lib.ampconv_scaled_supported(64, 128, 2) == 1
+    assert lib.ampconv_scaled_supported(20, 256, 8) == 0       # dh = 32: the plane-format kernels' shape
+    assert lib.ampconv_scaled_supported(65, 100, 2) == 0 and lib.ampconv_scaled_supported(40, 102, 2) == 0     # L > 64, odd dh
+    x = torch.zeros(40 * 300, device=dev)
+    v = _lib.View(x.data_ptr(), 40 * 100, 100, 50)
+    rp = torch.zeros(2, dtype=torch.int32, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    rc = lib.ampconv_fwd_edge_scaled(v, v, v, rp.data_ptr(), rp.data_ptr(), 1, 40, 100, 2, v, None, 0, None, None, st)
+    assert rc == -1                                     # no bounds
+    b = torch.ones(4, device=dev)
+    rc = lib.ampconv_fwd_edge_scaled(v, v, v, rp.data_ptr(), rp.data_ptr(), 1, 20, 256, 8, v, None, 0, None, b.data_ptr(), st)
+    assert rc == -2                                      # a shape of another kernel family
+    rc = lib.ampconv_bwd_edge_src_scaled(v, v, v, v, rp.data_ptr(), rp.data_ptr(), x.data_ptr(), 1, 40, 100, 2, v, v, None, 0,
+                                         None, b.data_ptr(), None, None, st)
+    assert rc == -1                                     # the source pass needs the statistics
+
+
+def test_wide_operands_leave_the_scaled_block_path(dev, monkeypatch):
+    """One row of x at 1e8: operand_stats reports a wide operand, the call takes the bound-free kernels and the exact
+    projections, and the other rows keep their fp32-grade relative error."""
+    from ampnet_amd.conv import functional as F_
+    monkeypatch.setattr(F_, 'PROJ_SCALED_MIN_ELEMENTS', 0)
+    N, E, L, D, H = 300, 2500, 40, 100, 2
+    layer, x, dy, ei = _make(N, E, L, D, H, dev, seed=11, hub=False)
+    x[5] *= 1e8
+    ei[:, (ei[0] == 5) | (ei[1] == 5)] = 6              # (the huge row talks to nobody: the other rows' outputs stay O(1))
+    calls = _Calls(monkeypatch, SCALED_CALLS + F32_CALLS)
+    got = _run(layer, x, dy, ei, dev)
+    assert all(calls.n[k] == 0 for k in SCALED_CALLS) and all(calls.n[k] == 1 for k in F32_CALLS), calls.n
+    want = _oracle(layer, x, dy, ei, H)
+    keep = np.ones(N, dtype=bool)
+    keep[5] = False
+    err = np.abs(got[0][keep] - want[0][keep]).max() / np.abs(want[0][keep]).max()
+    assert err < 2e-6, err
