@@ -476,6 +476,9 @@ __global__ __launch_bounds__(64 * NT, AMPCONV_X3_FWD_WAVES) void fwd_x3(XArgs a)
 #ifndef AMPCONV_X3_SRC_WAVES
 #define AMPCONV_X3_SRC_WAVES 2
 #endif
+#ifndef AMPCONV_X3_SRC_PAIRS
+#define AMPCONV_X3_SRC_PAIRS 0
+#endif
 template <int VEC, bool STATS, int NT>
 __global__ __launch_bounds__(64 * NT, AMPCONV_X3_DST_WAVES) void bwd_dst_x3(XArgs a) {
   constexpr int MCB = AMPCONV_X3_DST_MCB;
@@ -628,6 +631,47 @@ __global__ __launch_bounds__(64 * NT, AMPCONV_X3_SRC_WAVES) void bwd_src_x3(XArg
     if (p + 1 < end) fetch(p + 1);
     __syncthreads();
 
+#if AMPCONV_X3_SRC_PAIRS
+    // one pair of destination-token tiles at a time (registers; see bwd_src_xh)
+#pragma unroll
+    for (int i = 0; i < NPAIR; ++i) {
+      f32x4 P[2], dS[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int t = 2 * i + u;
+        P[u] = dS[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (t < NT) {
+          const f32x4 l4 = *reinterpret_cast<const f32x4 *>(sl + 16 * t + 4 * g);
+          const f32x4 d4 = *reinterpret_cast<const f32x4 *>(sl + LS + 16 * t + 4 * g);
+          f32x4 S = f32x4{0.f, 0.f, 0.f, 0.f}, dP = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            S = mfma6(rowfrag3<PB>(Qt, fa.a[ks], t), kf[ks], S);
+            dP = mfma6(rowfrag3<PB>(Gt, fa.a[ks], t), vf[ks], dP);
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float pr = colok ? fast_exp2(S[q] - l4[q]) : 0.f;
+            P[u][q] = pr;
+            dS[u][q] = pr * (dP[q] - d4[q]);
+          }
+        }
+      }
+      Frag3 pf, sf;
+#pragma unroll
+      for (int mc = 0; mc < 4; ++mc) {
+        X3_PRE_READ();
+        const Frag3 gc = colfrag3<NT, PB>(Gt, fa.tr[mc], i), qc = colfrag3<NT, PB>(Qt, fa.tr[mc], i);
+        if (mc == 0) {
+          pf = cd_frag3<2>(P, 0);
+          sf = cd_frag3<2>(dS, 0);
+        }
+        X3_FRAG_FENCE();
+        dVT[mc] = mfma6(gc, pf, dVT[mc]);
+        dKT[mc] = mfma6(qc, sf, dKT[mc]);
+      }
+    }
+#else
     f32x4 P[NT], dS[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {             // destination tokens 16 t + 4 g + q
@@ -670,6 +714,7 @@ __global__ __launch_bounds__(64 * NT, AMPCONV_X3_SRC_WAVES) void bwd_src_x3(XArg
         dKT[mc] = mfma6(qc[i], sf[i], dKT[mc]);
       }
     }
+#endif
     __syncthreads();
   }
   store_x3<VEC>(a.dK, onode, h, dKT, a.hub.mode == 2 ? 1.f : a.oscale, wave, L, dh, lane);

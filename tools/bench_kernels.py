@@ -1,6 +1,6 @@
 """Developer micro-benchmark: time each C-ABI edge kernel on a synthetic uniform graph.
 
-    python tools/bench_kernels.py [N E L D H] [--generic] [--bf16] [--hub] [--rmat] [--compact] [--absmax] [--planes]
+    python tools/bench_kernels.py [N E L D H] [--generic] [--bf16] [--hub] [--rmat] [--compact] [--absmax] [--planes] [--scaled]
 
 --planes: the plane-format passes of ABI 106 (csrc/edge_mfma_f16x2.hip) on the same random tensors, converted to two
 fp16 planes here (bounds 12 x the maxima, about what the a-priori bound of the projection gives).
@@ -154,6 +154,24 @@ def main():
             _lib.check(lib.ampconv_bwd_edge_src_planes(pQ, pK, pV, pG, csr.cscptr.data_ptr(), csr.crow.data_ptr(), N, L, D,
                                                        H, dKv, dVv, *hub('src', 2), bounds.data_ptr(), sp[1], amax, st), 'bwd_src')
         print('plane-format passes (fp16 planes, 16-bit matrix pipe)')
+
+    if '--scaled' in sys.argv:                      # ABI 107: fp32 views + operand bounds (csrc/edge_block_x3.hip, two fp16 planes)
+        mq, mg = float(qkv.abs().max()), float(dobar.abs().max())
+        bounds = torch.tensor([mq, mg, mq, mg], device=dev)
+
+        def fwd():
+            _lib.check(lib.ampconv_fwd_edge_scaled(Qv, Kv, Vv, csr.rowptr.data_ptr(), csr.col.data_ptr(), N, L, D, H,
+                                                   F_._view(obar, 0, L, dh), *hub('dst', 1), bounds.data_ptr(), st), 'fwd')
+
+        def bwd_dst():
+            _lib.check(lib.ampconv_bwd_edge_dst_scaled(Qv, Kv, Vv, dOv, csr.rowptr.data_ptr(), csr.col.data_ptr(), N, L, D,
+                                                       H, dQv, *hub('dst', 1), bounds.data_ptr(), *sp, amax, st), 'bwd_dst')
+
+        def bwd_src():
+            _lib.check(lib.ampconv_bwd_edge_src_scaled(Qv, Kv, Vv, dOv, csr.cscptr.data_ptr(), csr.crow.data_ptr(),
+                                                       csr.cinv.data_ptr(), N, L, D, H, dKv, dVv, *hub('src', 2),
+                                                       bounds.data_ptr(), sp[1], amax, st), 'bwd_src')
+        print('bound-carrying fp32-view passes (two fp16 planes split in the kernel, 16-bit matrix pipe)')
 
     for name, fn, nbytes, flops in (
             ('fwd_edge', fwd, (2 * E + 2 * N) * R, 4 * L * L * D * E),

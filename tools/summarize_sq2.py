@@ -10,8 +10,8 @@ import os
 import re
 import sys
 
-KERNELS = (('fwd', r'\bfwd_(mfma|bf16|block|f16x2|x3)'), ('bwd_dst', r'\bbwd_dst_(mfma|bf16|block|f16x2|x3)'),
-           ('bwd_src', r'\bbwd_src_(mfma|bf16|block|f16x2|x3)'),
+KERNELS = (('fwd', r'\bfwd_(mfma|bf16|block|f16x2|x3|xh)'), ('bwd_dst', r'\bbwd_dst_(mfma|bf16|block|f16x2|x3|xh)'),
+           ('bwd_src', r'\bbwd_src_(mfma|bf16|block|f16x2|x3|xh)'),
            ('proj_rows', r'proj_rows_(bf16_)?kernel'), ('proj_wgrad', r'proj_wgrad_(bf16_)?kernel'))
 
 
