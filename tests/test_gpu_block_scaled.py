@@ -171,3 +171,34 @@ def test_wide_operands_leave_the_scaled_block_path(dev, monkeypatch):
     keep[5] = False
     err = np.abs(got[0][keep] - want[0][keep]).max() / np.abs(want[0][keep]).max()
     assert err < 2e-6, err
+
+
+def test_message_aggregate_at_the_class_default_shape(dev):
+    """The decomposed public path message() -> aggregate() (separate query and key/value tensors, identity graph, Q rows
+    D apart and K | V rows 2 D apart) through the same kernels: same output and gradients as the fused call."""
+    from ampnet_amd import AMPConv
+    torch.manual_seed(4)
+    N, E, L, D, H = 60, 400, 40, 100, 2
+    layer = AMPConv(D, H).to(dev)
+    with torch.no_grad():
+        layer.multi_head_attention.in_proj_bias.normal_(0, 0.1)
+        layer.multi_head_attention.out_proj.bias.normal_(0, 0.1)
+    x = torch.randn(N, L * D, device=dev)
+    dy = torch.randn(N, L * D, device=dev)
+    ei = torch.randint(0, N, (2, E), device=dev)
+    ei[1, ei[1] == 3] = 4                                      # node 3 receives nothing
+
+    xa = x.clone().requires_grad_(True)
+    ya = layer(xa, ei)
+    ya.backward(dy)
+    ga = [xa.grad.clone()] + [p.grad.clone() for p in layer.parameters()]
+    layer.zero_grad(set_to_none=True)
+
+    xb = x.clone().requires_grad_(True)
+    msg = layer.message(xb.index_select(0, ei[1]), xb.index_select(0, ei[0]))
+    yb = layer.aggregate(msg, ei[1], dim_size=N)
+    yb.backward(dy)
+    gb = [xb.grad] + [p.grad for p in layer.parameters()]
+    assert_close_scaled(yb.detach().cpu().numpy(), ya.detach().cpu().numpy(), 'y (message+aggregate vs fused)')
+    for i, (a, b) in enumerate(zip(ga, gb)):
+        assert_close_scaled(b.cpu().numpy(), a.cpu().numpy(), 'dx' if i == 0 else f'parameter gradient {i}')
