@@ -183,9 +183,15 @@ def proj_rows_planes(a2, image, bound, bias=None, rowptr=None, L=0, row_scale=0,
     return out
 
 
+# Sequences of at most 4 tokens stay on the short-sequence kernels (csrc/edge_small.hip: one wave per ROW, no tile padding):
+# the plane-format kernels pad every sequence to 20-token tiles (config 3's L = 4 sweep: 4.0 ms per step there, 14.2 here)
+PLANES_MIN_L = 5
+
+
 def planes_ok(L, D, H, shared):
     """Does the plane-format edge phase serve this layer call?  (Only with the scaled projections; the caller checks.)"""
-    return bool(EDGE_PLANES and shared and D % 128 == 0 and _lib.load().ampconv_planes_supported(L, D, H))
+    return bool(EDGE_PLANES and shared and D % 128 == 0 and L >= PLANES_MIN_L
+                and _lib.load().ampconv_planes_supported(L, D, H))
 
 
 def scaled_views_ok(L, D, H, shared):

@@ -94,6 +94,7 @@ def test_plane_path_vs_fp64_oracle(shape, stats, dev, monkeypatch):
     are what ran."""
     from ampnet_amd.conv import functional as F_
     monkeypatch.setattr(F_, 'PROJ_SCALED_MIN_ELEMENTS', 0)
+    monkeypatch.setattr(F_, 'PLANES_MIN_L', 1)               # (by default L <= 4 stays on the short-sequence kernels)
     monkeypatch.setattr(F_, 'SOFTMAX_STATS', stats)          # hand-off of (log-sum-exp, delta) from the dst to the src pass
     N, E, L, D, H = shape
     layer, x, dy, ei = _make(N, E, L, D, H, dev)
