@@ -69,6 +69,7 @@ SIGNATURES = {
     'ampconv_saint_fill_edges': (_i32, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp]),
     'ampconv_saint_add_counts': (_i32, [_vp, _i64, _vp, _vp]),
     'ampconv_saint_norms': (_i32, [_vp, _vp, _vp, _i64, _i64, ctypes.c_float, _vp, _vp, _vp]),
+    'ampconv_saint_gather_rows': (_i32, [_vp, _i64, _i64, _vp, _i64, _vp, _vp]),
     'ampconv_feat_zscore_stats': (_i32, [_vp, _i64, _i64, _vp, _vp, _vp]),
     'ampconv_feat_sample_present': (_i32, [_vp, _i64, _i32, _i32, ctypes.c_uint64, _vp, _vp, _vp]),
     'ampconv_feat_build': (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),

@@ -244,3 +244,33 @@ extern "C" int ampconv_saint_norms(const float *node_count, const float *edge_co
                                                                             edge_norm);
   return ampconv_launch_status();
 }
+
+// ---- the batch's feature rows: dst[i, :] = src[idx[i], :], 16 bytes per lane, one workgroup per 4 KiB piece of a row
+namespace {
+__global__ __launch_bounds__(256) void gather_rows_kernel(const char *__restrict__ src, int64_t stride, int64_t row_bytes,
+                                                          const int64_t *__restrict__ idx, int64_t n, char *__restrict__ dst,
+                                                          int pieces) {
+  const int64_t u = blockIdx.x;
+  const int64_t i = u / pieces;
+  const int64_t off = (u - i * pieces) * 4096 + (int64_t)threadIdx.x * 16;
+  if (i >= n || off >= row_bytes) return;
+  const int64_t r = idx[i];
+  typedef int i32x4_t __attribute__((ext_vector_type(4)));
+  const i32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const i32x4_t *>(src + r * stride + off));
+  __builtin_nontemporal_store(v, reinterpret_cast<i32x4_t *>(dst + i * row_bytes + off));
+}
+}  // namespace
+
+extern "C" int ampconv_saint_gather_rows(const void *src, int64_t src_stride_bytes, int64_t row_bytes, const int64_t *idx,
+                                         int64_t n, void *dst, void *stream) {
+  if (n < 0 || row_bytes < 0) return AMPCONV_E_BADARG;
+  if (n == 0 || row_bytes == 0) return AMPCONV_OK;
+  if (!src || !idx || !dst || row_bytes % 16 || src_stride_bytes % 16 || (uintptr_t)src % 16 || (uintptr_t)dst % 16)
+    return AMPCONV_E_BADARG;
+  const int pieces = (int)((row_bytes + 4095) / 4096);
+  const int64_t nb = n * pieces;
+  if (nb > INT32_MAX) return AMPCONV_E_BADARG;
+  gather_rows_kernel<<<(unsigned)nb, 256, 0, (hipStream_t)stream>>>((const char *)src, src_stride_bytes, row_bytes, idx, n,
+                                                                    (char *)dst, pieces);
+  return ampconv_launch_status();
+}

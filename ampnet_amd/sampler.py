@@ -20,6 +20,23 @@ from . import _lib
 from .graph import EdgeCSR, _stream
 
 
+def gather_rows(item, node_idx):
+    """item[node_idx] for a resident per-node tensor (the sampler's collate step, visualize_graphsaint_subgraphs.py:112-135):
+    rows of a multiple of 16 bytes on the GPU go through the library's gather kernel, anything else through torch's indexing
+    (labels, masks: a few bytes per node)."""
+    rb = item[0].numel() * item.element_size() if item.size(0) else 0
+    if not (item.is_cuda and node_idx.is_cuda and node_idx.dtype == torch.int64 and item.dim() >= 2 and rb and rb % 16 == 0
+            and item[0].is_contiguous() and (item.stride(0) * item.element_size()) % 16 == 0 and item.data_ptr() % 16 == 0
+            and not item.requires_grad):
+        return item[node_idx]
+    out = torch.empty((node_idx.numel(),) + tuple(item.shape[1:]), dtype=item.dtype, device=item.device)
+    with torch.cuda.device(item.device):
+        _lib.check(_lib.load().ampconv_saint_gather_rows(item.data_ptr(), item.stride(0) * item.element_size(), rb,
+                                                         node_idx.contiguous().data_ptr(), node_idx.numel(), out.data_ptr(),
+                                                         torch.cuda.current_stream().cuda_stream), 'ampconv_saint_gather_rows')
+    return out
+
+
 class GraphSAINTRandomWalkSampler:
     def __init__(self, data, batch_size, walk_length, num_steps=1, sample_coverage=0, seed=0,
                  num_nodes=None):
@@ -111,7 +128,7 @@ class GraphSAINTRandomWalkSampler:
             if key in ('edge_index', 'num_nodes'):
                 continue
             if isinstance(item, torch.Tensor) and item.dim() > 0 and item.size(0) == self.N:
-                setattr(out, key, item[node_idx.to(item.device)])
+                setattr(out, key, gather_rows(item, node_idx.to(item.device)))
             elif isinstance(item, torch.Tensor) and item.dim() > 0 and item.size(0) == self.E:
                 setattr(out, key, item[edge_id.to(item.device)])
             else:

@@ -348,6 +348,7 @@ def measure_saint(workload, steps, warmup, args, rank, world, dev, dist_on, dt_n
     the host read-backs, per-rank kernel times."""
     import types
     from ampnet_amd import GraphSAINTRandomWalkSampler, graph_cache, _lib
+    from ampnet_amd.sampler import gather_rows
     N, E, L, D, H, desc = WORKLOADS[workload]
     tdt = torch.bfloat16 if dt_name == 'bf16' else torch.float32
     R = L * D * (2 if dt_name == 'bf16' else 4)
@@ -374,7 +375,7 @@ def measure_saint(workload, steps, warmup, args, rank, world, dev, dist_on, dt_n
         e1.record()
         graph_cache.clear()
         layer.zero_grad(set_to_none=True)
-        xs = x.index_select(0, node_idx).requires_grad_(True)
+        xs = gather_rows(x, node_idx).requires_grad_(True)       # (the library's gather kernel: csrc/sampler.hip)
         y = layer(xs, ei_sub)
         y.backward(dy_buf[: xs.size(0)])
         if dist_on:

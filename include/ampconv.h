@@ -429,6 +429,11 @@ int ampconv_saint_add_counts(const int64_t *idx, int64_t n, float *count, void *
 int ampconv_saint_norms(const float *node_count, const float *edge_count, const int64_t *edge_src,
                         int64_t N, int64_t E, float num_samples, float *node_norm, float *edge_norm,
                         void *stream);
+/* gather_rows: the batch's rows of a resident per-node tensor, dst[i, :] = src[idx[i], :] (the collate step of the
+ * vendored sampler, visualize_graphsaint_subgraphs.py:112-135: `item[node_idx]`).  Rows of row_bytes bytes (a multiple of
+ * 16, both tensors 16-byte aligned, src rows src_stride_bytes apart), idx in [0, n_src).  */
+int ampconv_saint_gather_rows(const void *src, int64_t src_stride_bytes, int64_t row_bytes, const int64_t *idx,
+                              int64_t n, void *dst, void *stream);
 
 /* ---- AMPGCN featuriser ("next" row: the step right before the first AMPConv layer) ----------
  * Reference src/ampnet/module/amp_gcn.py:120-183: z-score of the node features (:122-125), L present

@@ -164,3 +164,23 @@ def test_replayed_walks_are_range_checked():
     for bad in (good.clone().index_fill_(0, torch.tensor([0], device=dev), N), good - N, good.flatten()):
         with pytest.raises(ValueError):
             s.sample(walks=bad)
+
+
+def test_gather_rows_matches_indexing():
+    """The collate step's row gather (csrc/sampler.hip, ampconv_saint_gather_rows) against torch indexing: fp32 and bf16
+    rows, a strided view, repeated and out-of-order indices; tensors it does not serve fall through to torch."""
+    from ampnet_amd.sampler import gather_rows
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(2)
+    for shape, dtype in (((500, 20 * 256), torch.float32), ((300, 40 * 100), torch.float32), ((257, 20, 256), torch.bfloat16),
+                         ((64, 4), torch.float32), ((90, 5000), torch.float32)):
+        x = torch.randn(*shape, generator=g).to(dtype).to(dev)
+        idx = torch.randint(0, shape[0], (777,), generator=g).to(dev)
+        assert torch.equal(gather_rows(x, idx), x[idx]), (shape, dtype)
+    x = torch.randn(400, 1024, generator=g).to(dev)
+    view = x[:, :512]                                   # rows 4096 bytes apart, 2048 bytes long
+    idx = torch.arange(399, -1, -1, device=dev)
+    assert torch.equal(gather_rows(view, idx), view[idx])
+    y = torch.randint(0, 7, (400,), generator=g).to(dev)      # labels: 1-D, torch's path
+    assert torch.equal(gather_rows(y, idx), y[idx])
+    assert gather_rows(x, idx[:0]).shape == (0, 1024)
