@@ -26,9 +26,10 @@ bash tools/prof_fp32_pipe.sh ${tag}_pipe_f32
 echo "## bf16 edge kernels (R-MAT, cfg5 shape at 1/4 size)"
 bash tools/prof_sq.sh ${tag}_bf16 524288 10000000 20 256 8 --bf16 --rmat
 bash tools/prof_fp32_pipe.sh ${tag}_pipe_bf16 524288 10000000 20 256 8 --bf16 --rmat
-echo "## block kernels (AMPGCN default shape L=40 D=100 H=2)"
+echo "## workgroup-per-unit kernels (AMPGCN default shape L=40 D=100 H=2), bound-carrying entry points: two fp16 planes"
+bash tools/prof_sq.sh ${tag}_block_scaled 100000 1000000 40 100 2 --scaled
+echo "## the same shape through the fp32 entry points: three bf16 planes"
 bash tools/prof_sq.sh ${tag}_block 100000 1000000 40 100 2
-bash tools/prof_fp32_pipe.sh ${tag}_pipe_block 100000 1000000 40 100 2
 echo "## fp32 projections, scaled two-plane mode (8M rows, D=256)"
 bash tools/prof_sq_proj.sh ${tag}_proj_scaled 8000000 256 --iters=2 --no-lib --scaled
 echo "## fp32 projections, six-product form"

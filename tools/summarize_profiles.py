@@ -201,8 +201,9 @@ def main():
                     'active over SIMD cycles (fp32-input MFMA and VALU share one pipe on gfx950: `tools/coexec_probe`); for the '
                     'bf16 kernels, whose MFMAs co-issue with VALU, the two columns are separate resources and the VALU column is '
                     'the binding one.  Shapes: fp32 edge kernels 100 k nodes / 1 M edges, L=20, D=256, H=8 (uniform); bf16 edge '
-                    'kernels R-MAT scale 19 / 10 M edges (config 5 at a quarter of its size); block kernels L=40, D=100, H=2 (the '
-                    'reference\'s AMPGCN defaults); projections 8 M rows, D = 256 (`proj_rows` averages the qkv / out / dx launches, '
+                    'kernels R-MAT scale 19 / 10 M edges (config 5 at a quarter of its size); workgroup-per-unit kernels L=40, D=100, H=2 (the '
+                    'reference\'s AMPGCN defaults; since round 5 csrc/edge_block_x3.hip: `*_xh` = two fp16 planes behind the bound-carrying '
+                    'entry points, `*_x3` = three bf16 planes behind the fp32 ones; profiles/r05_x3_sq.md has their HBM traffic); projections 8 M rows, D = 256 (`proj_rows` averages the qkv / out / dx launches, '
                     '`proj_wgrad` the dWin / dWo launches).  The projections\' clock column is the DVFS evidence of DESIGN.md 4a: '
                     '1.54-1.75 GHz on random data in both the six-product and the scaled three-product form.  Profiled runs are a '
                     'few % slower than un-profiled ones.\n\n```\n')
