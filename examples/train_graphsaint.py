@@ -44,12 +44,17 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--epochs', type=int, default=3)
     ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--class-defaults', action='store_true',
+                    help="AMPGCN's class defaults (src/ampnet/module/amp_gcn.py:21-35: embedding_dim=100, heads=2, 40 sampled "
+                         "vectors: what experiments/cora_benchmark_graphsaint_distributed.py:58 instantiates) instead of the "
+                         "128 / 4 / 20 of experiments/cora_benchmark_graphsaint.py")
     args = ap.parse_args()
     device = torch.device('cuda:0')
     torch.manual_seed(1)
     data = synthetic_cora(device)
-    model = AMPGCN(device=device, embedding_dim=128, num_heads=4, num_node_features=1433, num_sampled_vectors=20,
-                   output_dim=7, softmax_out=True, feat_emb_dim=127, val_emb_dim=1, dropout_rate=0.0,
+    D, H, L = (100, 2, 40) if args.class_defaults else (128, 4, 20)
+    model = AMPGCN(device=device, embedding_dim=D, num_heads=H, num_node_features=1433, num_sampled_vectors=L,
+                   output_dim=7, softmax_out=True, feat_emb_dim=D - 1, val_emb_dim=1, dropout_rate=0.0,
                    dropout_adj_rate=0.0).to(device)
     loader = GraphSAINTRandomWalkSampler(data, batch_size=8, walk_length=150, num_steps=args.steps,
                                          sample_coverage=20, seed=1)
