@@ -202,3 +202,25 @@ def test_message_aggregate_at_the_class_default_shape(dev):
     assert_close_scaled(yb.detach().cpu().numpy(), ya.detach().cpu().numpy(), 'y (message+aggregate vs fused)')
     for i, (a, b) in enumerate(zip(ga, gb)):
         assert_close_scaled(b.cpu().numpy(), a.cpu().numpy(), 'dx' if i == 0 else f'parameter gradient {i}')
+
+
+def test_wide_gradient_leaves_the_scaled_block_path_in_backward_only(dev, monkeypatch):
+    """A dY with one row at 1e8: the forward pass ran through the bound-carrying entry point, the backward pass measures
+    dY, finds it wide and takes the bound-free kernels and the exact projections on the saved fp32 tensors."""
+    from ampnet_amd.conv import functional as F_
+    monkeypatch.setattr(F_, 'PROJ_SCALED_MIN_ELEMENTS', 0)
+    N, E, L, D, H = 300, 2500, 40, 100, 2
+    layer, x, dy, ei = _make(N, E, L, D, H, dev, seed=12, hub=False)
+    dy[9] *= 1e8
+    calls = _Calls(monkeypatch, SCALED_CALLS + F32_CALLS)
+    got = _run(layer, x, dy, ei, dev)
+    assert calls.n['ampconv_fwd_edge_scaled'] == 1 and calls.n['ampconv_fwd_edge'] == 0, calls.n
+    assert calls.n['ampconv_bwd_edge_dst'] == 1 and calls.n['ampconv_bwd_edge_src'] == 1, calls.n
+    assert calls.n['ampconv_bwd_edge_dst_scaled'] == 0 and calls.n['ampconv_bwd_edge_src_scaled'] == 0, calls.n
+    want = _oracle(layer, x, dy, ei, H)
+    assert_close_scaled(got[0], want[0], 'y')
+    # dx: rows that do not hear from node 9 carry gradients of O(1); fp32-grade relative error there
+    src_of_9 = set(ei[0, ei[1] == 9].tolist()) | {9}
+    keep = np.array([i not in src_of_9 for i in range(N)])
+    err = np.abs(got[1][keep] - want[1][keep]).max() / max(np.abs(want[1][keep]).max(), 1e-30)
+    assert err < 5e-6, err
