@@ -161,8 +161,7 @@ __device__ __forceinline__ void xstage_offsets(StageOffs<VEC, NT> &lo, int tid) 
 
 template <int VEC, int NT, bool SCALE>
 __device__ __forceinline__ void xstage_store(char *imgA, char *imgB, const StageX<VEC, NT> &s,
-                                             const StageOffs<VEC, NT> &lo, float mulA, float mulB, int L, int dh,
-                                             int tid) {
+                                             const StageOffs<VEC, NT> &lo, float mulA, float mulB, int L) {
   using S = StageX<VEC, NT>;
   constexpr int PB = 16 * NT * kRowB;
 #pragma unroll
@@ -422,7 +421,7 @@ __global__ __launch_bounds__(64 * NT, AMPCONV_X3_FWD_WAVES) void fwd_x3(XArgs a)
   own_split(qf, qraw, a.qscale);
   __syncthreads();
   for (int p = beg; p < end; ++p) {
-    xstage_store<VEC, NT, false>(Kt, Vt, st, lo, 1.f, 1.f, L, dh, tid);
+    xstage_store<VEC, NT, false>(Kt, Vt, st, lo, 1.f, 1.f, L);
 #ifndef AMPCONV_X3_NOLOADS          // developer probe: the first edge's tiles again and again (what does the compute side cost?)
     if (p + 1 < end) fetch(p + 1);
 #endif
@@ -522,7 +521,7 @@ __global__ __launch_bounds__(64 * NT, AMPCONV_X3_DST_WAVES) void bwd_dst_x3(XArg
   __syncthreads();
   constexpr int LS = 16 * NT;
   for (int p = beg; p < end; ++p) {
-    xstage_store<VEC, NT, false>(Kt, Vt, st, lo, 1.f, 1.f, L, dh, tid);
+    xstage_store<VEC, NT, false>(Kt, Vt, st, lo, 1.f, 1.f, L);
     float *sb = nullptr;
     if (STATS) sb = a.stats + ((int64_t)__builtin_bit_cast(int, pos_next) * a.H + h) * (2 * LS);
     if (p + 1 < end) fetch(p + 1);
@@ -626,7 +625,7 @@ __global__ __launch_bounds__(64 * NT, AMPCONV_X3_SRC_WAVES) void bwd_src_x3(XArg
   __syncthreads();
   const bool colok = n + 16 * wave < L;      // this lane's source token exists
   for (int p = beg; p < end; ++p) {
-    xstage_store<VEC, NT, true>(Qt, Gt, st, lo, a.qscale, inv_next, L, dh, tid);
+    xstage_store<VEC, NT, true>(Qt, Gt, st, lo, a.qscale, inv_next, L);
     if (tid < 2 * LS) sl[tid] = stat_next;
     if (p + 1 < end) fetch(p + 1);
     __syncthreads();
