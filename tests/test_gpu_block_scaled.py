@@ -224,3 +224,60 @@ def test_wide_gradient_leaves_the_scaled_block_path_in_backward_only(dev, monkey
     keep = np.array([i not in src_of_9 for i in range(N)])
     err = np.abs(got[1][keep] - want[1][keep]).max() / max(np.abs(want[1][keep]).max(), 1e-30)
     assert err < 5e-6, err
+
+
+@pytest.mark.parametrize('seed', range(10))
+def test_random_shapes_scaled_vs_generic(seed, dev, monkeypatch):
+    """Random small problems of this family's shapes (L in 1..64, even dh in 34..64), degenerate graphs included, through
+    the bound-carrying entry points, against the fp64 oracle at the flat tolerance and against the independent shape-generic kernels."""
+    from ampnet_amd import AMPConv, graph_cache
+    from ampnet_amd.conv import functional as F_
+    rng = np.random.default_rng(7000 + seed)
+    dh = int(rng.choice([34, 36, 40, 48, 50, 56, 62, 64]))
+    H = int(rng.choice([1, 2, 3]))
+    L = int(rng.integers(1, 65))
+    D = dh * H
+    N = int(rng.integers(1, 300))
+    kind = seed % 5
+    E = int(rng.integers(0, 6 * N + 2))
+    src = rng.integers(0, N, E)
+    dst = rng.integers(0, N, E)
+    if kind == 1:
+        dst[:] = rng.integers(0, N)                       # every edge into one node (one long segment)
+    elif kind == 2:
+        src[:] = rng.integers(0, N)                       # every edge out of one node
+    elif kind == 3:
+        dst = src.copy()                                  # self loops only
+    ei = torch.from_numpy(np.stack([src, dst]).astype(np.int64)).to(dev)
+    torch.manual_seed(seed)
+    layer = AMPConv(D, H).to(dev)
+    with torch.no_grad():
+        layer.multi_head_attention.in_proj_bias.normal_(0, 0.2)
+        layer.multi_head_attention.out_proj.bias.normal_(0, 0.2)
+    x = torch.randn(N, L * D, device=dev)
+    dy = torch.randn(N, L * D, device=dev)
+
+    def run():
+        graph_cache.clear()
+        layer.zero_grad(set_to_none=True)
+        xg = x.clone().requires_grad_(True)
+        y = layer(xg, ei)
+        y.backward(dy)
+        m = layer.multi_head_attention
+        return [t.detach().cpu().numpy() for t in (y, xg.grad, m.in_proj_weight.grad, m.in_proj_bias.grad,
+                                                    m.out_proj.weight.grad, m.out_proj.bias.grad)]
+
+    monkeypatch.setattr(F_, 'PROJ_SCALED_MIN_ELEMENTS', 0)
+    calls = _Calls(monkeypatch, SCALED_CALLS)
+    fast = run()
+    assert all(calls.n[k] == 1 for k in SCALED_CALLS) or D % 4, calls.n      # (embed_dim % 4 != 0: library projections, no scaled mode)
+    # the checker is the fp64 oracle: on a source with a thousand out-edges the generic kernels' one long fp32 chain is
+    # itself 2e-5 off (seed 2: dx 2.0e-5 generic, 3.6e-6 here, 5.1e-6 bf16x3 -- of a maximum of 8)
+    want = _oracle(layer, x.cpu(), dy.cpu(), ei.cpu(), H)
+    for name, a, b in zip(NAMES, fast, want):
+        assert_close_scaled(a, b, name)
+    monkeypatch.setattr(F_, 'PROJ_SCALED_MIN_ELEMENTS', 1 << 62)
+    monkeypatch.setenv('AMPCONV_FORCE_GENERIC', '1')
+    slow = run()
+    for name, a, b in zip(NAMES, fast, slow):      # ... and the independent kernels agree to the magnitude-scaled tolerance
+        assert_close_scaled(a, b, name + ' (vs generic kernels)', scaled=True)
