@@ -195,10 +195,11 @@ def planes_ok(L, D, H, shared):
 
 
 def scaled_views_ok(L, D, H, shared):
-    """Do the bound-carrying fp32 entry points (include/ampconv.h, ampconv_*_edge_scaled: the workgroup-per-unit shapes,
-    e.g. the AMPGCN class defaults L = 40, D = 100, H = 2) serve this layer call?  Only with the scaled projections and
+    """Do the bound-carrying fp32 entry points (include/ampconv.h, ampconv_*_edge_scaled: the workgroup-per-unit shapes --
+    L <= 64, even head widths up to 64 outside the one-wave-per-unit kernels' L <= 20 x {16, 32} -- e.g. the AMPGCN class
+    defaults L = 40, D = 100, H = 2) serve this layer call?  Only with the scaled projections and
     the statistics hand-off; the caller checks the former."""
-    return bool(EDGE_PLANES and SOFTMAX_STATS and shared and _lib.load().ampconv_scaled_supported(L, D, H))
+    return bool(EDGE_PLANES and SOFTMAX_STATS and shared and L >= PLANES_MIN_L and _lib.load().ampconv_scaled_supported(L, D, H))
 
 
 def absmax(t2, out=None, reset=False):

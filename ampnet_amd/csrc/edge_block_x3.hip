@@ -1,4 +1,4 @@
-// Workgroup-per-unit edge kernels for the shapes of edge_block.hip with 32 < dh <= 64 and fp32 storage (the reference's
+// Workgroup-per-unit edge kernels for the shapes of edge_block.hip (L <= 64, even dh <= 64) with fp32 storage (the reference's
 // AMPGCN class defaults: L = 40, D = 100, H = 2 -> dh = 50, src/ampnet/module/amp_gcn.py:21-35), OFF the FP32 pipe:
 // every fp32 tile is split into THREE bf16 planes on its way into LDS
 //      x = h + m + l,   h = bf16(x), m = bf16(x - h), l = bf16(x - h - m)        (24 significand bits, no scale needed:
@@ -12,7 +12,8 @@
 //
 // One WORKGROUP owns one (row, head) unit; wave w of its NT = ceil(L / 16) owns the unit's own tokens 16 w .. 16 w + 15
 // (the COLUMNS of every score tile), all waves share the LDS images of the streamed pair of tiles.  Per plane an image
-// is [16 NT token rows][64 channels] bf16 = 128-byte rows, 16-byte chunk c of row j stored at chunk c ^ 2 ((j >> 1) & 3):
+// is [16 NT token rows][64 channels] bf16 = 128-byte rows (dh <= 32: template KS = 1, one 32-channel k-step and two channel
+// tiles instead of two and four; the upper half of every row is then neither staged nor read), 16-byte chunk c of row j stored at chunk c ^ 2 ((j >> 1) & 3):
 // the ds_read_b128 of the channel-product fragments and the ds_read_b64_tr_b16 of the token-product fragments are both
 // bank-conflict free (tools/lds_bank_check.py).
 // Reference arithmetic replaced: torch functional.py:6578-6594 per edge, the mean of amp_conv.py:11, and their autograd
@@ -88,9 +89,9 @@ __device__ __forceinline__ const float *tile_of(const ampconv_view_t &v, int64_t
 
 // ---- cooperative staging of two [L x dh] fp32 tiles (A then B): global -> registers -> split -> three plane images
 // each.  Thread (r0 = tid / DVP, cv = tid % DVP) owns vector column cv (VEC floats) of rows r0 + i RS.
-template <int VEC, int NT>
+template <int VEC, int NT, int KS>
 struct StageX {
-  static constexpr int DVP = 64 / VEC;                      // vector slots per padded row
+  static constexpr int DVP = 32 * KS / VEC;                 // vector slots per padded row (KS k-steps of 32 channels)
   static constexpr int RS = 64 * NT / DVP;                  // rows per pass
   static constexpr int NP = (16 * NT + RS - 1) / RS;        // passes
   float v[2][NP][VEC];
@@ -105,9 +106,9 @@ struct StageSrc {
   int stepA, stepB;         // bytes between two passes (RS token rows)
   int nrecA, nrecB;         // bytes from the tile's first element to the end of its last row
 };
-template <int VEC, int NT>
+template <int VEC, int NT, int KS>
 __device__ __forceinline__ StageSrc stage_src(int sA, int sB, int L, int dh, int tid) {
-  using S = StageX<VEC, NT>;
+  using S = StageX<VEC, NT, KS>;
   const int cv = tid % S::DVP, r0 = tid / S::DVP, c = cv * VEC;
   StageSrc q;
   q.voA = c < dh ? (unsigned)(r0 * sA + c) * 4u : 0x80000000u;
@@ -122,9 +123,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(const float *base, i
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(base), 0, nrec, 0x00020000);
 }
 
-template <int VEC, int NT>
-__device__ __forceinline__ void xstage_load(StageX<VEC, NT> &s, const float *A, const float *B, const StageSrc &q, int L) {
-  using S = StageX<VEC, NT>;
+template <int VEC, int NT, int KS>
+__device__ __forceinline__ void xstage_load(StageX<VEC, NT, KS> &s, const float *A, const float *B, const StageSrc &q, int L) {
+  using S = StageX<VEC, NT, KS>;
   const __amdgpu_buffer_rsrc_t ra = tile_rsrc(A, q.nrecA), rb = tile_rsrc(B, q.nrecB);
 #pragma unroll
   for (int i = 0; i < S::NP; ++i) {
@@ -147,22 +148,22 @@ __device__ __forceinline__ void xstage_load(StageX<VEC, NT> &s, const float *A, 
 }
 
 // LDS byte offsets of this thread's vector in the rows it stages (plane 0 of an image)
-template <int VEC, int NT>
+template <int VEC, int NT, int KS>
 struct StageOffs {
-  int v[StageX<VEC, NT>::NP];
+  int v[StageX<VEC, NT, KS>::NP];
 };
-template <int VEC, int NT>
-__device__ __forceinline__ void xstage_offsets(StageOffs<VEC, NT> &lo, int tid) {
-  using S = StageX<VEC, NT>;
+template <int VEC, int NT, int KS>
+__device__ __forceinline__ void xstage_offsets(StageOffs<VEC, NT, KS> &lo, int tid) {
+  using S = StageX<VEC, NT, KS>;
   const int cv = tid % S::DVP, r0 = tid / S::DVP, c = cv * VEC;
 #pragma unroll
   for (int i = 0; i < S::NP; ++i) lo.v[i] = xoff(r0 + i * S::RS, c >> 3) + (c & 7) * 2;
 }
 
-template <int VEC, int NT, bool SCALE>
-__device__ __forceinline__ void xstage_store(char *imgA, char *imgB, const StageX<VEC, NT> &s,
-                                             const StageOffs<VEC, NT> &lo, float mulA, float mulB, int L) {
-  using S = StageX<VEC, NT>;
+template <int VEC, int NT, int KS, bool SCALE>
+__device__ __forceinline__ void xstage_store(char *imgA, char *imgB, const StageX<VEC, NT, KS> &s,
+                                             const StageOffs<VEC, NT, KS> &lo, float mulA, float mulB, int L) {
+  using S = StageX<VEC, NT, KS>;
   constexpr int PB = 16 * NT * kRowB;
 #pragma unroll
   for (int i = 0; i < S::NP; ++i) {
@@ -202,13 +203,15 @@ __device__ __forceinline__ void xstage_store(char *imgA, char *imgB, const Stage
 // channels 32 ks + 8 kg .. + 7 of token 16 wave + n, scaled, split; token rows >= L and channels >= dh read as zero.
 // Two steps, so that the loads are in flight while the unit's first tiles are requested (own_load), and are only waited
 // for behind that (own_split).
+template <int KS>
 struct OwnRaw {
-  float2 x[2][4];
+  float2 x[KS][4];
 };
-__device__ __forceinline__ void own_load(OwnRaw &o, const float *base, int row_stride, int wave, int L, int dh, int lane) {
+template <int KS>
+__device__ __forceinline__ void own_load(OwnRaw<KS> &o, const float *base, int row_stride, int wave, int L, int dh, int lane) {
   const int n = lane & 15, kg = lane >> 4, j = 16 * wave + n;
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
+  for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int c = 32 * ks + 8 * kg + 2 * u;
@@ -217,9 +220,10 @@ __device__ __forceinline__ void own_load(OwnRaw &o, const float *base, int row_s
     }
   }
 }
-__device__ __forceinline__ void own_split(Frag3 (&f)[2], const OwnRaw &o, float mul) {
+template <int KS>
+__device__ __forceinline__ void own_split(Frag3 (&f)[KS], const OwnRaw<KS> &o, float mul) {
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
+  for (int ks = 0; ks < KS; ++ks) {
     int h[4], m[4], l[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) split3(o.x[ks][u].x * mul, o.x[ks][u].y * mul, h[u], m[u], l[u]);
@@ -301,15 +305,15 @@ __device__ __forceinline__ FragAddr frag_addr(int lane) {
 
 // output: C/D tiles [channel tile mc] of this wave's token tile -> global rows (channels < dh, tokens < L).  Lane
 // (token n = lane & 15, g), register r of tile mc = channel 16 mc + 4 g + r
-template <int VEC>
-__device__ __forceinline__ float store_x3(const ampconv_view_t &v, int64_t node, int h, const f32x4 (&T)[4], float scale,
+template <int VEC, int MCT>
+__device__ __forceinline__ float store_x3(const ampconv_view_t &v, int64_t node, int h, const f32x4 (&T)[MCT], float scale,
                                           int tile, int L, int dh, int lane) {
   const int i = (lane & 15) + 16 * tile, g = lane >> 4;
   float mx = 0.f;                      // largest finite magnitude stored (the scaled backward kernels record it)
   if (i >= L) return mx;
   float *row = reinterpret_cast<float *>(v.ptr) + node * v.node_stride + (int64_t)h * v.head_stride + (int64_t)i * v.row_stride;
 #pragma unroll
-  for (int mc = 0; mc < 4; ++mc) {
+  for (int mc = 0; mc < MCT; ++mc) {
     const int c = 16 * mc + 4 * g;
     const float x0 = T[mc][0] * scale, x1 = T[mc][1] * scale, x2 = T[mc][2] * scale, x3 = T[mc][3] * scale;
     if constexpr (VEC == 4) {
@@ -365,9 +369,9 @@ __device__ __forceinline__ float x3_column_softmax(f32x4 (&S)[NT], int L, int g)
 
 // the staging passes rewrite whole 64-channel rows (zeros in the padding) of every token row below RS ceil(L / RS); the
 // rows above that, in all plane images, are zeroed once per unit
-template <int VEC, int NT, int NPLANES = 6>
+template <int VEC, int NT, int KS, int NPLANES = 6>
 __device__ __forceinline__ void lds_zero_tail(char *p, int L, int tid) {
-  using S = StageX<VEC, NT>;
+  using S = StageX<VEC, NT, KS>;
   constexpr int PB = 16 * NT * kRowB;
   const int zr = ((L + S::RS - 1) / S::RS) * S::RS, nrow = 16 * NT - zr;      // rows zr .. 16 NT - 1
   for (int i = tid; i < NPLANES * nrow * (kRowB / 16); i += 64 * NT) {
@@ -383,8 +387,9 @@ __device__ __forceinline__ void lds_zero_tail(char *p, int L, int tid) {
 #ifndef AMPCONV_X3_FWD_MCB
 #define AMPCONV_X3_FWD_MCB 1
 #endif
-template <int VEC, int NT>
+template <int VEC, int NT, int KS>
 __global__ __launch_bounds__(64 * NT, AMPCONV_X3_FWD_WAVES) void fwd_x3(XArgs a) {
+  constexpr int MCT = 2 * KS;                 // 16-channel tiles
   constexpr int MCB = AMPCONV_X3_FWD_MCB;
   constexpr int PB = 16 * NT * kRowB, TB = 3 * PB, NPAIR = (NT + 1) / 2;
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -400,28 +405,28 @@ __global__ __launch_bounds__(64 * NT, AMPCONV_X3_FWD_WAVES) void fwd_x3(XArgs a)
 
   IdxWindow win;
   if (beg < end) idxwin_load<false>(win, a.idx, nullptr, beg, end, lane);      // (first: everything else waits for it)
-  OwnRaw qraw;
+  OwnRaw<KS> qraw;
   own_load(qraw, tile_of(a.Q, d, h), (int)a.Q.row_stride, wave, L, dh, lane);
-  f32x4 OT[4];
+  f32x4 OT[MCT];
 #pragma unroll
-  for (int mc = 0; mc < 4; ++mc) OT[mc] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int mc = 0; mc < MCT; ++mc) OT[mc] = f32x4{0.f, 0.f, 0.f, 0.f};
   const FragAddr fa = frag_addr(lane);
-  StageOffs<VEC, NT> lo;
-  xstage_offsets<VEC, NT>(lo, tid);
+  StageOffs<VEC, NT, KS> lo;
+  xstage_offsets<VEC, NT, KS>(lo, tid);
 
-  StageX<VEC, NT> st;
-  const StageSrc sq = stage_src<VEC, NT>((int)a.K.row_stride, (int)a.V.row_stride, L, dh, tid);
+  StageX<VEC, NT, KS> st;
+  const StageSrc sq = stage_src<VEC, NT, KS>((int)a.K.row_stride, (int)a.V.row_stride, L, dh, tid);
   auto fetch = [&](int p) {
     const int64_t s = idxwin_get<false>(win, a.idx, nullptr, p, end, lane, nullptr);
-    xstage_load<VEC, NT>(st, tile_of(a.K, s, h), tile_of(a.V, s, h), sq, L);
+    xstage_load<VEC, NT, KS>(st, tile_of(a.K, s, h), tile_of(a.V, s, h), sq, L);
   };
   if (beg < end) fetch(beg);
-  lds_zero_tail<VEC, NT>(lds, L, tid);
-  Frag3 qf[2];
+  lds_zero_tail<VEC, NT, KS>(lds, L, tid);
+  Frag3 qf[KS];
   own_split(qf, qraw, a.qscale);
   __syncthreads();
   for (int p = beg; p < end; ++p) {
-    xstage_store<VEC, NT, false>(Kt, Vt, st, lo, 1.f, 1.f, L);
+    xstage_store<VEC, NT, KS, false>(Kt, Vt, st, lo, 1.f, 1.f, L);
 #ifndef AMPCONV_X3_NOLOADS          // developer probe: the first edge's tiles again and again (what does the compute side cost?)
     if (p + 1 < end) fetch(p + 1);
 #endif
@@ -437,12 +442,12 @@ __global__ __launch_bounds__(64 * NT, AMPCONV_X3_FWD_WAVES) void fwd_x3(XArgs a)
     for (int t = 0; t < NT; ++t) {
       S[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) S[t] = mfma6(rowfrag3<PB>(Kt, fa.a[ks], t), qf[ks], S[t]);
+      for (int ks = 0; ks < KS; ++ks) S[t] = mfma6(rowfrag3<PB>(Kt, fa.a[ks], t), qf[ks], S[t]);
     }
     x3_column_softmax<NT>(S, L, g);
     Frag3 pf[NPAIR];
 #pragma unroll
-    for (int mb = 0; mb < 4 / MCB; ++mb) {                  // MCB channel tiles per group of transposed reads
+    for (int mb = 0; mb < MCT / MCB; ++mb) {                  // MCB channel tiles per group of transposed reads
       X3_PRE_READ();
       Frag3 vc[MCB][NPAIR];
 #pragma unroll
@@ -462,7 +467,7 @@ __global__ __launch_bounds__(64 * NT, AMPCONV_X3_FWD_WAVES) void fwd_x3(XArgs a)
     __syncthreads();
   }
   // hub pass: unnormalised partial tile, the combine pass applies 1/deg
-  store_x3<VEC>(a.O, onode, h, OT, a.hub.mode == 2 ? 1.f : (deg > 0 ? 1.f / (float)deg : 0.f), wave, L, dh, lane);
+  store_x3<VEC, MCT>(a.O, onode, h, OT, a.hub.mode == 2 ? 1.f : (deg > 0 ? 1.f / (float)deg : 0.f), wave, L, dh, lane);
 }
 
 // ---------------------------------------------------------------- backward, destination pass
@@ -478,8 +483,9 @@ __global__ __launch_bounds__(64 * NT, AMPCONV_X3_FWD_WAVES) void fwd_x3(XArgs a)
 #ifndef AMPCONV_X3_SRC_PAIRS
 #define AMPCONV_X3_SRC_PAIRS 0
 #endif
-template <int VEC, bool STATS, int NT>
+template <int VEC, bool STATS, int NT, int KS>
 __global__ __launch_bounds__(64 * NT, AMPCONV_X3_DST_WAVES) void bwd_dst_x3(XArgs a) {
+  constexpr int MCT = 2 * KS;
   constexpr int MCB = AMPCONV_X3_DST_MCB;
   constexpr int PB = 16 * NT * kRowB, TB = 3 * PB, NPAIR = (NT + 1) / 2;
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -496,32 +502,32 @@ __global__ __launch_bounds__(64 * NT, AMPCONV_X3_DST_WAVES) void bwd_dst_x3(XArg
   IdxWindow win;
   const float *wts = reinterpret_cast<const float *>(a.spos);
   if (beg < end) idxwin_load<STATS>(win, a.idx, wts, beg, end, lane);
-  OwnRaw qraw, graw;
+  OwnRaw<KS> qraw, graw;
   own_load(qraw, tile_of(a.Q, r, h), (int)a.Q.row_stride, wave, L, dh, lane);
   own_load(graw, tile_of(a.dO, r, h), (int)a.dO.row_stride, wave, L, dh, lane);
-  f32x4 dQT[4];
+  f32x4 dQT[MCT];
 #pragma unroll
-  for (int mc = 0; mc < 4; ++mc) dQT[mc] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int mc = 0; mc < MCT; ++mc) dQT[mc] = f32x4{0.f, 0.f, 0.f, 0.f};
   const FragAddr fa = frag_addr(lane);
-  StageOffs<VEC, NT> lo;
-  xstage_offsets<VEC, NT>(lo, tid);
+  StageOffs<VEC, NT, KS> lo;
+  xstage_offsets<VEC, NT, KS>(lo, tid);
 
-  StageX<VEC, NT> st;
+  StageX<VEC, NT, KS> st;
   float pos_next = 0.f;                      // STATS: CSC position (int bits) in the window's weight slot
-  const StageSrc sq = stage_src<VEC, NT>((int)a.K.row_stride, (int)a.V.row_stride, L, dh, tid);
+  const StageSrc sq = stage_src<VEC, NT, KS>((int)a.K.row_stride, (int)a.V.row_stride, L, dh, tid);
   auto fetch = [&](int p) {
     const int64_t s = idxwin_get<STATS>(win, a.idx, wts, p, end, lane, &pos_next);
-    xstage_load<VEC, NT>(st, tile_of(a.K, s, h), tile_of(a.V, s, h), sq, L);
+    xstage_load<VEC, NT, KS>(st, tile_of(a.K, s, h), tile_of(a.V, s, h), sq, L);
   };
   if (beg < end) fetch(beg);
-  lds_zero_tail<VEC, NT>(lds, L, tid);
-  Frag3 qf[2], gf[2];
+  lds_zero_tail<VEC, NT, KS>(lds, L, tid);
+  Frag3 qf[KS], gf[KS];
   own_split(qf, qraw, a.qscale);
   own_split(gf, graw, inv);
   __syncthreads();
   constexpr int LS = 16 * NT;
   for (int p = beg; p < end; ++p) {
-    xstage_store<VEC, NT, false>(Kt, Vt, st, lo, 1.f, 1.f, L);
+    xstage_store<VEC, NT, KS, false>(Kt, Vt, st, lo, 1.f, 1.f, L);
     float *sb = nullptr;
     if (STATS) sb = a.stats + ((int64_t)__builtin_bit_cast(int, pos_next) * a.H + h) * (2 * LS);
     if (p + 1 < end) fetch(p + 1);
@@ -532,7 +538,7 @@ __global__ __launch_bounds__(64 * NT, AMPCONV_X3_DST_WAVES) void bwd_dst_x3(XArg
     for (int t = 0; t < NT; ++t) {
       S[t] = dP[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
+      for (int ks = 0; ks < KS; ++ks) {
         S[t] = mfma6(rowfrag3<PB>(Kt, fa.a[ks], t), qf[ks], S[t]);
         dP[t] = mfma6(rowfrag3<PB>(Vt, fa.a[ks], t), gf[ks], dP[t]);
       }
@@ -556,7 +562,7 @@ __global__ __launch_bounds__(64 * NT, AMPCONV_X3_DST_WAVES) void bwd_dst_x3(XArg
     }
     Frag3 sf[NPAIR];
 #pragma unroll
-    for (int mb = 0; mb < 4 / MCB; ++mb) {
+    for (int mb = 0; mb < MCT / MCB; ++mb) {
       X3_PRE_READ();
       Frag3 kc[MCB][NPAIR];
 #pragma unroll
@@ -575,12 +581,13 @@ __global__ __launch_bounds__(64 * NT, AMPCONV_X3_DST_WAVES) void bwd_dst_x3(XArg
     }
     __syncthreads();
   }
-  store_x3<VEC>(a.O, onode, h, dQT, a.hub.mode == 2 ? 1.f : a.oscale, wave, L, dh, lane);
+  store_x3<VEC, MCT>(a.O, onode, h, dQT, a.hub.mode == 2 ? 1.f : a.oscale, wave, L, dh, lane);
 }
 
 // ---------------------------------------------------------------- backward, source pass (needs the statistics)
-template <int VEC, int NT>
+template <int VEC, int NT, int KS>
 __global__ __launch_bounds__(64 * NT, AMPCONV_X3_SRC_WAVES) void bwd_src_x3(XArgs a) {
+  constexpr int MCT = 2 * KS;
   constexpr int PB = 16 * NT * kRowB, TB = 3 * PB, NPAIR = (NT + 1) / 2;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -594,38 +601,38 @@ __global__ __launch_bounds__(64 * NT, AMPCONV_X3_SRC_WAVES) void bwd_src_x3(XArg
 
   IdxWindow win;
   if (beg < end) idxwin_load<true>(win, a.idx, a.cinv, beg, end, lane);
-  OwnRaw kraw, vraw;
+  OwnRaw<KS> kraw, vraw;
   own_load(kraw, tile_of(a.K, s, h), (int)a.K.row_stride, wave, L, dh, lane);
   own_load(vraw, tile_of(a.V, s, h), (int)a.V.row_stride, wave, L, dh, lane);
-  f32x4 dKT[4], dVT[4];
+  f32x4 dKT[MCT], dVT[MCT];
 #pragma unroll
-  for (int mc = 0; mc < 4; ++mc) dKT[mc] = dVT[mc] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int mc = 0; mc < MCT; ++mc) dKT[mc] = dVT[mc] = f32x4{0.f, 0.f, 0.f, 0.f};
   const FragAddr fa = frag_addr(lane);
-  StageOffs<VEC, NT> lo;
-  xstage_offsets<VEC, NT>(lo, tid);
+  StageOffs<VEC, NT, KS> lo;
+  xstage_offsets<VEC, NT, KS>(lo, tid);
 
-  StageX<VEC, NT> st;
+  StageX<VEC, NT, KS> st;
   float inv_next = 0.f;
   // the edge's softmax statistics (2 LS floats, written by the destination pass at this CSC position) travel with its
   // tiles: one float per thread, requested an edge ahead and handed to the waves through LDS
   constexpr int LS = 16 * NT;
   float *sl = reinterpret_cast<float *>(lds + 2 * TB);
   float stat_next = 0.f;
-  const StageSrc sq = stage_src<VEC, NT>((int)a.Q.row_stride, (int)a.dO.row_stride, L, dh, tid);
+  const StageSrc sq = stage_src<VEC, NT, KS>((int)a.Q.row_stride, (int)a.dO.row_stride, L, dh, tid);
   auto fetch = [&](int p) {
     const int64_t d = idxwin_get<true>(win, a.idx, a.cinv, p, end, lane, &inv_next);
     if (tid < 2 * LS) stat_next = a.stats[((int64_t)p * a.H + h) * (2 * LS) + tid];
-    xstage_load<VEC, NT>(st, tile_of(a.Q, d, h), tile_of(a.dO, d, h), sq, L);
+    xstage_load<VEC, NT, KS>(st, tile_of(a.Q, d, h), tile_of(a.dO, d, h), sq, L);
   };
   if (beg < end) fetch(beg);
-  lds_zero_tail<VEC, NT>(lds, L, tid);
-  Frag3 kf[2], vf[2];
+  lds_zero_tail<VEC, NT, KS>(lds, L, tid);
+  Frag3 kf[KS], vf[KS];
   own_split(kf, kraw, 1.f);
   own_split(vf, vraw, 1.f);
   __syncthreads();
   const bool colok = n + 16 * wave < L;      // this lane's source token exists
   for (int p = beg; p < end; ++p) {
-    xstage_store<VEC, NT, true>(Qt, Gt, st, lo, a.qscale, inv_next, L);
+    xstage_store<VEC, NT, KS, true>(Qt, Gt, st, lo, a.qscale, inv_next, L);
     if (tid < 2 * LS) sl[tid] = stat_next;
     if (p + 1 < end) fetch(p + 1);
     __syncthreads();
@@ -644,7 +651,7 @@ __global__ __launch_bounds__(64 * NT, AMPCONV_X3_SRC_WAVES) void bwd_src_x3(XArg
           const f32x4 d4 = *reinterpret_cast<const f32x4 *>(sl + LS + 16 * t + 4 * g);
           f32x4 S = f32x4{0.f, 0.f, 0.f, 0.f}, dP = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int ks = 0; ks < 2; ++ks) {
+          for (int ks = 0; ks < KS; ++ks) {
             S = mfma6(rowfrag3<PB>(Qt, fa.a[ks], t), kf[ks], S);
             dP = mfma6(rowfrag3<PB>(Gt, fa.a[ks], t), vf[ks], dP);
           }
@@ -658,7 +665,7 @@ __global__ __launch_bounds__(64 * NT, AMPCONV_X3_SRC_WAVES) void bwd_src_x3(XArg
       }
       Frag3 pf, sf;
 #pragma unroll
-      for (int mc = 0; mc < 4; ++mc) {
+      for (int mc = 0; mc < MCT; ++mc) {
         X3_PRE_READ();
         const Frag3 gc = colfrag3<NT, PB>(Gt, fa.tr[mc], i), qc = colfrag3<NT, PB>(Qt, fa.tr[mc], i);
         if (mc == 0) {
@@ -678,7 +685,7 @@ __global__ __launch_bounds__(64 * NT, AMPCONV_X3_SRC_WAVES) void bwd_src_x3(XArg
       const f32x4 d4 = *reinterpret_cast<const f32x4 *>(sl + LS + 16 * t + 4 * g);
       f32x4 S = f32x4{0.f, 0.f, 0.f, 0.f}, dP = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
+      for (int ks = 0; ks < KS; ++ks) {
         S = mfma6(rowfrag3<PB>(Qt, fa.a[ks], t), kf[ks], S);
         dP = mfma6(rowfrag3<PB>(Gt, fa.a[ks], t), vf[ks], dP);
       }
@@ -691,7 +698,7 @@ __global__ __launch_bounds__(64 * NT, AMPCONV_X3_SRC_WAVES) void bwd_src_x3(XArg
     }
     Frag3 pf[NPAIR], sf[NPAIR];
 #pragma unroll
-    for (int mc = 0; mc < 4; ++mc) {
+    for (int mc = 0; mc < MCT; ++mc) {
       X3_PRE_READ();
       Frag3 gc[NPAIR], qc[NPAIR];
 #pragma unroll
@@ -716,8 +723,8 @@ __global__ __launch_bounds__(64 * NT, AMPCONV_X3_SRC_WAVES) void bwd_src_x3(XArg
 #endif
     __syncthreads();
   }
-  store_x3<VEC>(a.dK, onode, h, dKT, a.hub.mode == 2 ? 1.f : a.oscale, wave, L, dh, lane);
-  store_x3<VEC>(a.dV, onode, h, dVT, 1.f, wave, L, dh, lane);
+  store_x3<VEC, MCT>(a.dK, onode, h, dKT, a.hub.mode == 2 ? 1.f : a.oscale, wave, L, dh, lane);
+  store_x3<VEC, MCT>(a.dV, onode, h, dVT, 1.f, wave, L, dh, lane);
 }
 
 // =====================================================================================================================
@@ -774,8 +781,11 @@ __device__ __forceinline__ float frag_sumsq_h(const i32x4 &f) {
   return s;
 }
 // largest token-row norm^2 of the wave's own 16 tokens (hi planes of its two k-step fragments): wave-uniform
-__device__ __forceinline__ float own_max_norm2(const Frag2 (&f)[2]) {
-  const float t = groups_sum(frag_sumsq_h(f[0].h) + frag_sumsq_h(f[1].h));
+template <int KS>
+__device__ __forceinline__ float own_max_norm2(const Frag2 (&f)[KS]) {
+  float q = frag_sumsq_h(f[0].h);
+  if constexpr (KS == 2) q += frag_sumsq_h(f[1].h);
+  const float t = groups_sum(q);
   return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, row16_max(t))));
 }
 // scale of dS for a wave whose own side has largest row norm^2 `own2` and whose streamed side is bounded by `other` per
@@ -784,10 +794,10 @@ __device__ __forceinline__ float ds_scale_x(float own2, float other) {
   return plane_scale_x(2.f * __builtin_sqrtf(own2) * (8.f * other));
 }
 
-template <int VEC, int NT>
-__device__ __forceinline__ void xstage_store_h(char *imgA, char *imgB, const StageX<VEC, NT> &s,
-                                               const StageOffs<VEC, NT> &lo, float mulA, float mulB, int L) {
-  using S = StageX<VEC, NT>;
+template <int VEC, int NT, int KS>
+__device__ __forceinline__ void xstage_store_h(char *imgA, char *imgB, const StageX<VEC, NT, KS> &s,
+                                               const StageOffs<VEC, NT, KS> &lo, float mulA, float mulB, int L) {
+  using S = StageX<VEC, NT, KS>;
   constexpr int PB = 16 * NT * kRowB;
 #pragma unroll
   for (int i = 0; i < S::NP; ++i) {
@@ -812,9 +822,10 @@ __device__ __forceinline__ void xstage_store_h(char *imgA, char *imgB, const Sta
     }
   }
 }
-__device__ __forceinline__ void own_split_h(Frag2 (&f)[2], const OwnRaw &o, float mul) {
+template <int KS>
+__device__ __forceinline__ void own_split_h(Frag2 (&f)[KS], const OwnRaw<KS> &o, float mul) {
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
+  for (int ks = 0; ks < KS; ++ks) {
     int h[4], l[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) split2h(o.x[ks][u].x * mul, o.x[ks][u].y * mul, h[u], l[u]);
@@ -902,8 +913,9 @@ __device__ __forceinline__ float xh_column_softmax(f32x4 (&S)[NT], float sc, flo
 #endif
 
 // ---------------------------------------------------------------- forward (scaled)
-template <int VEC, int NT>
+template <int VEC, int NT, int KS>
 __global__ __launch_bounds__(64 * NT, AMPCONV_XH_FWD_WAVES) void fwd_xh(XArgs a) {
+  constexpr int MCT = 2 * KS;
   constexpr int MCB = AMPCONV_XH_FWD_MCB;
   constexpr int PB = 16 * NT * kRowB, TB = 2 * PB, NPAIR = (NT + 1) / 2;
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -920,28 +932,28 @@ __global__ __launch_bounds__(64 * NT, AMPCONV_XH_FWD_WAVES) void fwd_xh(XArgs a)
 
   IdxWindow win;
   if (beg < end) idxwin_load<false>(win, a.idx, nullptr, beg, end, lane);
-  OwnRaw qraw;
+  OwnRaw<KS> qraw;
   own_load(qraw, tile_of(a.Q, r, h), (int)a.Q.row_stride, wave, L, dh, lane);
-  f32x4 OT[4];
+  f32x4 OT[MCT];
 #pragma unroll
-  for (int mc = 0; mc < 4; ++mc) OT[mc] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int mc = 0; mc < MCT; ++mc) OT[mc] = f32x4{0.f, 0.f, 0.f, 0.f};
   const FragAddr fa = frag_addr(lane);
-  StageOffs<VEC, NT> lo;
-  xstage_offsets<VEC, NT>(lo, tid);
+  StageOffs<VEC, NT, KS> lo;
+  xstage_offsets<VEC, NT, KS>(lo, tid);
 
-  StageX<VEC, NT> st;
-  const StageSrc sq_ = stage_src<VEC, NT>((int)a.K.row_stride, (int)a.V.row_stride, L, dh, tid);
+  StageX<VEC, NT, KS> st;
+  const StageSrc sq_ = stage_src<VEC, NT, KS>((int)a.K.row_stride, (int)a.V.row_stride, L, dh, tid);
   auto fetch = [&](int p) {
     const int64_t s = idxwin_get<false>(win, a.idx, nullptr, p, end, lane, nullptr);
-    xstage_load<VEC, NT>(st, tile_of(a.K, s, h), tile_of(a.V, s, h), sq_, L);
+    xstage_load<VEC, NT, KS>(st, tile_of(a.K, s, h), tile_of(a.V, s, h), sq_, L);
   };
   if (beg < end) fetch(beg);
-  lds_zero_tail<VEC, NT, 4>(lds, L, tid);
-  Frag2 qf[2];
+  lds_zero_tail<VEC, NT, KS, 4>(lds, L, tid);
+  Frag2 qf[KS];
   own_split_h(qf, qraw, sq);
   __syncthreads();
   for (int p = beg; p < end; ++p) {
-    xstage_store_h<VEC, NT>(Kt, Vt, st, lo, sq, sq, L);
+    xstage_store_h<VEC, NT, KS>(Kt, Vt, st, lo, sq, sq, L);
     if (p + 1 < end) fetch(p + 1);
     __syncthreads();
 
@@ -950,12 +962,12 @@ __global__ __launch_bounds__(64 * NT, AMPCONV_XH_FWD_WAVES) void fwd_xh(XArgs a)
     for (int t = 0; t < NT; ++t) {
       S[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) S[t] = mfma3h(rowfrag2<PB>(Kt, fa.a[ks], t), qf[ks], S[t]);
+      for (int ks = 0; ks < KS; ++ks) S[t] = mfma3h(rowfrag2<PB>(Kt, fa.a[ks], t), qf[ks], S[t]);
     }
     xh_column_softmax<NT>(S, sc, kPScaleX, L, g);
     Frag2 pf[NPAIR];
 #pragma unroll
-    for (int mb = 0; mb < 4 / MCB; ++mb) {
+    for (int mb = 0; mb < MCT / MCB; ++mb) {
       X3_PRE_READ();
       Frag2 vc[MCB][NPAIR];
 #pragma unroll
@@ -974,13 +986,14 @@ __global__ __launch_bounds__(64 * NT, AMPCONV_XH_FWD_WAVES) void fwd_xh(XArgs a)
     }
     __syncthreads();
   }
-  store_x3<VEC>(a.O, onode, h, OT, kPUnscaleX * uq * (a.hub.mode == 2 ? 1.f : (deg > 0 ? 1.f / (float)deg : 0.f)), wave, L, dh,
+  store_x3<VEC, MCT>(a.O, onode, h, OT, kPUnscaleX * uq * (a.hub.mode == 2 ? 1.f : (deg > 0 ? 1.f / (float)deg : 0.f)), wave, L, dh,
                 lane);
 }
 
 // ---------------------------------------------------------------- backward, destination pass (scaled)
-template <int VEC, bool STATS, int NT>
+template <int VEC, bool STATS, int NT, int KS>
 __global__ __launch_bounds__(64 * NT, AMPCONV_XH_DST_WAVES) void bwd_dst_xh(XArgs a) {
+  constexpr int MCT = 2 * KS;
   constexpr int MCB = AMPCONV_XH_DST_MCB;
   constexpr int PB = 16 * NT * kRowB, TB = 2 * PB, NPAIR = (NT + 1) / 2;
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -999,26 +1012,26 @@ __global__ __launch_bounds__(64 * NT, AMPCONV_XH_DST_WAVES) void bwd_dst_xh(XArg
   IdxWindow win;
   const float *wts = reinterpret_cast<const float *>(a.spos);
   if (beg < end) idxwin_load<STATS>(win, a.idx, wts, beg, end, lane);
-  OwnRaw qraw, graw;
+  OwnRaw<KS> qraw, graw;
   own_load(qraw, tile_of(a.Q, r, h), (int)a.Q.row_stride, wave, L, dh, lane);
   own_load(graw, tile_of(a.dO, r, h), (int)a.dO.row_stride, wave, L, dh, lane);
-  f32x4 dQT[4];
+  f32x4 dQT[MCT];
 #pragma unroll
-  for (int mc = 0; mc < 4; ++mc) dQT[mc] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int mc = 0; mc < MCT; ++mc) dQT[mc] = f32x4{0.f, 0.f, 0.f, 0.f};
   const FragAddr fa = frag_addr(lane);
-  StageOffs<VEC, NT> lo;
-  xstage_offsets<VEC, NT>(lo, tid);
+  StageOffs<VEC, NT, KS> lo;
+  xstage_offsets<VEC, NT, KS>(lo, tid);
 
-  StageX<VEC, NT> st;
+  StageX<VEC, NT, KS> st;
   float pos_next = 0.f;                      // STATS: CSC position (int bits) in the window's weight slot
-  const StageSrc sq_ = stage_src<VEC, NT>((int)a.K.row_stride, (int)a.V.row_stride, L, dh, tid);
+  const StageSrc sq_ = stage_src<VEC, NT, KS>((int)a.K.row_stride, (int)a.V.row_stride, L, dh, tid);
   auto fetch = [&](int p) {
     const int64_t s = idxwin_get<STATS>(win, a.idx, wts, p, end, lane, &pos_next);
-    xstage_load<VEC, NT>(st, tile_of(a.K, s, h), tile_of(a.V, s, h), sq_, L);
+    xstage_load<VEC, NT, KS>(st, tile_of(a.K, s, h), tile_of(a.V, s, h), sq_, L);
   };
   if (beg < end) fetch(beg);
-  lds_zero_tail<VEC, NT, 4>(lds, L, tid);
-  Frag2 qf[2], gf[2];
+  lds_zero_tail<VEC, NT, KS, 4>(lds, L, tid);
+  Frag2 qf[KS], gf[KS];
   own_split_h(qf, qraw, sq);
   own_split_h(gf, graw, inv * sg);
   // dS = P (dP' - delta'), |dP'_ij| <= |dO'_i| |V'_j|: this wave's dO' rows, any V' row
@@ -1026,7 +1039,7 @@ __global__ __launch_bounds__(64 * NT, AMPCONV_XH_DST_WAVES) void bwd_dst_xh(XArg
   __syncthreads();
   constexpr int LS = 16 * NT;
   for (int p = beg; p < end; ++p) {
-    xstage_store_h<VEC, NT>(Kt, Vt, st, lo, sq, sq, L);
+    xstage_store_h<VEC, NT, KS>(Kt, Vt, st, lo, sq, sq, L);
     float *sb = nullptr;
     if (STATS) sb = a.stats + ((int64_t)__builtin_bit_cast(int, pos_next) * a.H + h) * (2 * LS);
     if (p + 1 < end) fetch(p + 1);
@@ -1037,7 +1050,7 @@ __global__ __launch_bounds__(64 * NT, AMPCONV_XH_DST_WAVES) void bwd_dst_xh(XArg
     for (int t = 0; t < NT; ++t) {
       S[t] = dP[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
+      for (int ks = 0; ks < KS; ++ks) {
         S[t] = mfma3h(rowfrag2<PB>(Kt, fa.a[ks], t), qf[ks], S[t]);
         dP[t] = mfma3h(rowfrag2<PB>(Vt, fa.a[ks], t), gf[ks], dP[t]);
       }
@@ -1061,7 +1074,7 @@ __global__ __launch_bounds__(64 * NT, AMPCONV_XH_DST_WAVES) void bwd_dst_xh(XArg
     }
     Frag2 sf[NPAIR];
 #pragma unroll
-    for (int mb = 0; mb < 4 / MCB; ++mb) {
+    for (int mb = 0; mb < MCT / MCB; ++mb) {
       X3_PRE_READ();
       Frag2 kc[MCB][NPAIR];
 #pragma unroll
@@ -1081,14 +1094,15 @@ __global__ __launch_bounds__(64 * NT, AMPCONV_XH_DST_WAVES) void bwd_dst_xh(XArg
     __syncthreads();
   }
   // partial tiles of a long row leave in the units the combine pass expects (it applies 1 / sqrt(dh))
-  const float mx = store_x3<VEC>(a.O, onode, h, dQT, (a.hub.mode == 2 ? 1.f : a.oscale) * (((uq * uq) * ug) * usd), wave, L, dh,
+  const float mx = store_x3<VEC, MCT>(a.O, onode, h, dQT, (a.hub.mode == 2 ? 1.f : a.oscale) * (((uq * uq) * ug) * usd), wave, L, dh,
                                  lane);
   if (a.absmax) wave_record_absmax(a.absmax, mx);
 }
 
 // ---------------------------------------------------------------- backward, source pass (scaled; needs the statistics)
-template <int VEC, int NT>
+template <int VEC, int NT, int KS>
 __global__ __launch_bounds__(64 * NT, AMPCONV_XH_SRC_WAVES) void bwd_src_xh(XArgs a) {
+  constexpr int MCT = 2 * KS;
   constexpr int PB = 16 * NT * kRowB, TB = 2 * PB, NPAIR = (NT + 1) / 2;
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1104,30 +1118,30 @@ __global__ __launch_bounds__(64 * NT, AMPCONV_XH_SRC_WAVES) void bwd_src_xh(XArg
 
   IdxWindow win;
   if (beg < end) idxwin_load<true>(win, a.idx, a.cinv, beg, end, lane);
-  OwnRaw kraw, vraw;
+  OwnRaw<KS> kraw, vraw;
   own_load(kraw, tile_of(a.K, s, h), (int)a.K.row_stride, wave, L, dh, lane);
   own_load(vraw, tile_of(a.V, s, h), (int)a.V.row_stride, wave, L, dh, lane);
-  f32x4 dKT[4], dVT[4];
+  f32x4 dKT[MCT], dVT[MCT];
 #pragma unroll
-  for (int mc = 0; mc < 4; ++mc) dKT[mc] = dVT[mc] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int mc = 0; mc < MCT; ++mc) dKT[mc] = dVT[mc] = f32x4{0.f, 0.f, 0.f, 0.f};
   const FragAddr fa = frag_addr(lane);
-  StageOffs<VEC, NT> lo;
-  xstage_offsets<VEC, NT>(lo, tid);
+  StageOffs<VEC, NT, KS> lo;
+  xstage_offsets<VEC, NT, KS>(lo, tid);
 
-  StageX<VEC, NT> st;
+  StageX<VEC, NT, KS> st;
   float inv_next = 0.f;
   constexpr int LS = 16 * NT;
   float *sl = reinterpret_cast<float *>(lds + 2 * TB);
   float stat_next = 0.f;
-  const StageSrc sq_ = stage_src<VEC, NT>((int)a.Q.row_stride, (int)a.dO.row_stride, L, dh, tid);
+  const StageSrc sq_ = stage_src<VEC, NT, KS>((int)a.Q.row_stride, (int)a.dO.row_stride, L, dh, tid);
   auto fetch = [&](int p) {
     const int64_t d = idxwin_get<true>(win, a.idx, a.cinv, p, end, lane, &inv_next);
     if (tid < 2 * LS) stat_next = a.stats[((int64_t)p * a.H + h) * (2 * LS) + tid];
-    xstage_load<VEC, NT>(st, tile_of(a.Q, d, h), tile_of(a.dO, d, h), sq_, L);
+    xstage_load<VEC, NT, KS>(st, tile_of(a.Q, d, h), tile_of(a.dO, d, h), sq_, L);
   };
   if (beg < end) fetch(beg);
-  lds_zero_tail<VEC, NT, 4>(lds, L, tid);
-  Frag2 kf[2], vf[2];
+  lds_zero_tail<VEC, NT, KS, 4>(lds, L, tid);
+  Frag2 kf[KS], vf[KS];
   own_split_h(kf, kraw, sq);
   own_split_h(vf, vraw, sq);
   // |dP'_ij| <= |dO'_i| |V'_j|: any dO' row (its elements are bounded by the recorded maximum), this wave's V' rows
@@ -1135,7 +1149,7 @@ __global__ __launch_bounds__(64 * NT, AMPCONV_XH_SRC_WAVES) void bwd_src_xh(XArg
   __syncthreads();
   const bool colok = n + 16 * wave < L;      // this lane's source token exists
   for (int p = beg; p < end; ++p) {
-    xstage_store_h<VEC, NT>(Qt, Gt, st, lo, sq, inv_next * sg, L);
+    xstage_store_h<VEC, NT, KS>(Qt, Gt, st, lo, sq, inv_next * sg, L);
     if (tid < 2 * LS) sl[tid] = stat_next;
     if (p + 1 < end) fetch(p + 1);
     __syncthreads();
@@ -1155,7 +1169,7 @@ __global__ __launch_bounds__(64 * NT, AMPCONV_XH_SRC_WAVES) void bwd_src_xh(XArg
           const f32x4 d4 = *reinterpret_cast<const f32x4 *>(sl + LS + 16 * t + 4 * g);
           f32x4 S = f32x4{0.f, 0.f, 0.f, 0.f}, dP = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int ks = 0; ks < 2; ++ks) {
+          for (int ks = 0; ks < KS; ++ks) {
             S = mfma3h(rowfrag2<PB>(Qt, fa.a[ks], t), kf[ks], S);
             dP = mfma3h(rowfrag2<PB>(Gt, fa.a[ks], t), vf[ks], dP);
           }
@@ -1169,7 +1183,7 @@ __global__ __launch_bounds__(64 * NT, AMPCONV_XH_SRC_WAVES) void bwd_src_xh(XArg
       }
       Frag2 pf, sf;
 #pragma unroll
-      for (int mc = 0; mc < 4; ++mc) {
+      for (int mc = 0; mc < MCT; ++mc) {
         X3_PRE_READ();
         const Frag2 gc = colfrag2<NT, PB>(Gt, fa.tr[mc], i), qc = colfrag2<NT, PB>(Qt, fa.tr[mc], i);
         if (mc == 0) {
@@ -1189,7 +1203,7 @@ __global__ __launch_bounds__(64 * NT, AMPCONV_XH_SRC_WAVES) void bwd_src_xh(XArg
       const f32x4 d4 = *reinterpret_cast<const f32x4 *>(sl + LS + 16 * t + 4 * g);
       f32x4 S = f32x4{0.f, 0.f, 0.f, 0.f}, dP = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
+      for (int ks = 0; ks < KS; ++ks) {
         S = mfma3h(rowfrag2<PB>(Qt, fa.a[ks], t), kf[ks], S);
         dP = mfma3h(rowfrag2<PB>(Gt, fa.a[ks], t), vf[ks], dP);
       }
@@ -1202,7 +1216,7 @@ __global__ __launch_bounds__(64 * NT, AMPCONV_XH_SRC_WAVES) void bwd_src_xh(XArg
     }
     Frag2 pf[NPAIR], sf[NPAIR];
 #pragma unroll
-    for (int mc = 0; mc < 4; ++mc) {
+    for (int mc = 0; mc < MCT; ++mc) {
       X3_PRE_READ();
       Frag2 gc[NPAIR], qc[NPAIR];
 #pragma unroll
@@ -1227,29 +1241,34 @@ __global__ __launch_bounds__(64 * NT, AMPCONV_XH_SRC_WAVES) void bwd_src_xh(XArg
 #endif
     __syncthreads();
   }
-  float mx = store_x3<VEC>(a.dK, onode, h, dKT, (a.hub.mode == 2 ? 1.f : a.oscale) * (((uq * uq) * ug) * usd), wave, L, dh, lane);
-  mx = fmaxf(mx, store_x3<VEC>(a.dV, onode, h, dVT, kPUnscaleX * ug, wave, L, dh, lane));
+  float mx = store_x3<VEC, MCT>(a.dK, onode, h, dKT, (a.hub.mode == 2 ? 1.f : a.oscale) * (((uq * uq) * ug) * usd), wave, L, dh, lane);
+  mx = fmaxf(mx, store_x3<VEC, MCT>(a.dV, onode, h, dVT, kPUnscaleX * ug, wave, L, dh, lane));
   if (a.absmax) wave_record_absmax(a.absmax, mx);
 }
 
 typedef void (*X3Kernel)(XArgs);
-template <template <int, int> class F>
-X3Kernel x3_pick(int vec, int ntok) {
+template <template <int, int, int> class F, int KS>
+X3Kernel x3_pick_ks(int vec, int ntok) {
   switch (ntok) {
-    case 1: return vec == 4 ? F<4, 1>::get() : F<2, 1>::get();
-    case 2: return vec == 4 ? F<4, 2>::get() : F<2, 2>::get();
-    case 3: return vec == 4 ? F<4, 3>::get() : F<2, 3>::get();
-    default: return vec == 4 ? F<4, 4>::get() : F<2, 4>::get();
+    case 1: return vec == 4 ? F<4, 1, KS>::get() : F<2, 1, KS>::get();
+    case 2: return vec == 4 ? F<4, 2, KS>::get() : F<2, 2, KS>::get();
+    case 3: return vec == 4 ? F<4, 3, KS>::get() : F<2, 3, KS>::get();
+    default: return vec == 4 ? F<4, 4, KS>::get() : F<2, 4, KS>::get();
   }
 }
-template <int VEC, int NT> struct XFwd { static X3Kernel get() { return fwd_x3<VEC, NT>; } };
-template <int VEC, int NT> struct XDstS { static X3Kernel get() { return bwd_dst_x3<VEC, true, NT>; } };
-template <int VEC, int NT> struct XDst { static X3Kernel get() { return bwd_dst_x3<VEC, false, NT>; } };
-template <int VEC, int NT> struct XSrc { static X3Kernel get() { return bwd_src_x3<VEC, NT>; } };
-template <int VEC, int NT> struct HFwd { static X3Kernel get() { return fwd_xh<VEC, NT>; } };
-template <int VEC, int NT> struct HDstS { static X3Kernel get() { return bwd_dst_xh<VEC, true, NT>; } };
-template <int VEC, int NT> struct HDst { static X3Kernel get() { return bwd_dst_xh<VEC, false, NT>; } };
-template <int VEC, int NT> struct HSrc { static X3Kernel get() { return bwd_src_xh<VEC, NT>; } };
+// ks = k-steps of 32 channels: 1 for dh <= 32, 2 for dh <= 64
+template <template <int, int, int> class F>
+X3Kernel x3_pick(int vec, int ntok, int ks) {
+  return ks == 1 ? x3_pick_ks<F, 1>(vec, ntok) : x3_pick_ks<F, 2>(vec, ntok);
+}
+template <int VEC, int NT, int KS> struct XFwd { static X3Kernel get() { return fwd_x3<VEC, NT, KS>; } };
+template <int VEC, int NT, int KS> struct XDstS { static X3Kernel get() { return bwd_dst_x3<VEC, true, NT, KS>; } };
+template <int VEC, int NT, int KS> struct XDst { static X3Kernel get() { return bwd_dst_x3<VEC, false, NT, KS>; } };
+template <int VEC, int NT, int KS> struct XSrc { static X3Kernel get() { return bwd_src_x3<VEC, NT, KS>; } };
+template <int VEC, int NT, int KS> struct HFwd { static X3Kernel get() { return fwd_xh<VEC, NT, KS>; } };
+template <int VEC, int NT, int KS> struct HDstS { static X3Kernel get() { return bwd_dst_xh<VEC, true, NT, KS>; } };
+template <int VEC, int NT, int KS> struct HDst { static X3Kernel get() { return bwd_dst_xh<VEC, false, NT, KS>; } };
+template <int VEC, int NT, int KS> struct HSrc { static X3Kernel get() { return bwd_src_xh<VEC, NT, KS>; } };
 
 int launch_x3(const XArgs &a, int ntok, X3Kernel k, hipStream_t stream, int extra_bytes = 0, int planes = 3) {
   const int64_t nb = xcd_grid(a.n_units, a.H);
@@ -1277,7 +1296,7 @@ bool ampconv_block_x3_supported(int L, int D, int H, bool bf16) {
     return !(e && e[0] == '0');
   }();
   const int dh = D / H;
-  return on && !bf16 && L >= 1 && L <= 64 && dh > 32 && dh <= 64 && dh % 2 == 0;
+  return on && !bf16 && L >= 1 && L <= 64 && dh >= 2 && dh <= 64 && dh % 2 == 0;
 }
 
 int ampconv_fwd_edge_block_x3(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V, const int32_t *rowptr,
@@ -1287,8 +1306,8 @@ int ampconv_fwd_edge_block_x3(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t
   a.hub = hub;
   a.Q = Q; a.K = K; a.V = V; a.O = O;
   a.ptr = rowptr; a.idx = col; a.qidx = qidx;
-  const int ntok = (L + 15) / 16;
-  return launch_x3(a, ntok, x3_pick<XFwd>(vec, ntok), stream);
+  const int ntok = (L + 15) / 16, ks = a.dh > 32 ? 2 : 1;
+  return launch_x3(a, ntok, x3_pick<XFwd>(vec, ntok, ks), stream);
 }
 
 int ampconv_bwd_edge_dst_block_x3(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V, ampconv_view_t dO,
@@ -1299,8 +1318,8 @@ int ampconv_bwd_edge_dst_block_x3(ampconv_view_t Q, ampconv_view_t K, ampconv_vi
   a.Q = Q; a.K = K; a.V = V; a.dO = dO; a.O = dQ;
   a.ptr = rowptr; a.idx = col; a.spos = sa.spos; a.stats = sa.stats;
   a.oscale = 1.f / sqrtf((float)a.dh);
-  const int ntok = (L + 15) / 16;
-  return launch_x3(a, ntok, sa.stats ? x3_pick<XDstS>(vec, ntok) : x3_pick<XDst>(vec, ntok), stream);
+  const int ntok = (L + 15) / 16, ks = a.dh > 32 ? 2 : 1;
+  return launch_x3(a, ntok, sa.stats ? x3_pick<XDstS>(vec, ntok, ks) : x3_pick<XDst>(vec, ntok, ks), stream);
 }
 
 int ampconv_bwd_edge_src_block_x3(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V, ampconv_view_t dO,
@@ -1313,8 +1332,8 @@ int ampconv_bwd_edge_src_block_x3(ampconv_view_t Q, ampconv_view_t K, ampconv_vi
   a.Q = Q; a.K = K; a.V = V; a.dO = dO; a.dK = dK; a.dV = dV;
   a.ptr = cscptr; a.idx = crow; a.cinv = cinv; a.stats = const_cast<float *>(stats);
   a.oscale = 0.6931471805599453f;       // dK = ln2 * sum dS^T (Q * log2e / sqrt(dh))
-  const int ntok = (L + 15) / 16;
-  return launch_x3(a, ntok, x3_pick<XSrc>(vec, ntok), stream, 2 * 16 * ntok * (int)sizeof(float));
+  const int ntok = (L + 15) / 16, ks = a.dh > 32 ? 2 : 1;
+  return launch_x3(a, ntok, x3_pick<XSrc>(vec, ntok, ks), stream, 2 * 16 * ntok * (int)sizeof(float));
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1344,7 +1363,8 @@ int x3_check(int64_t n, int L, int D, int H, const float *bounds) {
 extern "C" int ampconv_scaled_supported(int L, int D, int H) {
   if (L < 1 || D < 1 || H < 1 || D % H != 0) return 0;
   const int dh = D / H;
-  return L <= 64 && dh > 32 && dh <= 64 && dh % 2 == 0;
+  if (L <= 20 && (dh == 32 || dh == 16)) return 0;      // the one-wave-per-unit kernels' shapes (plane format / edge_mfma.hip)
+  return L <= 64 && dh >= 2 && dh <= 64 && dh % 2 == 0;
 }
 
 extern "C" int ampconv_fwd_edge_scaled(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V, const int32_t *rowptr,
@@ -1354,7 +1374,7 @@ extern "C" int ampconv_fwd_edge_scaled(ampconv_view_t Q, ampconv_view_t K, ampco
   if (int rc = x3_check(n_rows, L, D, H, bounds)) return rc;
   if (n_rows == 0) return AMPCONV_OK;
   const ampconv_view_t views[] = {Q, K, V, O};
-  const int vec = x3_vec(views, 4, D / H), ntok = (L + 15) / 16;
+  const int vec = x3_vec(views, 4, D / H), ntok = (L + 15) / 16, ks = D / H > 32 ? 2 : 1;
   if (vec < 2 || !rowptr) return AMPCONV_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
   XArgs a = x3_args(n_rows, L, D, H);
@@ -1362,17 +1382,17 @@ extern "C" int ampconv_fwd_edge_scaled(ampconv_view_t Q, ampconv_view_t K, ampco
   a.ptr = rowptr; a.idx = col; a.bounds = bounds;
   if (hub_plan && hub_chunks > 0 && hub_ws) {          // long segments: main + hub + combine
     a.hub = HubArgs{(const int32_t *)hub_plan, 1};
-    if (int rc = launch_x3(a, ntok, x3_pick<HFwd>(vec, ntok), st, 0, 2)) return rc;
+    if (int rc = launch_x3(a, ntok, x3_pick<HFwd>(vec, ntok, ks), st, 0, 2)) return rc;
     const ampconv_view_t P = x3_partial_view(hub_ws, 0, hub_chunks, L, D, H);
     a.O = P;
     a.hub.mode = 2;
     a.n_units = hub_chunks * H;
     const ampconv_view_t pviews[] = {Q, K, V, P};
     const int pvec = x3_vec(pviews, 4, D / H);
-    if (int rc = launch_x3(a, ntok, x3_pick<HFwd>(pvec, ntok), st, 0, 2)) return rc;
+    if (int rc = launch_x3(a, ntok, x3_pick<HFwd>(pvec, ntok, ks), st, 0, 2)) return rc;
     return ampconv_hub_combine(hub_plan, hub_chunks, (const float *)P.ptr, O, rowptr, L, D, H, 1.f, 0, st);
   }
-  return launch_x3(a, ntok, x3_pick<HFwd>(vec, ntok), st, 0, 2);
+  return launch_x3(a, ntok, x3_pick<HFwd>(vec, ntok, ks), st, 0, 2);
 }
 
 extern "C" int ampconv_bwd_edge_dst_scaled(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V, ampconv_view_t dObar,
@@ -1384,7 +1404,7 @@ extern "C" int ampconv_bwd_edge_dst_scaled(ampconv_view_t Q, ampconv_view_t K, a
   if (stats && (!spos || (uintptr_t)stats % 16 != 0)) return AMPCONV_E_BADARG;
   if (n_rows == 0) return AMPCONV_OK;
   const ampconv_view_t views[] = {Q, K, V, dObar, dQ};
-  const int vec = x3_vec(views, 5, D / H), ntok = (L + 15) / 16;
+  const int vec = x3_vec(views, 5, D / H), ntok = (L + 15) / 16, ks = D / H > 32 ? 2 : 1;
   if (vec < 2 || !rowptr) return AMPCONV_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
   XArgs a = x3_args(n_rows, L, D, H);
@@ -1392,7 +1412,7 @@ extern "C" int ampconv_bwd_edge_dst_scaled(ampconv_view_t Q, ampconv_view_t K, a
   a.ptr = rowptr; a.idx = col; a.bounds = bounds; a.absmax = out_absmax;
   a.spos = spos; a.stats = stats;
   a.oscale = 1.f / sqrtf((float)a.dh);
-  auto pick = [&](int v) { return stats ? x3_pick<HDstS>(v, ntok) : x3_pick<HDst>(v, ntok); };
+  auto pick = [&](int v) { return stats ? x3_pick<HDstS>(v, ntok, ks) : x3_pick<HDst>(v, ntok, ks); };
   if (hub_plan && hub_chunks > 0 && hub_ws) {
     a.hub = HubArgs{(const int32_t *)hub_plan, 1};
     if (int rc = launch_x3(a, ntok, pick(vec), st, 0, 2)) return rc;
@@ -1417,7 +1437,7 @@ extern "C" int ampconv_bwd_edge_src_scaled(ampconv_view_t Q, ampconv_view_t K, a
   if (!stats || (uintptr_t)stats % 16 != 0 || !cinv) return AMPCONV_E_BADARG;      // this pass exists only with the hand-off
   if (n_src == 0) return AMPCONV_OK;
   const ampconv_view_t views[] = {Q, K, V, dObar, dK, dV};
-  const int vec = x3_vec(views, 6, D / H), ntok = (L + 15) / 16;
+  const int vec = x3_vec(views, 6, D / H), ntok = (L + 15) / 16, ks = D / H > 32 ? 2 : 1;
   if (vec < 2 || !cscptr) return AMPCONV_E_BADARG;
   hipStream_t st = (hipStream_t)stream;
   XArgs a = x3_args(n_src, L, D, H);
@@ -1428,7 +1448,7 @@ extern "C" int ampconv_bwd_edge_src_scaled(ampconv_view_t Q, ampconv_view_t K, a
   const int extra = 2 * 16 * ntok * (int)sizeof(float);
   if (hub_plan && hub_chunks > 0 && hub_ws) {
     a.hub = HubArgs{(const int32_t *)hub_plan, 1};
-    if (int rc = launch_x3(a, ntok, x3_pick<HSrc>(vec, ntok), st, extra, 2)) return rc;
+    if (int rc = launch_x3(a, ntok, x3_pick<HSrc>(vec, ntok, ks), st, extra, 2)) return rc;
     const ampconv_view_t PK = x3_partial_view(hub_ws, 0, hub_chunks, L, D, H), PV = x3_partial_view(hub_ws, 1, hub_chunks, L, D, H);
     a.dK = PK;
     a.dV = PV;
@@ -1436,10 +1456,10 @@ extern "C" int ampconv_bwd_edge_src_scaled(ampconv_view_t Q, ampconv_view_t K, a
     a.hub.mode = 2;
     a.n_units = hub_chunks * H;
     const ampconv_view_t pviews[] = {Q, K, V, dObar, PK, PV};
-    if (int rc = launch_x3(a, ntok, x3_pick<HSrc>(x3_vec(pviews, 6, D / H), ntok), st, extra, 2)) return rc;
+    if (int rc = launch_x3(a, ntok, x3_pick<HSrc>(x3_vec(pviews, 6, D / H), ntok, ks), st, extra, 2)) return rc;
     if (int rc = ampconv_hub_combine(hub_plan, hub_chunks, (const float *)PK.ptr, dK, nullptr, L, D, H, a.oscale, 0, st, out_absmax))
       return rc;
     return ampconv_hub_combine(hub_plan, hub_chunks, (const float *)PV.ptr, dV, nullptr, L, D, H, 1.f, 0, st, out_absmax);
   }
-  return launch_x3(a, ntok, x3_pick<HSrc>(vec, ntok), st, extra, 2);
+  return launch_x3(a, ntok, x3_pick<HSrc>(vec, ntok, ks), st, extra, 2);
 }

@@ -218,8 +218,9 @@ int ampconv_bwd_edge_src_planes(ampconv_view_t Q, ampconv_view_t K, ampconv_view
 
 /* ---- edge phase on fp32 VIEWS with operand bounds: the workgroup-per-unit shapes off the FP32 pipe (csrc/edge_block_x3.hip,
  * ABI 107) ----------------------------------------------------------------------------------------------------------
- * The same three passes for L <= 64, even 32 < dh <= 64 (the reference's AMPGCN class defaults L = 40, D = 100, H = 2:
- * src/ampnet/module/amp_gcn.py:21-35) on plain fp32 views -- what ampconv_fwd_edge / _bwd_edge_dst / _bwd_edge_src take --
+ * The same three passes for L <= 64 and even dh <= 64 outside the one-wave-per-unit kernels' shapes (L <= 20 with dh = 32 or
+ * 16) -- the reference's AMPGCN class defaults L = 40, D = 100, H = 2 (src/ampnet/module/amp_gcn.py:21-35), or 40 tokens at
+ * its 128 / 4 -- on plain fp32 views -- what ampconv_fwd_edge / _bwd_edge_dst / _bwd_edge_src take --
  * plus the `bounds` of the plane-format entry points above: bounds[0] >= max |Q|K|V|, bounds[1] >= max |dObar|,
  * bounds[2] >= max |V|, bounds[3] >= max |dObar| (device, 4 floats; the forward pass reads bounds[0] only).  With them
  * the kernels split every fp32 tile, on its way into LDS, into TWO fp16 planes of x * 2^(14 - floor(log2 bound)) and

@@ -1,4 +1,4 @@
-"""GPU parity of the workgroup-per-unit edge kernels off the FP32 pipe (csrc/edge_block_x3.hip): 32 < dh <= 64, L <= 64,
+"""GPU parity of the workgroup-per-unit edge kernels off the FP32 pipe (csrc/edge_block_x3.hip): even dh <= 64, L <= 64,
 fp32 storage -- the reference's AMPGCN class defaults L = 40, D = 100, H = 2 (src/ampnet/module/amp_gcn.py:21-35).
 Two arithmetic variants behind two sets of entry points:
   * ampconv_fwd_edge / _bwd_edge_dst / _bwd_edge_src (no bounds): three bf16 planes, six partial products;
@@ -27,8 +27,10 @@ def dev():
 
 
 SHAPES = [(500, 5000, 40, 100, 2), (400, 4000, 24, 128, 2), (300, 2500, 64, 128, 2), (400, 3000, 33, 72, 2),
-          (300, 2500, 7, 100, 2), (300, 2500, 16, 68, 2)]
-IDS = ['class_default_L40_dh50', 'L24_dh64', 'L64_dh64', 'L33_dh36', 'L7_dh50', 'L16_dh34']
+          (300, 2500, 7, 100, 2), (300, 2500, 16, 68, 2), (400, 4000, 40, 128, 4), (300, 2500, 33, 40, 2),
+          (300, 2500, 24, 64, 4), (300, 2500, 12, 48, 2)]
+IDS = ['class_default_L40_dh50', 'L24_dh64', 'L64_dh64', 'L33_dh36', 'L7_dh50', 'L16_dh34', 'L40_dh32', 'L33_dh20',
+       'L24_dh16', 'L12_dh24']
 
 
 @pytest.mark.parametrize('shape', SHAPES, ids=IDS)
@@ -138,7 +140,8 @@ def test_block_scaled_entry_points_reject_what_they_do_not_serve(dev):
     from ampnet_amd import _lib
     lib = _lib.load()
     assert lib.ampconv_scaled_supported(40, 100, 2) == 1 and lib.ampconv_scaled_supported(64, 128, 2) == 1
-    assert lib.ampconv_scaled_supported(20, 256, 8) == 0       # dh = 32: the plane-format kernels' shape
+    assert lib.ampconv_scaled_supported(20, 256, 8) == 0       # L <= 20, dh = 32: the plane-format kernels' shape
+    assert lib.ampconv_scaled_supported(40, 128, 4) == 1 and lib.ampconv_scaled_supported(20, 40, 2) == 1     # dh <= 32 otherwise
     assert lib.ampconv_scaled_supported(65, 100, 2) == 0 and lib.ampconv_scaled_supported(40, 102, 2) == 0     # L > 64, odd dh
     x = torch.zeros(40 * 300, device=dev)
     v = _lib.View(x.data_ptr(), 40 * 100, 100, 50)
@@ -228,14 +231,14 @@ def test_wide_gradient_leaves_the_scaled_block_path_in_backward_only(dev, monkey
 
 @pytest.mark.parametrize('seed', range(10))
 def test_random_shapes_scaled_vs_generic(seed, dev, monkeypatch):
-    """Random small problems of this family's shapes (L in 1..64, even dh in 34..64), degenerate graphs included, through
+    """Random small problems of this family's shapes (L in 5..64, even dh up to 64 outside 16 / 32), degenerate graphs included, through
     the bound-carrying entry points, against the fp64 oracle at the flat tolerance and against the independent shape-generic kernels."""
     from ampnet_amd import AMPConv, graph_cache
     from ampnet_amd.conv import functional as F_
     rng = np.random.default_rng(7000 + seed)
-    dh = int(rng.choice([34, 36, 40, 48, 50, 56, 62, 64]))
+    dh = int(rng.choice([34, 36, 40, 48, 50, 56, 62, 64, 6, 12, 20, 24, 28]))
     H = int(rng.choice([1, 2, 3]))
-    L = int(rng.integers(1, 65))
+    L = int(rng.integers(5, 65))
     D = dh * H
     N = int(rng.integers(1, 300))
     kind = seed % 5

@@ -42,8 +42,8 @@ def main():
                 kg, q, pp = l >> 4, (l >> 2) & 3, l & 3
                 return xoff(16 * t + 4 * kg + q, 2 * mc + (pp >> 1)) + ((pp & 1) << 3)
             print(f'token-product fragment, token tile {t}, channel tile {mc}: ds_read_b64_tr_b16 worst {worst(HALVES, addr, 8)}')
-    for vec, nt in ((2, 3), (4, 3), (2, 4), (2, 1)):
-        dvp, nthr = 64 // vec, 64 * nt
+    for vec, nt, ks in ((2, 3, 2), (4, 3, 2), (2, 4, 2), (2, 1, 2), (2, 3, 1), (4, 3, 1), (2, 2, 1), (4, 1, 1)):
+        dvp, nthr = 32 * ks // vec, 64 * nt           # ks = k-steps of 32 channels: dh <= 32 stages half rows
         rs = nthr // dvp
         for wave in range(nt):
             def addr(l, wave=wave):
@@ -52,7 +52,7 @@ def main():
                 c = cv * vec
                 return xoff(r0, c >> 3) + (c & 7) * 2
             groups = HALVES if vec == 2 else [list(range(8 * k, 8 * k + 8)) for k in range(8)]
-            print(f'staging store, {vec}-float vectors, {nt} waves (rows per pass {rs}), wave {wave}: worst '
+            print(f'staging store, {vec}-float vectors, {nt} waves, {32 * ks} channels (rows per pass {rs}), wave {wave}: worst '
                   f'{worst(groups, addr, 2 * vec, 64 if vec == 2 else 32)}')
 
 
