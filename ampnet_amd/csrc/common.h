@@ -176,19 +176,19 @@ int ampconv_bwd_edge_src_block(ampconv_view_t Q, ampconv_view_t K, ampconv_view_
                                int L, int D, int H, ampconv_view_t dK, ampconv_view_t dV, HubArgs hub,
                                const float *stats, bool bf16, hipStream_t stream);
 
-// ---- the same path with 32 < dh <= 64, fp32 storage, on the 16-bit matrix pipe (edge_block_x3.hip: three bf16 planes per
-// fp32 value, six partial products); `vec` = vec_of() of the views (4 or 2 floats)
+// ---- the same path on the 16-bit matrix pipe (edge_block_x3.hip: fp32 rows as three bf16 planes per value, six partial
+// products; bf16 rows as they lie, one product); `vec` = vec_of() of the views (4 or 2 elements)
 bool ampconv_block_x3_supported(int L, int D, int H, bool bf16);
 int ampconv_fwd_edge_block_x3(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V, const int32_t *rowptr,
                               const int32_t *col, const int32_t *qidx, int64_t n_rows, int L, int D, int H,
-                              ampconv_view_t O, HubArgs hub, int vec, hipStream_t stream);
+                              ampconv_view_t O, HubArgs hub, int vec, bool bf16, hipStream_t stream);
 int ampconv_bwd_edge_dst_block_x3(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V, ampconv_view_t dO,
                                   const int32_t *rowptr, const int32_t *col, int64_t n_rows, int L, int D, int H,
-                                  ampconv_view_t dQ, HubArgs hub, StatsArgs sa, int vec, hipStream_t stream);
+                                  ampconv_view_t dQ, HubArgs hub, StatsArgs sa, int vec, bool bf16, hipStream_t stream);
 int ampconv_bwd_edge_src_block_x3(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V, ampconv_view_t dO,
                                   const int32_t *cscptr, const int32_t *crow, const float *cinv, int64_t n_src, int L,
                                   int D, int H, ampconv_view_t dK, ampconv_view_t dV, HubArgs hub, const float *stats,
-                                  int vec, hipStream_t stream);
+                                  int vec, bool bf16, hipStream_t stream);
 
 // ---- short token sequences (edge_small.hip): L <= 4, one wave per row, VALU only, fp32; views aligned to the lane's
 // vector width.  No softmax statistics.

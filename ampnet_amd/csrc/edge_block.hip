@@ -577,7 +577,7 @@ int ampconv_fwd_edge_block(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V,
   const ampconv_view_t views[] = {Q, K, V, O};
   const int vec = vec_of(views, 4, a.dh, bf16 ? 2 : 4), dhp = a.dh > 32 ? 64 : 32;
   if (ampconv_block_x3_supported(L, D, H, bf16))
-    return ampconv_fwd_edge_block_x3(Q, K, V, rowptr, col, qidx, n_rows, L, D, H, O, hub, vec, stream);
+    return ampconv_fwd_edge_block_x3(Q, K, V, rowptr, col, qidx, n_rows, L, D, H, O, hub, vec, bf16, stream);
   return launch_block(a, dhp, KernelTable<FwdK>::get(dhp, vec, a.ntok), stream);
 }
 
@@ -592,7 +592,7 @@ int ampconv_bwd_edge_dst_block(ampconv_view_t Q, ampconv_view_t K, ampconv_view_
   const ampconv_view_t views[] = {Q, K, V, dO, dQ};
   const int vec = vec_of(views, 5, a.dh, bf16 ? 2 : 4), dhp = a.dh > 32 ? 64 : 32;
   if (ampconv_block_x3_supported(L, D, H, bf16))
-    return ampconv_bwd_edge_dst_block_x3(Q, K, V, dO, rowptr, col, n_rows, L, D, H, dQ, hub, sa, vec, stream);
+    return ampconv_bwd_edge_dst_block_x3(Q, K, V, dO, rowptr, col, n_rows, L, D, H, dQ, hub, sa, vec, bf16, stream);
   return launch_block(a, dhp, sa.stats ? KernelTable<DstKS>::get(dhp, vec, a.ntok) : KernelTable<DstK>::get(dhp, vec, a.ntok),
                       stream);
 }
@@ -610,6 +610,6 @@ int ampconv_bwd_edge_src_block(ampconv_view_t Q, ampconv_view_t K, ampconv_view_
   const ampconv_view_t views[] = {Q, K, V, dO, dK, dV};
   const int vec = vec_of(views, 6, a.dh, bf16 ? 2 : 4), dhp = a.dh > 32 ? 64 : 32;
   if (ampconv_block_x3_supported(L, D, H, bf16))
-    return ampconv_bwd_edge_src_block_x3(Q, K, V, dO, cscptr, crow, cinv, n_src, L, D, H, dK, dV, hub, stats, vec, stream);
+    return ampconv_bwd_edge_src_block_x3(Q, K, V, dO, cscptr, crow, cinv, n_src, L, D, H, dK, dV, hub, stats, vec, bf16, stream);
   return launch_block(a, dhp, KernelTable<SrcK>::get(dhp, vec, a.ntok), stream, 2 * 16 * a.ntok);
 }

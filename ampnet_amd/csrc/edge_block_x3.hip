@@ -1246,6 +1246,408 @@ __global__ __launch_bounds__(64 * NT, AMPCONV_XH_SRC_WAVES) void bwd_src_xh(XArg
   if (a.absmax) wave_record_absmax(a.absmax, mx);
 }
 
+// =====================================================================================================================
+// bf16 STORAGE (dtype AMPCONV_BF16) on the same structure: the rows are 16-bit already, so a tile is ONE plane copied into
+// LDS as it stands and every product is one v_mfma_f32_16x16x32_bf16; softmax weights and dS are rounded to bf16 for their
+// second product (the accuracy class of this storage mode: rtol 2e-2; edge_mfma_bf16.hip does the same),
+// accumulators, softmax and delta stay fp32.  Nothing is pre-scaled (that would round the operands again): the scores meet
+// log2e / sqrt(dh) inside the exponential, 1 / in-degree is applied to dS and to the weights that multiply dObar, and
+// delta is handed over in the units of the raw dObar V^T product.  Views: strides in bf16 elements, bases and strides
+// even (4-byte pieces) at least.  These kernels replace the fp32-MFMA kernels of edge_block.hip for bf16 rows.
+template <int EV, int NT, int KS>
+struct StageB {                                             // EV = bf16 elements per lane and load (2 or 4)
+  static constexpr int DVP = 32 * KS / EV;
+  static constexpr int RS = 64 * NT / DVP;
+  static constexpr int NP = (16 * NT + RS - 1) / RS;
+  int v[2][NP][EV / 2];
+};
+template <int EV, int NT, int KS>
+__device__ __forceinline__ StageSrc stage_src_b(int sA, int sB, int L, int dh, int tid) {
+  using S = StageB<EV, NT, KS>;
+  const int cv = tid % S::DVP, r0 = tid / S::DVP, c = cv * EV;
+  StageSrc q;
+  q.voA = c < dh ? (unsigned)(r0 * sA + c) * 2u : 0x80000000u;
+  q.voB = c < dh ? (unsigned)(r0 * sB + c) * 2u : 0x80000000u;
+  q.stepA = S::RS * sA * 2;
+  q.stepB = S::RS * sB * 2;
+  q.nrecA = ((L - 1) * sA + dh) * 2;
+  q.nrecB = ((L - 1) * sB + dh) * 2;
+  return q;
+}
+template <int EV, int NT, int KS>
+__device__ __forceinline__ void bstage_load(StageB<EV, NT, KS> &s, const void *A, const void *B, const StageSrc &q, int L) {
+  using S = StageB<EV, NT, KS>;
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(A), 0, q.nrecA, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(B), 0, q.nrecB, 0x00020000);
+#pragma unroll
+  for (int i = 0; i < S::NP; ++i) {
+    if (i * S::RS < L) {
+      if constexpr (EV == 4) {
+        const i32x2 x = __builtin_bit_cast(i32x2, __builtin_amdgcn_raw_buffer_load_b64(ra, q.voA, i * q.stepA, 0));
+        const i32x2 y = __builtin_bit_cast(i32x2, __builtin_amdgcn_raw_buffer_load_b64(rb, q.voB, i * q.stepB, 0));
+        s.v[0][i][0] = x[0]; s.v[0][i][1] = x[1];
+        s.v[1][i][0] = y[0]; s.v[1][i][1] = y[1];
+      } else {
+        s.v[0][i][0] = (int)__builtin_amdgcn_raw_buffer_load_b32(ra, q.voA, i * q.stepA, 0);
+        s.v[1][i][0] = (int)__builtin_amdgcn_raw_buffer_load_b32(rb, q.voB, i * q.stepB, 0);
+      }
+    }
+  }
+}
+template <int EV, int NT, int KS>
+__device__ __forceinline__ void bstage_offsets(int (&lo)[8], int tid) {
+  using S = StageB<EV, NT, KS>;
+  static_assert(S::NP <= 8, "passes");
+  const int cv = tid % S::DVP, r0 = tid / S::DVP, c = cv * EV;
+#pragma unroll
+  for (int i = 0; i < S::NP; ++i) lo[i] = xoff(r0 + i * S::RS, c >> 3) + (c & 7) * 2;
+}
+template <int EV, int NT, int KS>
+__device__ __forceinline__ void bstage_store(char *imgA, char *imgB, const StageB<EV, NT, KS> &s, const int (&lo)[8], int L) {
+  using S = StageB<EV, NT, KS>;
+#pragma unroll
+  for (int i = 0; i < S::NP; ++i) {
+    if (i * S::RS < L) {
+      if constexpr (EV == 4) {
+        *reinterpret_cast<i32x2 *>(imgA + lo[i]) = i32x2{s.v[0][i][0], s.v[0][i][1]};
+        *reinterpret_cast<i32x2 *>(imgB + lo[i]) = i32x2{s.v[1][i][0], s.v[1][i][1]};
+      } else {
+        *reinterpret_cast<int *>(imgA + lo[i]) = s.v[0][i][0];
+        *reinterpret_cast<int *>(imgB + lo[i]) = s.v[1][i][0];
+      }
+    }
+  }
+}
+template <int EV, int NT, int KS>
+__device__ __forceinline__ void lds_zero_tail_b(char *p, int L, int tid) {
+  using S = StageB<EV, NT, KS>;
+  constexpr int PB = 16 * NT * kRowB;
+  const int zr = ((L + S::RS - 1) / S::RS) * S::RS, nrow = 16 * NT - zr;
+  for (int i = tid; i < 2 * nrow * (kRowB / 16); i += 64 * NT) {
+    const int plane = i / (nrow * (kRowB / 16)), rem = i - plane * (nrow * (kRowB / 16));
+    *reinterpret_cast<i32x4 *>(p + plane * PB + zr * kRowB + rem * 16) = i32x4{0, 0, 0, 0};
+  }
+}
+// the unit's own side: lane (n, kg) = the 8 bf16 channels 32 ks + 8 kg .. + 7 of token 16 wave + n, as they lie in memory
+template <int KS>
+__device__ __forceinline__ void own_frags_b(i32x4 (&f)[KS], const unsigned short *base, int row_stride, int wave, int L, int dh,
+                                            int lane) {
+  const int n = lane & 15, kg = lane >> 4, j = 16 * wave + n;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    int w[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int c = 32 * ks + 8 * kg + 2 * u;
+      w[u] = (j < L && c < dh) ? *reinterpret_cast<const int *>(base + j * row_stride + c) : 0;
+    }
+    f[ks] = i32x4{w[0], w[1], w[2], w[3]};
+  }
+}
+__device__ __forceinline__ const unsigned short *tile_of_b(const ampconv_view_t &v, int64_t n, int h) {
+  return reinterpret_cast<const unsigned short *>(v.ptr) + n * v.node_stride + (int64_t)h * v.head_stride;
+}
+template <int PB>
+__device__ __forceinline__ i32x4 rowfrag1(const char *img, int aks, int t) {
+  return *reinterpret_cast<const i32x4 *>(img + aks + t * kTileRowsB);
+}
+template <int NT>
+__device__ __forceinline__ i32x4 colfrag1(const char *img, int trb, int pair) {
+  const char *p = img + trb + 2 * pair * kTileRowsB;
+  const i32x2 a = tr64(p), b = 2 * pair + 1 < NT ? tr64(p + kTileRowsB) : a;
+  return i32x4{a[0], a[1], b[0], b[1]};
+}
+template <int NT>
+__device__ __forceinline__ i32x4 cd_frag1(const f32x4 (&T)[NT], int pair) {
+  const f32x4 a = T[2 * pair];
+  int h2 = 0, h3 = 0;
+  if (2 * pair + 1 < NT) {
+    const f32x4 b = T[2 * pair + 1 < NT ? 2 * pair + 1 : 0];
+    h2 = pk_bf(b[0], b[1]);
+    h3 = pk_bf(b[2], b[3]);
+  }
+  return i32x4{pk_bf(a[0], a[1]), pk_bf(a[2], a[3]), h2, h3};
+}
+// output tile -> bf16 rows (main pass) or fp32 partial tiles (long-segment pass)
+template <int EV, int MCT>
+__device__ __forceinline__ void store_xb(const ampconv_view_t &v, int64_t node, int h, const f32x4 (&T)[MCT], float scale, int tile,
+                                         int L, int dh, int lane, bool bf) {
+  if (!bf) {
+    store_x3<2, MCT>(v, node, h, T, scale, tile, L, dh, lane);
+    return;
+  }
+  const int i = (lane & 15) + 16 * tile, g = lane >> 4;
+  if (i >= L) return;
+  unsigned short *row = reinterpret_cast<unsigned short *>(v.ptr) + node * v.node_stride + (int64_t)h * v.head_stride +
+                        (int64_t)i * v.row_stride;
+#pragma unroll
+  for (int mc = 0; mc < MCT; ++mc) {
+    const int c = 16 * mc + 4 * g;
+    const int p0 = pk_bf(T[mc][0] * scale, T[mc][1] * scale), p1 = pk_bf(T[mc][2] * scale, T[mc][3] * scale);
+    if constexpr (EV == 4) {
+      if (c < dh) *reinterpret_cast<i32x2 *>(row + c) = i32x2{p0, p1};
+    } else {
+      if (c < dh) *reinterpret_cast<int *>(row + c) = p0;
+      if (c + 2 < dh) *reinterpret_cast<int *>(row + c + 2) = p1;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- forward (bf16 storage)
+template <int EV, int NT, int KS>
+__global__ __launch_bounds__(64 * NT, 4) void fwd_xb(XArgs a) {
+  constexpr int MCT = 2 * KS;
+  constexpr int PB = 16 * NT * kRowB, NPAIR = (NT + 1) / 2;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int64_t r, onode;
+  int h, beg, end, deg;
+  const int64_t unit = xcd_unit(blockIdx.x, a.n_units, a.H);
+  if (unit < 0 || !map_unit(a.hub, a.ptr, unit, a.n_units, a.H, r, onode, h, beg, end, deg)) return;
+  const int L = a.L, dh = a.dh, g = lane >> 4;
+  char *Kt = lds, *Vt = lds + PB;
+  const int64_t d = a.qidx ? a.qidx[r] : r;
+
+  IdxWindow win;
+  if (beg < end) idxwin_load<false>(win, a.idx, nullptr, beg, end, lane);
+  i32x4 qf[KS];
+  own_frags_b<KS>(qf, tile_of_b(a.Q, d, h), (int)a.Q.row_stride, wave, L, dh, lane);
+  f32x4 OT[MCT];
+#pragma unroll
+  for (int mc = 0; mc < MCT; ++mc) OT[mc] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const FragAddr fa = frag_addr(lane);
+  int lo[8];
+  bstage_offsets<EV, NT, KS>(lo, tid);
+  StageB<EV, NT, KS> st;
+  const StageSrc sq = stage_src_b<EV, NT, KS>((int)a.K.row_stride, (int)a.V.row_stride, L, dh, tid);
+  auto fetch = [&](int p) {
+    const int64_t s = idxwin_get<false>(win, a.idx, nullptr, p, end, lane, nullptr);
+    bstage_load<EV, NT, KS>(st, tile_of_b(a.K, s, h), tile_of_b(a.V, s, h), sq, L);
+  };
+  if (beg < end) fetch(beg);
+  lds_zero_tail_b<EV, NT, KS>(lds, L, tid);
+  __syncthreads();
+  for (int p = beg; p < end; ++p) {
+    bstage_store<EV, NT, KS>(Kt, Vt, st, lo, L);
+    if (p + 1 < end) fetch(p + 1);
+    __syncthreads();
+
+    f32x4 S[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      S[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) S[t] = MFMA_X3(rowfrag1<PB>(Kt, fa.a[ks], t), qf[ks], S[t]);
+    }
+    xh_column_softmax<NT>(S, a.qscale, 1.f, L, g);
+    i32x4 pf[NPAIR];
+    X3_PRE_READ();
+    i32x4 vc[MCT][NPAIR];
+#pragma unroll
+    for (int mc = 0; mc < MCT; ++mc)
+#pragma unroll
+      for (int i = 0; i < NPAIR; ++i) vc[mc][i] = colfrag1<NT>(Vt, fa.tr[mc], i);
+#pragma unroll
+    for (int i = 0; i < NPAIR; ++i) pf[i] = cd_frag1<NT>(S, i);
+    X3_FRAG_FENCE();
+#pragma unroll
+    for (int mc = 0; mc < MCT; ++mc)
+#pragma unroll
+      for (int i = 0; i < NPAIR; ++i) OT[mc] = MFMA_X3(vc[mc][i], pf[i], OT[mc]);
+    __syncthreads();
+  }
+  store_xb<EV, MCT>(a.O, onode, h, OT, a.hub.mode == 2 ? 1.f : (deg > 0 ? 1.f / (float)deg : 0.f), wave, L, dh, lane,
+                    a.hub.mode != 2);
+}
+
+// ---------------------------------------------------------------- backward, destination pass (bf16 storage)
+template <int EV, bool STATS, int NT, int KS>
+__global__ __launch_bounds__(64 * NT, 3) void bwd_dst_xb(XArgs a) {
+  constexpr int MCT = 2 * KS;
+  constexpr int PB = 16 * NT * kRowB, NPAIR = (NT + 1) / 2;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int64_t r, onode;
+  int h, beg, end, deg;
+  const int64_t unit = xcd_unit(blockIdx.x, a.n_units, a.H);
+  if (unit < 0 || !map_unit(a.hub, a.ptr, unit, a.n_units, a.H, r, onode, h, beg, end, deg)) return;
+  const int L = a.L, dh = a.dh, g = lane >> 4;
+  char *Kt = lds, *Vt = lds + PB;
+  const float inv = deg > 0 ? 1.f / (float)deg : 0.f;       // dO is the gradient of the MEAN
+
+  IdxWindow win;
+  const float *wts = reinterpret_cast<const float *>(a.spos);
+  if (beg < end) idxwin_load<STATS>(win, a.idx, wts, beg, end, lane);
+  i32x4 qf[KS], gf[KS];
+  own_frags_b<KS>(qf, tile_of_b(a.Q, r, h), (int)a.Q.row_stride, wave, L, dh, lane);
+  own_frags_b<KS>(gf, tile_of_b(a.dO, r, h), (int)a.dO.row_stride, wave, L, dh, lane);
+  f32x4 dQT[MCT];
+#pragma unroll
+  for (int mc = 0; mc < MCT; ++mc) dQT[mc] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const FragAddr fa = frag_addr(lane);
+  int lo[8];
+  bstage_offsets<EV, NT, KS>(lo, tid);
+  StageB<EV, NT, KS> st;
+  float pos_next = 0.f;
+  const StageSrc sq = stage_src_b<EV, NT, KS>((int)a.K.row_stride, (int)a.V.row_stride, L, dh, tid);
+  auto fetch = [&](int p) {
+    const int64_t s = idxwin_get<STATS>(win, a.idx, wts, p, end, lane, &pos_next);
+    bstage_load<EV, NT, KS>(st, tile_of_b(a.K, s, h), tile_of_b(a.V, s, h), sq, L);
+  };
+  if (beg < end) fetch(beg);
+  lds_zero_tail_b<EV, NT, KS>(lds, L, tid);
+  __syncthreads();
+  constexpr int LS = 16 * NT;
+  for (int p = beg; p < end; ++p) {
+    bstage_store<EV, NT, KS>(Kt, Vt, st, lo, L);
+    float *sb = nullptr;
+    if (STATS) sb = a.stats + ((int64_t)__builtin_bit_cast(int, pos_next) * a.H + h) * (2 * LS);
+    if (p + 1 < end) fetch(p + 1);
+    __syncthreads();
+
+    f32x4 S[NT], dP[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      S[t] = dP[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        S[t] = MFMA_X3(rowfrag1<PB>(Kt, fa.a[ks], t), qf[ks], S[t]);
+        dP[t] = MFMA_X3(rowfrag1<PB>(Vt, fa.a[ks], t), gf[ks], dP[t]);
+      }
+    }
+    const float lse2 = xh_column_softmax<NT>(S, a.qscale, 1.f, L, g);
+    float part = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) part = fmaf(S[t][q], dP[t][q], part);
+    }
+    const float delta = groups_sum(part);            // in the units of the raw dObar V^T product (no 1 / in-degree)
+    if (STATS && g == 0) {
+      sb[(lane & 15) + 16 * wave] = lse2;
+      sb[LS + (lane & 15) + 16 * wave] = delta;
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) S[t][q] *= (dP[t][q] - delta) * inv;       // dS
+    }
+    i32x4 sf[NPAIR];
+    X3_PRE_READ();
+    i32x4 kc[MCT][NPAIR];
+#pragma unroll
+    for (int mc = 0; mc < MCT; ++mc)
+#pragma unroll
+      for (int i = 0; i < NPAIR; ++i) kc[mc][i] = colfrag1<NT>(Kt, fa.tr[mc], i);
+#pragma unroll
+    for (int i = 0; i < NPAIR; ++i) sf[i] = cd_frag1<NT>(S, i);
+    X3_FRAG_FENCE();
+#pragma unroll
+    for (int mc = 0; mc < MCT; ++mc)
+#pragma unroll
+      for (int i = 0; i < NPAIR; ++i) dQT[mc] = MFMA_X3(kc[mc][i], sf[i], dQT[mc]);
+    __syncthreads();
+  }
+  store_xb<EV, MCT>(a.O, onode, h, dQT, a.hub.mode == 2 ? 1.f : a.oscale, wave, L, dh, lane, a.hub.mode != 2);
+}
+
+// ---------------------------------------------------------------- backward, source pass (bf16 storage; needs the statistics)
+template <int EV, int NT, int KS>
+__global__ __launch_bounds__(64 * NT, 3) void bwd_src_xb(XArgs a) {
+  constexpr int MCT = 2 * KS;
+  constexpr int PB = 16 * NT * kRowB, NPAIR = (NT + 1) / 2;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int64_t s, onode;
+  int h, beg, end, deg;
+  const int64_t unit = xcd_unit(blockIdx.x, a.n_units, a.H);
+  if (unit < 0 || !map_unit(a.hub, a.ptr, unit, a.n_units, a.H, s, onode, h, beg, end, deg)) return;
+  const int L = a.L, dh = a.dh, g = lane >> 4, n = lane & 15;
+  char *Qt = lds, *Gt = lds + PB;
+
+  IdxWindow win;
+  if (beg < end) idxwin_load<true>(win, a.idx, a.cinv, beg, end, lane);
+  i32x4 kf[KS], vf[KS];
+  own_frags_b<KS>(kf, tile_of_b(a.K, s, h), (int)a.K.row_stride, wave, L, dh, lane);
+  own_frags_b<KS>(vf, tile_of_b(a.V, s, h), (int)a.V.row_stride, wave, L, dh, lane);
+  f32x4 dKT[MCT], dVT[MCT];
+#pragma unroll
+  for (int mc = 0; mc < MCT; ++mc) dKT[mc] = dVT[mc] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const FragAddr fa = frag_addr(lane);
+  int lo[8];
+  bstage_offsets<EV, NT, KS>(lo, tid);
+  StageB<EV, NT, KS> st;
+  float inv_next = 0.f, inv_cur = 0.f;
+  constexpr int LS = 16 * NT;
+  float *sl = reinterpret_cast<float *>(lds + 2 * PB);
+  float stat_next = 0.f;
+  const StageSrc sq = stage_src_b<EV, NT, KS>((int)a.Q.row_stride, (int)a.dO.row_stride, L, dh, tid);
+  auto fetch = [&](int p) {
+    const int64_t d = idxwin_get<true>(win, a.idx, a.cinv, p, end, lane, &inv_next);
+    if (tid < 2 * LS) stat_next = a.stats[((int64_t)p * a.H + h) * (2 * LS) + tid];
+    bstage_load<EV, NT, KS>(st, tile_of_b(a.Q, d, h), tile_of_b(a.dO, d, h), sq, L);
+  };
+  if (beg < end) fetch(beg);
+  lds_zero_tail_b<EV, NT, KS>(lds, L, tid);
+  __syncthreads();
+  const bool colok = n + 16 * wave < L;
+  for (int p = beg; p < end; ++p) {
+    bstage_store<EV, NT, KS>(Qt, Gt, st, lo, L);
+    if (tid < 2 * LS) sl[tid] = stat_next;
+    inv_cur = inv_next;                              // 1 / in-degree of THIS edge's destination (fetch overwrites inv_next)
+    if (p + 1 < end) fetch(p + 1);
+    __syncthreads();
+
+#pragma unroll
+    for (int i = 0; i < NPAIR; ++i) {
+      f32x4 P[2], dS[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int t = 2 * i + u;
+        P[u] = dS[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (t < NT) {
+          const f32x4 l4 = *reinterpret_cast<const f32x4 *>(sl + 16 * t + 4 * g);
+          const f32x4 d4 = *reinterpret_cast<const f32x4 *>(sl + LS + 16 * t + 4 * g);
+          f32x4 S = f32x4{0.f, 0.f, 0.f, 0.f}, dP = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            S = MFMA_X3(rowfrag1<PB>(Qt, fa.a[ks], t), kf[ks], S);
+            dP = MFMA_X3(rowfrag1<PB>(Gt, fa.a[ks], t), vf[ks], dP);
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float pr = colok ? fast_exp2(fmaf(S[q], a.qscale, -l4[q])) * inv_cur : 0.f;      // P / in-degree
+            P[u][q] = pr;
+            dS[u][q] = pr * (dP[q] - d4[q]);
+          }
+        }
+      }
+      i32x4 pf, sf;
+#pragma unroll
+      for (int mc = 0; mc < MCT; ++mc) {
+        X3_PRE_READ();
+        const i32x4 gc = colfrag1<NT>(Gt, fa.tr[mc], i), qc = colfrag1<NT>(Qt, fa.tr[mc], i);
+        if (mc == 0) {
+          pf = cd_frag1<2>(P, 0);
+          sf = cd_frag1<2>(dS, 0);
+        }
+        X3_FRAG_FENCE();
+        dVT[mc] = MFMA_X3(gc, pf, dVT[mc]);
+        dKT[mc] = MFMA_X3(qc, sf, dKT[mc]);
+      }
+    }
+    __syncthreads();
+  }
+  const bool bf = a.hub.mode != 2;
+  // (partial tiles of a long column: the combine pass of this family multiplies dK by ln 2 -- its fp32 kernels carry
+  // log2e / sqrt(dh) in Q --, so they leave with log2e / sqrt(dh) here)
+  store_xb<EV, MCT>(a.dK, onode, h, dKT, a.hub.mode == 2 ? a.oscale * kLog2eX : a.oscale, wave, L, dh, lane, bf);
+  store_xb<EV, MCT>(a.dV, onode, h, dVT, 1.f, wave, L, dh, lane, bf);
+}
+
 typedef void (*X3Kernel)(XArgs);
 template <template <int, int, int> class F, int KS>
 X3Kernel x3_pick_ks(int vec, int ntok) {
@@ -1269,6 +1671,10 @@ template <int VEC, int NT, int KS> struct HFwd { static X3Kernel get() { return 
 template <int VEC, int NT, int KS> struct HDstS { static X3Kernel get() { return bwd_dst_xh<VEC, true, NT, KS>; } };
 template <int VEC, int NT, int KS> struct HDst { static X3Kernel get() { return bwd_dst_xh<VEC, false, NT, KS>; } };
 template <int VEC, int NT, int KS> struct HSrc { static X3Kernel get() { return bwd_src_xh<VEC, NT, KS>; } };
+template <int VEC, int NT, int KS> struct BFwd { static X3Kernel get() { return fwd_xb<VEC, NT, KS>; } };
+template <int VEC, int NT, int KS> struct BDstS { static X3Kernel get() { return bwd_dst_xb<VEC, true, NT, KS>; } };
+template <int VEC, int NT, int KS> struct BDst { static X3Kernel get() { return bwd_dst_xb<VEC, false, NT, KS>; } };
+template <int VEC, int NT, int KS> struct BSrc { static X3Kernel get() { return bwd_src_xb<VEC, NT, KS>; } };
 
 int launch_x3(const XArgs &a, int ntok, X3Kernel k, hipStream_t stream, int extra_bytes = 0, int planes = 3) {
   const int64_t nb = xcd_grid(a.n_units, a.H);
@@ -1296,36 +1702,39 @@ bool ampconv_block_x3_supported(int L, int D, int H, bool bf16) {
     return !(e && e[0] == '0');
   }();
   const int dh = D / H;
-  return on && !bf16 && L >= 1 && L <= 64 && dh >= 2 && dh <= 64 && dh % 2 == 0;
+  (void)bf16;       // fp32 rows: three bf16 planes split in the kernel; bf16 rows: one plane as it lies
+  return on && L >= 1 && L <= 64 && dh >= 2 && dh <= 64 && dh % 2 == 0;
 }
 
 int ampconv_fwd_edge_block_x3(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V, const int32_t *rowptr,
                               const int32_t *col, const int32_t *qidx, int64_t n_rows, int L, int D, int H,
-                              ampconv_view_t O, HubArgs hub, int vec, hipStream_t stream) {
+                              ampconv_view_t O, HubArgs hub, int vec, bool bf16, hipStream_t stream) {
   XArgs a = x3_args(n_rows, L, D, H);
   a.hub = hub;
   a.Q = Q; a.K = K; a.V = V; a.O = O;
   a.ptr = rowptr; a.idx = col; a.qidx = qidx;
   const int ntok = (L + 15) / 16, ks = a.dh > 32 ? 2 : 1;
+  if (bf16) return launch_x3(a, ntok, x3_pick<BFwd>(vec, ntok, ks), stream, 0, 1);
   return launch_x3(a, ntok, x3_pick<XFwd>(vec, ntok, ks), stream);
 }
 
 int ampconv_bwd_edge_dst_block_x3(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V, ampconv_view_t dO,
                                   const int32_t *rowptr, const int32_t *col, int64_t n_rows, int L, int D, int H,
-                                  ampconv_view_t dQ, HubArgs hub, StatsArgs sa, int vec, hipStream_t stream) {
+                                  ampconv_view_t dQ, HubArgs hub, StatsArgs sa, int vec, bool bf16, hipStream_t stream) {
   XArgs a = x3_args(n_rows, L, D, H);
   a.hub = hub;
   a.Q = Q; a.K = K; a.V = V; a.dO = dO; a.O = dQ;
   a.ptr = rowptr; a.idx = col; a.spos = sa.spos; a.stats = sa.stats;
   a.oscale = 1.f / sqrtf((float)a.dh);
   const int ntok = (L + 15) / 16, ks = a.dh > 32 ? 2 : 1;
+  if (bf16) return launch_x3(a, ntok, sa.stats ? x3_pick<BDstS>(vec, ntok, ks) : x3_pick<BDst>(vec, ntok, ks), stream, 0, 1);
   return launch_x3(a, ntok, sa.stats ? x3_pick<XDstS>(vec, ntok, ks) : x3_pick<XDst>(vec, ntok, ks), stream);
 }
 
 int ampconv_bwd_edge_src_block_x3(ampconv_view_t Q, ampconv_view_t K, ampconv_view_t V, ampconv_view_t dO,
                                   const int32_t *cscptr, const int32_t *crow, const float *cinv, int64_t n_src, int L,
                                   int D, int H, ampconv_view_t dK, ampconv_view_t dV, HubArgs hub, const float *stats,
-                                  int vec, hipStream_t stream) {
+                                  int vec, bool bf16, hipStream_t stream) {
   if (!stats) return AMPCONV_E_BADARG;
   XArgs a = x3_args(n_src, L, D, H);
   a.hub = hub;
@@ -1333,6 +1742,10 @@ int ampconv_bwd_edge_src_block_x3(ampconv_view_t Q, ampconv_view_t K, ampconv_vi
   a.ptr = cscptr; a.idx = crow; a.cinv = cinv; a.stats = const_cast<float *>(stats);
   a.oscale = 0.6931471805599453f;       // dK = ln2 * sum dS^T (Q * log2e / sqrt(dh))
   const int ntok = (L + 15) / 16, ks = a.dh > 32 ? 2 : 1;
+  if (bf16) {                           // (Q enters unscaled there: dK = sum dS^T Q / sqrt(dh))
+    a.oscale = 1.f / sqrtf((float)a.dh);
+    return launch_x3(a, ntok, x3_pick<BSrc>(vec, ntok, ks), stream, 2 * 16 * ntok * (int)sizeof(float), 1);
+  }
   return launch_x3(a, ntok, x3_pick<XSrc>(vec, ntok, ks), stream, 2 * 16 * ntok * (int)sizeof(float));
 }
 

@@ -189,6 +189,12 @@ def test_register_budgets_of_the_kernels_that_must_not_spill():
         assert len(ks) == variants, (name, ks)
         for k in ks:
             assert usage[k]['spill'] == 0 and usage[k]['vgprs'] <= budget, (k, usage[k])
+    # ... and the single-plane kernels of bf16 storage on the same structure
+    for name, budget, variants in (('fwd_xb', 128, 16), ('bwd_dst_xb', 168, 32), ('bwd_src_xb', 168, 16)):
+        ks = [k for k in usage if name in k]
+        assert len(ks) == variants, (name, ks)
+        for k in ks:
+            assert usage[k]['spill'] == 0 and usage[k]['vgprs'] <= budget, (k, usage[k])
     hot = [k for k in usage if ('bwd_src_mfma_t4ILi32ELb1ELb1E' in k or 'bwd_dst_mfma_t4ILi32ELb1ELb1ELb1E' in k
                                 or 'fwd_mfma_t4ILi32ELb1ELb1E' in k)]
     assert len(hot) == 3, hot
