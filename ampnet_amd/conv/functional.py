@@ -359,7 +359,7 @@ class AMPConvFunction(torch.autograd.Function):
             if not ((dh in (16, 32) and L <= 20) or (dh % 2 == 0 and dh <= 64 and L <= 64)):
                 raise ValueError(f'bf16 storage is implemented for head dimensions 32 and 16 with at most 20 tokens per '
                                  f'node (csrc/edge_mfma_bf16.hip; BASELINE configs 5 and 3) and for even head dimensions '
-                                 f'up to 64 with at most 64 tokens (csrc/edge_block.hip: fp32 arithmetic on bf16 rows); '
+                                 f'up to 64 with at most 64 tokens (csrc/edge_block_x3.hip: the workgroup-per-unit kernels on bf16 rows); '
                                  f'got head dimension {dh}, {L} tokens: use float32 for this shape')
         Nq, Nk = xq.size(0), xkv.size(0)
         xq2 = xq.contiguous().view(Nq * L, D)

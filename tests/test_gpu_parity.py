@@ -546,7 +546,7 @@ def test_training_steps_match_cpu_reference(dev):
 def test_random_shapes_mfma_vs_generic(seed, family, dev, monkeypatch):
     """Random small problems, degenerate graphs included: the MFMA kernels and the independent
     shape-generic kernels must agree on y and every gradient.  'wave' = edge_mfma.hip shapes
-    (L in 1..20, dh in {16, 32}), 'block' = edge_block.hip shapes (L in 1..64, even dh <= 64,
+    (L in 1..20, dh in {16, 32}), 'block' = the workgroup-per-unit shapes of edge_block_x3.hip (L in 1..64, even dh <= 64,
     e.g. the reference's class defaults L = 40, dh = 50)."""
     from ampnet_amd import AMPConv, graph_cache
     rng = np.random.default_rng(1000 + seed + (500 if family == 'block' else 0))
@@ -642,7 +642,7 @@ def test_softmax_stats_rejected_where_unsupported(dev):
     lib = _lib.load()
     assert lib.ampconv_softmax_stats_bytes(1000, 70, 100, 2, _lib.AMPCONV_F32) == 0       # L > 64
     assert lib.ampconv_softmax_stats_bytes(1000, 2, 3, 1, _lib.AMPCONV_F32) == 0          # odd dh
-    assert lib.ampconv_softmax_stats_bytes(1000, 40, 100, 2, _lib.AMPCONV_F32) == 1000 * 2 * 2 * 48 * 4   # edge_block.hip
+    assert lib.ampconv_softmax_stats_bytes(1000, 40, 100, 2, _lib.AMPCONV_F32) == 1000 * 2 * 2 * 48 * 4   # edge_block_x3.hip
     assert lib.ampconv_softmax_stats_bytes(1000, 20, 256, 8, _lib.AMPCONV_BF16) == 0      # HBM-bound: no gain
 
 
@@ -726,7 +726,7 @@ def test_batched_tail_kernels_large_scores(dev, monkeypatch):
 
 @pytest.mark.parametrize('shape', [(300, 3000, 40, 100, 2), (300, 3000, 24, 128, 2)], ids=['L40_dh50', 'L24_dh64'])
 def test_block_kernels_long_segments(shape, dev, monkeypatch):
-    """Workgroup-per-unit kernels (edge_block.hip) on a graph with a hub destination and a hub source
+    """Workgroup-per-unit kernels (edge_block_x3.hip) on a graph with a hub destination and a hub source
     (segments of ~600 edges, cut into 64-edge chunks -> partial tiles -> ordered combine) against the
     shape-generic kernels, which walk every segment in one piece."""
     from ampnet_amd import AMPConv, graph_cache
