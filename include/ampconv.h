@@ -41,15 +41,17 @@ enum {
 };
 
 /* dtype codes.
- * AMPCONV_F32:  every view is fp32 in HBM; the per-edge products run on v_mfma_f32_16x16x4_f32 (exact fp32,
- *               fmaf-chain numerics), the per-node projections (ampconv_proj_*) on the bf16 matrix cores with every
- *               fp32 operand split exactly into three bf16 terms (fp32-grade error).
+ * AMPCONV_F32:  every view is fp32 in HBM; the per-edge products of the one-wave-per-unit shapes (L <= 20, dh = 32 or 16)
+ *               run on v_mfma_f32_16x16x4_f32 (exact fp32, fmaf-chain numerics), those of the workgroup-per-unit shapes
+ *               (other even dh <= 64, L <= 64) on the 16-bit matrix cores with every fp32 tile split exactly into three
+ *               bf16 planes on its way into LDS (fp32-grade error; csrc/edge_block_x3.hip), the per-node projections
+ *               (ampconv_proj_*) the same way.
  * AMPCONV_BF16: every view is bf16 in HBM (Q/K/V/O and gradients), fp32 softmax and accumulation.
  *               L <= 20 with dh = 32 (BASELINE config 5) or dh = 16 (half-filled tiles): products on the bf16 MFMA,
  *               no softmax statistics.  Other even dh <= 64 with L <= 64 (e.g. the reference's class default L = 40,
- *               dh = 50): the fp32 workgroup-per-unit kernels read / write the bf16 rows themselves (fp32 MFMA
- *               arithmetic); their source pass needs the statistics buffer of ampconv_softmax_stats_bytes like the
- *               fp32 call.  Anything else: AMPCONV_E_DTYPE.
+ *               dh = 50): the workgroup-per-unit kernels on the bf16 rows as they lie (one bf16 MFMA per product,
+ *               softmax weights and dS rounded to bf16 for their second product); their source pass needs the
+ *               statistics buffer of ampconv_softmax_stats_bytes like the fp32 call.  Anything else: AMPCONV_E_DTYPE.
  * (Versions <= 102 had three more codes for split-operand edge kernels; they were slower than the native fp32 MFMA
  * kernels on MI355X and were removed in 103.) */
 enum { AMPCONV_F32 = 0, AMPCONV_BF16 = 1 };
