@@ -87,7 +87,7 @@ def main():
     report('qkv  native', t, 2 * M * D * 3 * D, err(F_.proj_rows(x[:S], img, b_in, amax=ax), ref), err(torch.addmm(b_in, x[:S], w_in.t()), ref),
            nbytes=M * 4 * D * es)
     report('qkv  library (addmm)', timeit_lib(lambda: torch.addmm(b_in, x, w_in.t()), iters), 2 * M * D * 3 * D, nbytes=M * 4 * D * es)
-    if scaled and want('qkv'):      # the same product leaving as two fp16 planes (the format of csrc/edge_mfma_f16x2.hip)
+    if scaled and want('qkv') and D % 128 == 0:      # the same product leaving as two fp16 planes (the format of csrc/edge_mfma_f16x2.hip; embed_dim % 128 == 0)
         bound = torch.empty(1, device=dev)
         F_.proj_out_bound(w_in, False, b_in, ax, bound)
         t = timeit(lambda: F_.proj_rows_planes(x, img, bound, b_in, amax=ax, out_amax=am_out, amax_col0=2 * D), iters)
